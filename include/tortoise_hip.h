@@ -1,0 +1,157 @@
+/*
+ * tortoise_hip.h — C ABI of the MI355X-native batched AL-iLQR attitude-slew solver.
+ *
+ * This is the drop-in boundary for the ONE hot path of RoboticExplorationLab/TortoiseSat.jl:
+ * the `TrajectoryOptimization.solve!(prob, solver)` call of src/TortoiseSat.jl:199 (and the old-API
+ * `solve(solver,U)` of src/monte_carlo.jl:196) together with the dynamics callback it drives
+ * (src/DerivFunction.jl:1-48).  A host (Julia `ccall`, Python `ctypes`, C++) builds the problem exactly
+ * as the reference scripts do and then hands a whole *batch* of independent slews to `tsat_solve_batch`.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes, no callbacks, no torch/HIP types in signatures;
+ *   - every function returns 0 on success, <0 on API error (text via tsat_last_error);
+ *     per-trajectory outcomes are reported in tsat_stats.status, never as an error code;
+ *   - arrays are Julia/Fortran column-major with the component fastest, then knot, then trajectory:
+ *     X is reshape(X,7,N,T); U is reshape(U,3,N-1,T); K is reshape(K,3,7,N-1,T);
+ *   - state x = [omega(3); q(4, scalar first)] — the reference's 8th "time" state
+ *     (src/DerivFunction.jl:6,44) is folded into (tau0, dtau): the B-table row used at knot k, RK stage
+ *     offset c in {0, 1/2, 1} is floor(fma(k + c, dtau, tau0)), clamped to [0, n_tab-1]
+ *     (reference: B_ECI[floor(Int, t*N + 1), :], src/DerivFunction.jl:28);
+ *   - controls are in units of u_scale A*m^2 (u_scale = 1e-2, src/DerivFunction.jl:37);
+ *   - the library is synchronous and keeps no caller pointers after a call returns;
+ *   - one handle per (host thread, GPU). Handles are not thread-safe.
+ *
+ * There is NO CPU fallback behind this ABI: if no gfx950 device is usable, tsat_create fails.
+ */
+#ifndef TORTOISE_HIP_H
+#define TORTOISE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSAT_NX 7 /* omega(3) + quaternion(4)            (src/DerivFunction.jl:4-5)   */
+#define TSAT_NU 3 /* magnetic dipole command (3)         (src/DerivFunction.jl:37)    */
+#define TSAT_NC 6 /* control box rows per knot: u<=uhi, u>=ulo (src/TortoiseSat.jl:178) */
+#define TSAT_MAX_LINESEARCH 32
+
+/* per-trajectory outcome codes (tsat_stats.status) */
+enum {
+  TSAT_CONVERGED = 0,   /* c_max < constraint_tol after an inner solve                       */
+  TSAT_MAX_OUTER = 1,   /* outer budget exhausted (src/TortoiseSat.jl:196 `iterations`)      */
+  TSAT_REG_FAIL  = 2,   /* backward-pass regularisation exceeded reg_max                     */
+  TSAT_DIVERGED  = 3    /* non-finite cost in the initial rollout                            */
+};
+
+/*
+ * Solver options. Replaces AugmentedLagrangianSolverOptions{Float64}() + .opts_uncon
+ * (src/TortoiseSat.jl:194-196) and solver.opts.* of the old API (src/monte_carlo.jl:187-192).
+ * Field defaults (tsat_default_options) follow the published AL-iLQR/ALTRO algorithm, SURVEY.md App. A.
+ */
+typedef struct tsat_options {
+  int32_t n_knots;          /* N, knot points incl. terminal (src/TortoiseSat.jl:85)                */
+  int32_t n_tab;            /* rows in each B table                                                 */
+  int32_t integrator;       /* 3 = rk3 (src/TortoiseSat.jl:146), 4 = rk4 (src/attitude_controller.jl:122) */
+  int32_t precision;        /* 64 (fp64). 32 is reserved.                                           */
+  int32_t max_outer;        /* opts_al.iterations            (src/TortoiseSat.jl:196; 20)           */
+  int32_t max_inner;        /* opts_al.opts_uncon.iterations (src/TortoiseSat.jl:195; 50)           */
+  int32_t max_linesearch;   /* backtracking trials alpha = 2^-j, j < max_linesearch (<= 32)         */
+  int32_t dj_counter_limit; /* solver.opts.dJ_counter_limit  (src/monte_carlo.jl:191)               */
+  double  cost_tol;         /* inner: stop when 0 < dJ < cost_tol                                   */
+  double  grad_tol;         /* inner: stop when mean_k max_i |d|/(|u|+1) < grad_tol                 */
+  double  constraint_tol;   /* outer: stop when c_max < constraint_tol                              */
+  double  penalty_init, penalty_scale, penalty_max, dual_max;
+  double  reg_init, reg_scale, reg_min, reg_max, reg_fp;
+  double  ls_lower, ls_upper;
+  double  max_state;        /* rollout rejected when |x_i| or |u_i| exceeds this                     */
+  double  u_scale;          /* 1e-2 (src/DerivFunction.jl:37)                                        */
+  int32_t terminal_mask;    /* bit i set: state component i has a terminal equality x_N[i]=xf[i]
+                               (goal_constraint, src/TortoiseSat.jl:182,188)                         */
+  int32_t error_state;      /* 0: plain 7-state differences (Model(DerivFunction,8,3), src/TortoiseSat.jl:145)
+                               1: reserved for the quaternion hooks of src/quaternion_toolbox.jl:15-75 */
+} tsat_options;
+
+/* per-trajectory result record */
+typedef struct tsat_stats {
+  int32_t status;       /* TSAT_* code                                                    */
+  int32_t outer_iters;  /* AL outer iterations executed                                   */
+  int32_t inner_iters;  /* total iLQR iterations over all outer iterations                */
+  int32_t ls_trials;    /* line-search candidates a sequential backtracking search would
+                           have rolled out (index of accepted alpha + 1, summed)          */
+  int32_t n_backward;   /* backward sweeps executed (incl. regularisation restarts)       */
+  int32_t n_forward;    /* forward sweeps executed on this backend                        */
+  int32_t bp_restarts;  /* backward sweeps abandoned on a non-PD Quu                      */
+  int32_t fp_fails;     /* line searches in which no alpha was accepted                   */
+  double  cost;         /* LQR objective of the returned trajectory (no AL terms)         */
+  double  cost_al;      /* augmented-Lagrangian cost at exit                              */
+  double  c_max;        /* max constraint violation of the returned trajectory            */
+  double  grad;         /* last Todorov gradient                                          */
+} tsat_stats;
+
+typedef struct tsat_handle tsat_handle;
+
+/* library/ABI version: major*100 + minor */
+int  tsat_version(void);
+
+/* fill *o with defaults (rk3, 20 x 50 budget as src/TortoiseSat.jl:195-196, ALTRO constants) */
+void tsat_default_options(tsat_options* o);
+
+/* open GPU `device_id` (must be a gfx950 device); replaces AugmentedLagrangianSolver(prob,opts)
+ * (src/TortoiseSat.jl:197) as the object that owns solver workspace. */
+int  tsat_create(tsat_handle** h, int device_id);
+int  tsat_destroy(tsat_handle* h);
+const char* tsat_last_error(const tsat_handle* h);
+
+/*
+ * One-call drop-in for solve!(prob, solver) over a batch of T independent slews
+ * (src/TortoiseSat.jl:199; loop body of src/monte_carlo.jl:118-235). Host pointers in, host pointers out.
+ *   x0, xf  7 x T            initial / goal state              (src/TortoiseSat.jl:124,130)
+ *   Btab    3 x n_tab x n_btab  ECI field tables [T]           (global B_ECI, src/TortoiseSat.jl:89)
+ *   btab_idx T (or NULL)     table used by trajectory t (NULL: t, requires n_btab == T)
+ *   tau0, dtau  T            table row of knot 0 and rows per knot (see header comment)
+ *   dt      T                step [s]                          (src/TortoiseSat.jl:84)
+ *   Jmat    9 x T            inertia, column-major 3x3         (src/input_parameters.jl:29-51)
+ *   Qd,Qfd  7 x T, Rd 3 x T  diagonal LQR weights              (src/TortoiseSat.jl:157-169)
+ *   ulo,uhi 3 x T            control box                       (src/TortoiseSat.jl:178)
+ *   U0      3 x (N-1) x T    initial controls                  (initial_controls!, src/TortoiseSat.jl:191)
+ *   X       7 x N x T  out;  U  3 x (N-1) x T out;  K 3 x 7 x (N-1) x T out (may be NULL);  stats T out
+ */
+int  tsat_solve_batch(tsat_handle* h, const tsat_options* o, int64_t T, int64_t n_btab,
+                      const double* x0, const double* xf, const double* Btab, const int32_t* btab_idx,
+                      const double* tau0, const double* dtau, const double* dt, const double* Jmat,
+                      const double* Qd, const double* Qfd, const double* Rd,
+                      const double* ulo, const double* uhi, const double* U0,
+                      double* X, double* U, double* K, tsat_stats* stats);
+
+/*
+ * Resident-batch API (what tsat_solve_batch is made of). Lets a caller keep a batch in HBM, re-run it,
+ * time only the solve, and export results straight into device buffers it owns (e.g. for an RCCL all-gather).
+ */
+int  tsat_batch_reserve(tsat_handle* h, int64_t T, int32_t n_knots, int32_t n_tab, int64_t n_btab,
+                        int32_t max_linesearch);
+int  tsat_batch_upload(tsat_handle* h,
+                       const double* x0, const double* xf, const double* Btab, const int32_t* btab_idx,
+                       const double* tau0, const double* dtau, const double* dt, const double* Jmat,
+                       const double* Qd, const double* Qfd, const double* Rd,
+                       const double* ulo, const double* uhi, const double* U0);
+/* run the solve on the resident batch (always restarts from the uploaded U0); blocks until done.
+ * *kernel_ms (may be NULL) receives the HIP-event time of the solve kernel on the handle's stream. */
+int  tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms);
+/* unpack results to HOST buffers (any may be NULL) */
+int  tsat_batch_download(tsat_handle* h, double* X, double* U, double* K, tsat_stats* stats);
+/* unpack results to DEVICE buffers owned by the caller on the same GPU (any may be NULL); blocks */
+int  tsat_batch_export_device(tsat_handle* h, void* X_dev, void* U_dev, void* K_dev, void* stats_dev);
+/* bytes of HBM currently reserved by the handle */
+int64_t tsat_batch_bytes(const tsat_handle* h);
+/* optional per-iteration trace for debugging parity: rows of 8 doubles
+ * [outer, inner, J_prev, J_new, alpha_index(-1 = none), rho, dV1, dV2], `rows` per trajectory.
+ * Pass rows = 0 to disable. Call before tsat_batch_run; read back with tsat_batch_trace_download. */
+int  tsat_batch_trace(tsat_handle* h, int32_t rows);
+int  tsat_batch_trace_download(tsat_handle* h, double* trace /* 8 x rows x T */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TORTOISE_HIP_H */

@@ -1,0 +1,747 @@
+/*
+ * tsat_oracle.cpp — CPU restatement (fp64, scalar C++) of the TortoiseSat.jl attitude-slew hot path.
+ *
+ * >>> TEST INFRASTRUCTURE ONLY. <<<  Nothing under oracle/ is imported, linked or executed by the product
+ * (tortoisesat.jl_amd/, libtortoise_hip.so). Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may load liboracle.so — as the checker / the CPU baseline, never as the thing shipped.
+ *
+ * >>> PARITY UNPINNED. <<<  The reference repository has no tests, no golden vectors and no fixtures, and no
+ * Julia interpreter exists in the authoring container or on the GPU box, so this restatement cannot be pinned
+ * against outputs of the reference itself.  What IS pinned (tests/test_oracle_*.py): every function whose text
+ * is physically in the reference (A1..A7 below) is checked against an independent NumPy transcription of the
+ * same reference lines, against analytic invariants, and against SciPy's DARE.  The AL-iLQR driver (A10) lives
+ * in the un-vendored dependency TrajectoryOptimization.jl v0.1.2 (Manifest.toml:994-998, git-tree-sha1
+ * b933cc4febea19e643ea6fc4a17dfb53d1f926f3); it is restated here from the published algorithm
+ * (Howell, Jackson, Manchester, "ALTRO", IROS 2019) and anchored on the reference's
+ * call sites (src/TortoiseSat.jl:145-199, src/monte_carlo.jl:158-198).
+ *
+ * Map of functions to reference text:
+ *   A1  orc_qmult/orc_qrot/orc_qinv/orc_hat/orc_gmat   src/DerivFunction.jl:50-56, src/attitude_controller.jl:69,164-176
+ *   A2  orc_deriv8                                      src/DerivFunction.jl:1-48 (8-state, table lookup)
+ *   A3  orc_attitude_dynamics                           src/attitude_dynamics.jl:2-24
+ *   A4  orc_rk_step, orc_rk_generic                     src/attitude_controller.jl:122-132 (rk4), :178-187 (rk3)
+ *   A5  orc_discrete_jacobian                           src/attitude_controller.jl:95-119 (forward-mode duals, as ForwardDiff)
+ *   A6  orc_reduce_error_state, orc_quaternion_error,
+ *       orc_quaternion_expansion                        src/attitude_controller.jl:50-81, src/quaternion_toolbox.jl:15-75
+ *   A7  orc_tvlqr_riccati                               src/attitude_controller.jl:83-92
+ *   A8/A9/A10 orc_solve_batch                           src/TortoiseSat.jl:157-199 + SURVEY.md Appendix A
+ */
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+#include <limits>
+#include <algorithm>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "../include/tortoise_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// forward-mode dual numbers (what ForwardDiff.jacobian! does at src/attitude_controller.jl:103)
+// ------------------------------------------------------------------------------------------------
+template <int NP>
+struct Dual {
+  double v;
+  double p[NP];
+  Dual() : v(0) { for (int i = 0; i < NP; ++i) p[i] = 0; }
+  Dual(double a) : v(a) { for (int i = 0; i < NP; ++i) p[i] = 0; }
+};
+template <int NP> inline Dual<NP> operator+(const Dual<NP>& a, const Dual<NP>& b) { Dual<NP> r; r.v = a.v + b.v; for (int i = 0; i < NP; ++i) r.p[i] = a.p[i] + b.p[i]; return r; }
+template <int NP> inline Dual<NP> operator-(const Dual<NP>& a, const Dual<NP>& b) { Dual<NP> r; r.v = a.v - b.v; for (int i = 0; i < NP; ++i) r.p[i] = a.p[i] - b.p[i]; return r; }
+template <int NP> inline Dual<NP> operator-(const Dual<NP>& a) { Dual<NP> r; r.v = -a.v; for (int i = 0; i < NP; ++i) r.p[i] = -a.p[i]; return r; }
+template <int NP> inline Dual<NP> operator*(const Dual<NP>& a, const Dual<NP>& b) { Dual<NP> r; r.v = a.v * b.v; for (int i = 0; i < NP; ++i) r.p[i] = a.p[i] * b.v + a.v * b.p[i]; return r; }
+template <int NP> inline Dual<NP> operator/(const Dual<NP>& a, const Dual<NP>& b) { Dual<NP> r; r.v = a.v / b.v; for (int i = 0; i < NP; ++i) r.p[i] = (a.p[i] - r.v * b.p[i]) / b.v; return r; }
+template <int NP> inline Dual<NP> operator*(double a, const Dual<NP>& b) { return Dual<NP>(a) * b; }
+template <int NP> inline Dual<NP> operator*(const Dual<NP>& a, double b) { return a * Dual<NP>(b); }
+template <int NP> inline Dual<NP> operator/(const Dual<NP>& a, double b) { return a / Dual<NP>(b); }
+template <int NP> inline Dual<NP> dsqrt(const Dual<NP>& a) { Dual<NP> r; r.v = std::sqrt(a.v); for (int i = 0; i < NP; ++i) r.p[i] = a.p[i] / (2.0 * r.v); return r; }
+inline double dsqrt(double a) { return std::sqrt(a); }
+
+// ------------------------------------------------------------------------------------------------
+// A1: quaternion algebra, scalar-first
+// ------------------------------------------------------------------------------------------------
+template <class S> inline void cross3(const S a[3], const S b[3], S o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// src/DerivFunction.jl:54-56  qmult(q1,q2) = [s1 s2 - v1'v2 ; s1 v2 + s2 v1 + v1 x v2]
+template <class S> inline void qmult(const S q1[4], const S q2[4], S o[4]) {
+  S c[3];
+  cross3(q1 + 1, q2 + 1, c);
+  S s = q1[0] * q2[0] - (q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3]);
+  for (int i = 0; i < 3; ++i) o[i + 1] = q1[0] * q2[i + 1] + q2[0] * q1[i + 1] + c[i];
+  o[0] = s;
+}
+// src/DerivFunction.jl:50-52  qrot(q,r) = r + 2 v x (v x r + s r)
+template <class S> inline void qrot(const S q[4], const S r[3], S o[3]) {
+  S t[3], c[3];
+  cross3(q + 1, r, t);
+  for (int i = 0; i < 3; ++i) t[i] = t[i] + q[0] * r[i];
+  cross3(q + 1, t, c);
+  for (int i = 0; i < 3; ++i) o[i] = r[i] + 2.0 * c[i];
+}
+
+struct Phys {
+  double J[9];     // J(r,c) = J[r + 3c] (column-major, as handed over the ABI)
+  double Jinv[9];  // same layout
+  double u_scale;
+};
+
+// closed-form 3x3 inverse (adjugate); replaces inv(p.J) of src/DerivFunction.jl:41
+void inv3(const double* M, double* Mi) {
+  auto m = [&](int r, int c) { return M[r + 3 * c]; };
+  double c00 = m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1);
+  double c01 = m(1, 2) * m(2, 0) - m(1, 0) * m(2, 2);
+  double c02 = m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0);
+  double det = m(0, 0) * c00 + m(0, 1) * c01 + m(0, 2) * c02;
+  double id = 1.0 / det;
+  Mi[0 + 3 * 0] = c00 * id;
+  Mi[1 + 3 * 0] = c01 * id;
+  Mi[2 + 3 * 0] = c02 * id;
+  Mi[0 + 3 * 1] = (m(0, 2) * m(2, 1) - m(0, 1) * m(2, 2)) * id;
+  Mi[1 + 3 * 1] = (m(0, 0) * m(2, 2) - m(0, 2) * m(2, 0)) * id;
+  Mi[2 + 3 * 1] = (m(0, 1) * m(2, 0) - m(0, 0) * m(2, 1)) * id;
+  Mi[0 + 3 * 2] = (m(0, 1) * m(1, 2) - m(0, 2) * m(1, 1)) * id;
+  Mi[1 + 3 * 2] = (m(0, 2) * m(1, 0) - m(0, 0) * m(1, 2)) * id;
+  Mi[2 + 3 * 2] = (m(0, 0) * m(1, 1) - m(0, 1) * m(1, 0)) * id;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A2/A3: continuous dynamics on the 7-state with the table row `b` already looked up.
+// src/DerivFunction.jl:4-44: q normalised inside f (:5), qdot = 0.5 qmult(q,[0;w]) (:24),
+// B_B = qrot(q, b) (:28), tau_c = cross(u*1e-2, B_B) (:37), wdot = inv(J)(tau_c - w x Jw) (:41).
+// ------------------------------------------------------------------------------------------------
+template <class S>
+void dyn7(const S x[7], const S u[3], const double b[3], const Phys& ph, S xd[7]) {
+  S w[3] = {x[0], x[1], x[2]};
+  S nq = dsqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+  S q[4] = {x[3] / nq, x[4] / nq, x[5] / nq, x[6] / nq};
+  S p[4] = {S(0.0), w[0], w[1], w[2]};
+  S qd[4];
+  qmult(q, p, qd);
+  S bs[3] = {S(b[0]), S(b[1]), S(b[2])};
+  S BB[3];
+  qrot(q, bs, BB);
+  S us[3] = {u[0] * ph.u_scale, u[1] * ph.u_scale, u[2] * ph.u_scale};
+  S tau[3];
+  cross3(us, BB, tau);
+  S Jw[3], wJw[3];
+  for (int r = 0; r < 3; ++r) Jw[r] = ph.J[r + 0] * w[0] + ph.J[r + 3] * w[1] + ph.J[r + 6] * w[2];
+  cross3(w, Jw, wJw);
+  S rhs[3] = {tau[0] - wJw[0], tau[1] - wJw[1], tau[2] - wJw[2]};
+  for (int r = 0; r < 3; ++r) xd[r] = ph.Jinv[r + 0] * rhs[0] + ph.Jinv[r + 3] * rhs[1] + ph.Jinv[r + 6] * rhs[2];
+  for (int i = 0; i < 4; ++i) xd[3 + i] = 0.5 * qd[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// A4: discretisers. b0/b1/b2 = table rows at stage times tau, tau + dtau/2, tau + dtau.
+// rk3: src/attitude_controller.jl:178-187; rk4: :122-132.
+// ------------------------------------------------------------------------------------------------
+template <class S>
+void rk_step(int integ, const S x[7], const S u[3], const double* b0, const double* b1, const double* b2,
+             double h, const Phys& ph, S xn[7]) {
+  S k1[7], k2[7], k3[7], k4[7], t[7];
+  dyn7(x, u, b0, ph, k1);
+  for (int i = 0; i < 7; ++i) { k1[i] = k1[i] * h; t[i] = x[i] + k1[i] / 2.0; }
+  dyn7(t, u, b1, ph, k2);
+  if (integ == 3) {
+    for (int i = 0; i < 7; ++i) { k2[i] = k2[i] * h; t[i] = x[i] - k1[i] + 2.0 * k2[i]; }
+    dyn7(t, u, b2, ph, k3);
+    for (int i = 0; i < 7; ++i) { k3[i] = k3[i] * h; xn[i] = x[i] + (k1[i] + 4.0 * k2[i] + k3[i]) / 6.0; }
+  } else {
+    for (int i = 0; i < 7; ++i) { k2[i] = k2[i] * h; t[i] = x[i] + k2[i] / 2.0; }
+    dyn7(t, u, b1, ph, k3);
+    for (int i = 0; i < 7; ++i) { k3[i] = k3[i] * h; t[i] = x[i] + k3[i]; }
+    dyn7(t, u, b2, ph, k4);
+    for (int i = 0; i < 7; ++i) { k4[i] = k4[i] * h; xn[i] = x[i] + (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0; }
+  }
+}
+
+// A5: A = d x+/dx (7x7, row-major A[i*7+j]), B = d x+/du (7x3, row-major B[i*3+a])
+void discrete_jacobian(int integ, const double x[7], const double u[3], const double* b0, const double* b1,
+                       const double* b2, double h, const Phys& ph, double* A, double* B) {
+  typedef Dual<10> D;
+  D xd[7], ud[3], xn[7];
+  for (int i = 0; i < 7; ++i) { xd[i] = D(x[i]); xd[i].p[i] = 1.0; }
+  for (int a = 0; a < 3; ++a) { ud[a] = D(u[a]); ud[a].p[7 + a] = 1.0; }
+  rk_step<D>(integ, xd, ud, b0, b1, b2, h, ph, xn);
+  for (int i = 0; i < 7; ++i) {
+    for (int j = 0; j < 7; ++j) A[i * 7 + j] = xn[i].p[j];
+    for (int a = 0; a < 3; ++a) B[i * 3 + a] = xn[i].p[7 + a];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// problem description of one trajectory
+// ------------------------------------------------------------------------------------------------
+struct Traj {
+  int N, n_tab, integ;
+  const double *x0, *xf, *Bt;  // Bt: [n_tab][3]
+  double tau0, dtau, dt;
+  Phys ph;
+  const double *Qd, *Qfd, *Rd, *ulo, *uhi;
+};
+inline const double* brow(const Traj& t, int k, double c) {
+  double r = std::floor(std::fma((double)k + c, t.dtau, t.tau0));
+  long i = (long)r;
+  if (!(r >= 0.0)) i = 0;  // also catches NaN
+  if (i > t.n_tab - 1) i = t.n_tab - 1;
+  return t.Bt + 3 * i;
+}
+inline void step(const Traj& t, int k, const double* x, const double* u, double* xn) {
+  rk_step<double>(t.integ, x, u, brow(t, k, 0.0), brow(t, k, 0.5), brow(t, k, 1.0), t.dt, t.ph, xn);
+}
+
+struct AL {
+  std::vector<double> lam;  // 6 per knot k < N-1 : [upper(3), lower(3)]
+  double nu[7];
+  double mu;
+};
+
+// A8 + A9: stage cost 0.5 (x-xf)'Q(x-xf) + 0.5 u'Ru (src/TortoiseSat.jl:169) + AL terms of the control box
+// (src/TortoiseSat.jl:178,185-187): lam'c + 0.5 c' I_mu c, I_mu,ii = mu if c_i > 0 or lam_i > 0.
+double stage_cost(const Traj& t, const double* x, const double* u, const double* lam, double mu, bool with_al) {
+  double l = 0.0;
+  for (int i = 0; i < 7; ++i) { double e = x[i] - t.xf[i]; l += 0.5 * t.Qd[i] * e * e; }
+  for (int a = 0; a < 3; ++a) l += 0.5 * t.Rd[a] * u[a] * u[a];
+  if (with_al) {
+    for (int a = 0; a < 3; ++a) {
+      double c = u[a] - t.uhi[a], lm = lam[a];
+      l += lm * c;
+      if (c > 0.0 || lm > 0.0) l += 0.5 * mu * c * c;
+    }
+    for (int a = 0; a < 3; ++a) {
+      double c = t.ulo[a] - u[a], lm = lam[3 + a];
+      l += lm * c;
+      if (c > 0.0 || lm > 0.0) l += 0.5 * mu * c * c;
+    }
+  }
+  return l;
+}
+// terminal cost 0.5 (x-xf)'Qf(x-xf) + goal-constraint AL terms (src/TortoiseSat.jl:182,188)
+double term_cost(const Traj& t, const double* x, const double* nu, double mu, int mask, bool with_al) {
+  double l = 0.0;
+  for (int i = 0; i < 7; ++i) { double e = x[i] - t.xf[i]; l += 0.5 * t.Qfd[i] * e * e; }
+  if (with_al)
+    for (int i = 0; i < 7; ++i)
+      if (mask >> i & 1) { double e = x[i] - t.xf[i]; l += nu[i] * e + 0.5 * mu * e * e; }
+  return l;
+}
+double total_cost(const Traj& t, const tsat_options& o, const double* X, const double* U, const AL& al, bool with_al) {
+  double J = 0.0;
+  for (int k = 0; k < t.N - 1; ++k) J += stage_cost(t, X + 7 * k, U + 3 * k, al.lam.data() + 6 * k, al.mu, with_al);
+  J += term_cost(t, X + 7 * (t.N - 1), al.nu, al.mu, o.terminal_mask, with_al);
+  return J;
+}
+double max_violation(const Traj& t, const tsat_options& o, const double* X, const double* U) {
+  double c = 0.0;
+  for (int k = 0; k < t.N - 1; ++k)
+    for (int a = 0; a < 3; ++a) {
+      c = std::max(c, U[3 * k + a] - t.uhi[a]);
+      c = std::max(c, t.ulo[a] - U[3 * k + a]);
+    }
+  for (int i = 0; i < 7; ++i)
+    if (o.terminal_mask >> i & 1) c = std::max(c, std::fabs(X[7 * (t.N - 1) + i] - t.xf[i]));
+  return c;
+}
+
+// forward rollout with the iLQR policy u = ubar + K (x - xbar) + alpha d   (Appendix A "forward")
+bool rollout(const Traj& t, const tsat_options& o, const double* X, const double* U, const double* K,
+             const double* d, double alpha, bool closed, double* Xc, double* Uc) {
+  for (int i = 0; i < 7; ++i) Xc[i] = t.x0[i];
+  bool ok = true;
+  for (int k = 0; k < t.N - 1; ++k) {
+    double* xc = Xc + 7 * k;
+    double* uc = Uc + 3 * k;
+    for (int a = 0; a < 3; ++a) {
+      double v = U[3 * k + a];
+      if (closed) {
+        for (int j = 0; j < 7; ++j) v += K[(k * 3 + a) * 7 + j] * (xc[j] - X[7 * k + j]);
+        v += alpha * d[3 * k + a];
+      }
+      uc[a] = v;
+    }
+    for (int i = 0; i < 7; ++i) if (!(std::fabs(xc[i]) <= o.max_state)) ok = false;
+    for (int a = 0; a < 3; ++a) if (!(std::fabs(uc[a]) <= o.max_state)) ok = false;
+    step(t, k, xc, uc, xc + 7);
+  }
+  for (int i = 0; i < 7; ++i) if (!(std::fabs(Xc[7 * (t.N - 1) + i]) <= o.max_state)) ok = false;
+  return ok;
+}
+
+// backward Riccati sweep of iLQR on the AL cost (Appendix A "backward"); false if some Quu_reg is not PD.
+bool backward(const Traj& t, const tsat_options& o, const double* X, const double* U, const AL& al, double rho,
+              double* K, double* d, double dV[2]) {
+  const int N = t.N;
+  double S[49], s[7];
+  for (int i = 0; i < 49; ++i) S[i] = 0.0;
+  const double* xN = X + 7 * (N - 1);
+  for (int i = 0; i < 7; ++i) {
+    double e = xN[i] - t.xf[i];
+    S[i * 7 + i] = t.Qfd[i];
+    s[i] = t.Qfd[i] * e;
+    if (o.terminal_mask >> i & 1) { S[i * 7 + i] += al.mu; s[i] += al.nu[i] + al.mu * e; }
+  }
+  dV[0] = dV[1] = 0.0;
+  double A[49], B[21];
+  for (int k = N - 2; k >= 0; --k) {
+    const double* x = X + 7 * k;
+    const double* u = U + 3 * k;
+    discrete_jacobian(t.integ, x, u, brow(t, k, 0.0), brow(t, k, 0.5), brow(t, k, 1.0), t.dt, t.ph, A, B);
+    double lx[7], lu[3], luu[3];
+    for (int i = 0; i < 7; ++i) lx[i] = t.Qd[i] * (x[i] - t.xf[i]);
+    const double* lam = al.lam.data() + 6 * k;
+    for (int a = 0; a < 3; ++a) {
+      lu[a] = t.Rd[a] * u[a];
+      luu[a] = t.Rd[a];
+      double c = u[a] - t.uhi[a], lm = lam[a];
+      bool act = (c > 0.0 || lm > 0.0);
+      lu[a] += lm + (act ? al.mu * c : 0.0);
+      if (act) luu[a] += al.mu;
+      c = t.ulo[a] - u[a]; lm = lam[3 + a];
+      act = (c > 0.0 || lm > 0.0);
+      lu[a] -= lm + (act ? al.mu * c : 0.0);
+      if (act) luu[a] += al.mu;
+    }
+    // SA = S A (7x7), SB = S B (7x3)
+    double SA[49], SB[21];
+    for (int i = 0; i < 7; ++i) {
+      for (int j = 0; j < 7; ++j) { double a = 0; for (int m = 0; m < 7; ++m) a += S[i * 7 + m] * A[m * 7 + j]; SA[i * 7 + j] = a; }
+      for (int c = 0; c < 3; ++c) { double a = 0; for (int m = 0; m < 7; ++m) a += S[i * 7 + m] * B[m * 3 + c]; SB[i * 3 + c] = a; }
+    }
+    double Qx[7], Qu[3], Qxx[49], Quu[9], Qux[21];
+    for (int j = 0; j < 7; ++j) { double a = lx[j]; for (int m = 0; m < 7; ++m) a += A[m * 7 + j] * s[m]; Qx[j] = a; }
+    for (int c = 0; c < 3; ++c) { double a = lu[c]; for (int m = 0; m < 7; ++m) a += B[m * 3 + c] * s[m]; Qu[c] = a; }
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) { double a = (i == j) ? t.Qd[i] : 0.0; for (int m = 0; m < 7; ++m) a += A[m * 7 + i] * SA[m * 7 + j]; Qxx[i * 7 + j] = a; }
+    for (int c = 0; c < 3; ++c)
+      for (int e = 0; e < 3; ++e) { double a = (c == e) ? luu[c] : 0.0; for (int m = 0; m < 7; ++m) a += B[m * 3 + c] * SB[m * 3 + e]; Quu[c * 3 + e] = a; }
+    for (int c = 0; c < 3; ++c)
+      for (int j = 0; j < 7; ++j) { double a = 0; for (int m = 0; m < 7; ++m) a += B[m * 3 + c] * SA[m * 7 + j]; Qux[c * 7 + j] = a; }
+    // control regularisation + Sylvester PD test + adjugate inverse of the symmetric 3x3
+    double q00 = Quu[0] + rho, q11 = Quu[4] + rho, q22 = Quu[8] + rho;
+    double q10 = 0.5 * (Quu[3] + Quu[1]), q20 = 0.5 * (Quu[6] + Quu[2]), q21 = 0.5 * (Quu[7] + Quu[5]);
+    double c00 = q11 * q22 - q21 * q21;
+    double c01 = q20 * q21 - q10 * q22;
+    double c02 = q10 * q21 - q20 * q11;
+    double c11 = q00 * q22 - q20 * q20;
+    double c12 = q10 * q20 - q00 * q21;
+    double c22 = q00 * q11 - q10 * q10;
+    double det = q00 * c00 + q10 * c01 + q20 * c02;
+    if (!(q00 > 0.0 && c22 > 0.0 && det > 0.0)) return false;
+    double id = 1.0 / det;
+    double Qi[9] = {c00 * id, c01 * id, c02 * id, c01 * id, c11 * id, c12 * id, c02 * id, c12 * id, c22 * id};
+    double* Kk = K + (size_t)k * 21;
+    double* dk = d + (size_t)k * 3;
+    for (int c = 0; c < 3; ++c) {
+      for (int j = 0; j < 7; ++j) Kk[c * 7 + j] = -(Qi[c * 3 + 0] * Qux[0 * 7 + j] + Qi[c * 3 + 1] * Qux[1 * 7 + j] + Qi[c * 3 + 2] * Qux[2 * 7 + j]);
+      dk[c] = -(Qi[c * 3 + 0] * Qu[0] + Qi[c * 3 + 1] * Qu[1] + Qi[c * 3 + 2] * Qu[2]);
+    }
+    // cost-to-go update (literal Appendix A form, un-regularised Quu)
+    double QuuK[21], Quud[3];
+    for (int c = 0; c < 3; ++c) {
+      for (int j = 0; j < 7; ++j) QuuK[c * 7 + j] = Quu[c * 3 + 0] * Kk[0 * 7 + j] + Quu[c * 3 + 1] * Kk[1 * 7 + j] + Quu[c * 3 + 2] * Kk[2 * 7 + j];
+      Quud[c] = Quu[c * 3 + 0] * dk[0] + Quu[c * 3 + 1] * dk[1] + Quu[c * 3 + 2] * dk[2];
+    }
+    double Sn[49], sn[7];
+    for (int i = 0; i < 7; ++i) {
+      double a = Qx[i];
+      for (int c = 0; c < 3; ++c) a += Kk[c * 7 + i] * Quud[c] + Kk[c * 7 + i] * Qu[c] + Qux[c * 7 + i] * dk[c];
+      sn[i] = a;
+      for (int j = 0; j < 7; ++j) {
+        double b = Qxx[i * 7 + j];
+        for (int c = 0; c < 3; ++c) b += Kk[c * 7 + i] * QuuK[c * 7 + j] + Kk[c * 7 + i] * Qux[c * 7 + j] + Qux[c * 7 + i] * Kk[c * 7 + j];
+        Sn[i * 7 + j] = b;
+      }
+    }
+    for (int i = 0; i < 7; ++i) {
+      s[i] = sn[i];
+      for (int j = 0; j < 7; ++j) S[i * 7 + j] = 0.5 * (Sn[i * 7 + j] + Sn[j * 7 + i]);
+    }
+    dV[0] += dk[0] * Qu[0] + dk[1] * Qu[1] + dk[2] * Qu[2];
+    dV[1] += 0.5 * (dk[0] * Quud[0] + dk[1] * Quud[1] + dk[2] * Quud[2]);
+  }
+  return true;
+}
+
+inline void reg_increase(const tsat_options& o, double& rho, double& drho) {
+  drho = std::max(drho * o.reg_scale, o.reg_scale);
+  rho = std::max(rho * drho, o.reg_min);
+}
+inline void reg_decrease(const tsat_options& o, double& rho, double& drho) {
+  drho = std::min(drho / o.reg_scale, 1.0 / o.reg_scale);
+  double r = rho * drho;
+  rho = (r > o.reg_min) ? r : 0.0;
+}
+
+struct Work {
+  std::vector<double> X, U, Xc, Uc, K, d;
+};
+
+void solve_one(const Traj& t, const tsat_options& o, const double* U0, double* Xout, double* Uout, double* Kout,
+               tsat_stats* st, double* trace, int trace_rows) {
+  const int N = t.N;
+  Work w;
+  w.X.assign((size_t)7 * N, 0.0); w.U.assign((size_t)3 * (N - 1), 0.0);
+  w.Xc.assign((size_t)7 * N, 0.0); w.Uc.assign((size_t)3 * (N - 1), 0.0);
+  w.K.assign((size_t)21 * (N - 1), 0.0); w.d.assign((size_t)3 * (N - 1), 0.0);
+  AL al;
+  al.lam.assign((size_t)6 * (N - 1), 0.0);
+  for (int i = 0; i < 7; ++i) al.nu[i] = 0.0;
+  al.mu = o.penalty_init;
+  std::memset(st, 0, sizeof(*st));
+  int trow = 0;
+
+  for (size_t i = 0; i < w.U.size(); ++i) w.U[i] = U0[i];
+  bool ok0 = rollout(t, o, w.X.data(), w.U.data(), nullptr, nullptr, 0.0, false, w.Xc.data(), w.Uc.data());
+  w.X = w.Xc;  // (Uc == U for an open-loop rollout)
+  st->n_forward = 1;
+  double J0 = total_cost(t, o, w.X.data(), w.U.data(), al, true);
+  if (!ok0 || !std::isfinite(J0)) {
+    st->status = TSAT_DIVERGED;
+  } else {
+    st->status = TSAT_MAX_OUTER;
+    for (int outer = 1; outer <= o.max_outer; ++outer) {
+      // ---------------- inner iLQR on the AL cost ----------------
+      double Jprev = total_cost(t, o, w.X.data(), w.U.data(), al, true);
+      double rho = o.reg_init, drho = 0.0;
+      int djz = 0;
+      bool regfail = false;
+      for (int it = 1; it <= o.max_inner; ++it) {
+        double dV[2];
+        for (;;) {
+          st->n_backward++;
+          if (backward(t, o, w.X.data(), w.U.data(), al, rho, w.K.data(), w.d.data(), dV)) break;
+          st->bp_restarts++;
+          reg_increase(o, rho, drho);
+          if (rho > o.reg_max) { regfail = true; break; }
+        }
+        if (regfail) break;
+        double rho_used = rho;
+        reg_decrease(o, rho, drho);
+        // forward pass with backtracking line search
+        double alpha = 1.0, J = Jprev;
+        int jacc = -1;
+        for (int j = 0; j < o.max_linesearch; ++j) {
+          st->n_forward++;
+          st->ls_trials++;
+          bool ok = rollout(t, o, w.X.data(), w.U.data(), w.K.data(), w.d.data(), alpha, true, w.Xc.data(), w.Uc.data());
+          if (ok) {
+            double Jc = total_cost(t, o, w.Xc.data(), w.Uc.data(), al, true);
+            double expected = -alpha * (dV[0] + alpha * dV[1]);
+            double z = (expected > 0.0) ? (Jprev - Jc) / expected : -1.0;
+            if ((z > o.ls_lower && z <= o.ls_upper) || Jc < Jprev) { jacc = j; J = Jc; break; }
+          }
+          alpha *= 0.5;
+        }
+        if (jacc >= 0) {
+          w.X.swap(w.Xc);
+          w.U.swap(w.Uc);
+        } else {
+          st->fp_fails++;
+          J = Jprev;
+          reg_increase(o, rho, drho);
+          rho += o.reg_fp;
+        }
+        double dJ = std::fabs(J - Jprev);
+        if (trace && trow < trace_rows) {
+          double* r = trace + 8 * (trow++);
+          r[0] = outer; r[1] = it; r[2] = Jprev; r[3] = J; r[4] = jacc; r[5] = rho_used; r[6] = dV[0]; r[7] = dV[1];
+        }
+        Jprev = J;
+        djz = (dJ == 0.0) ? djz + 1 : 0;
+        double g = 0.0;
+        for (int k = 0; k < N - 1; ++k) {
+          double m = 0.0;
+          for (int a = 0; a < 3; ++a) m = std::max(m, std::fabs(w.d[3 * k + a]) / (std::fabs(w.U[3 * k + a]) + 1.0));
+          g += m;
+        }
+        st->grad = g / (double)(N - 1);
+        st->inner_iters++;
+        if (0.0 < dJ && dJ < o.cost_tol) break;
+        if (st->grad < o.grad_tol) break;
+        if (djz > o.dj_counter_limit) break;
+      }
+      st->outer_iters = outer;
+      st->c_max = max_violation(t, o, w.X.data(), w.U.data());
+      if (regfail) { st->status = TSAT_REG_FAIL; break; }
+      if (st->c_max < o.constraint_tol) { st->status = TSAT_CONVERGED; break; }
+      if (outer == o.max_outer) break;
+      // dual + penalty update (Appendix A "solve_AL")
+      for (int k = 0; k < N - 1; ++k) {
+        const double* u = w.U.data() + 3 * k;
+        double* lam = al.lam.data() + 6 * k;
+        for (int a = 0; a < 3; ++a) {
+          double c = u[a] - t.uhi[a];
+          lam[a] = std::min(std::max(lam[a] + al.mu * c, 0.0), o.dual_max);
+          c = t.ulo[a] - u[a];
+          lam[3 + a] = std::min(std::max(lam[3 + a] + al.mu * c, 0.0), o.dual_max);
+        }
+      }
+      for (int i = 0; i < 7; ++i)
+        if (o.terminal_mask >> i & 1) {
+          double e = w.X[7 * (N - 1) + i] - t.xf[i];
+          al.nu[i] = std::min(std::max(al.nu[i] + al.mu * e, -o.dual_max), o.dual_max);
+        }
+      al.mu = std::min(al.mu * o.penalty_scale, o.penalty_max);
+    }
+  }
+  st->c_max = max_violation(t, o, w.X.data(), w.U.data());
+  st->cost = total_cost(t, o, w.X.data(), w.U.data(), al, false);
+  st->cost_al = total_cost(t, o, w.X.data(), w.U.data(), al, true);
+  std::memcpy(Xout, w.X.data(), sizeof(double) * 7 * N);
+  std::memcpy(Uout, w.U.data(), sizeof(double) * 3 * (N - 1));
+  if (Kout)  // ABI layout: K(a, j, k) column-major 3 x 7 x (N-1)
+    for (int k = 0; k < N - 1; ++k)
+      for (int a = 0; a < 3; ++a)
+        for (int j = 0; j < 7; ++j) Kout[(size_t)k * 21 + j * 3 + a] = w.K[(size_t)(k * 3 + a) * 7 + j];
+}
+
+}  // namespace
+
+// =================================================================================================
+// C entry points (ctypes)
+// =================================================================================================
+extern "C" {
+
+void orc_default_options(tsat_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->n_knots = 0; o->n_tab = 0; o->integrator = 3; o->precision = 64;
+  o->max_outer = 20; o->max_inner = 50; o->max_linesearch = 20; o->dj_counter_limit = 10;
+  o->cost_tol = 1e-4; o->grad_tol = 1e-5; o->constraint_tol = 1e-3;
+  o->penalty_init = 1.0; o->penalty_scale = 10.0; o->penalty_max = 1e8; o->dual_max = 1e8;
+  o->reg_init = 0.0; o->reg_scale = 1.6; o->reg_min = 1e-8; o->reg_max = 1e8; o->reg_fp = 10.0;
+  o->ls_lower = 1e-8; o->ls_upper = 10.0; o->max_state = 1e8; o->u_scale = 1e-2;
+  o->terminal_mask = 0x7f; o->error_state = 0;
+}
+
+void orc_qmult(const double* q1, const double* q2, double* o) { qmult<double>(q1, q2, o); }
+void orc_qrot(const double* q, const double* r, double* o) { qrot<double>(q, r, o); }
+// src/attitude_controller.jl:164-166
+void orc_qinv(const double* q, double* o) { o[0] = q[0]; o[1] = -q[1]; o[2] = -q[2]; o[3] = -q[3]; }
+// src/attitude_controller.jl:172-176, column-major 3x3
+void orc_hat(const double* x, double* H) {
+  H[0] = 0;     H[3] = -x[2]; H[6] = x[1];
+  H[1] = x[2];  H[4] = 0;     H[7] = -x[0];
+  H[2] = -x[1]; H[5] = x[0];  H[8] = 0;
+}
+// G(q) = [-v'; s I + hat(v)]  (4x3, column-major)   src/attitude_controller.jl:69
+void orc_gmat(const double* q, double* G) {
+  double H[9];
+  orc_hat(q + 1, H);
+  for (int c = 0; c < 3; ++c) {
+    G[0 + 4 * c] = -q[1 + c];
+    for (int r = 0; r < 3; ++r) G[(1 + r) + 4 * c] = (r == c ? q[0] : 0.0) + H[r + 3 * c];
+  }
+}
+void orc_inv3(const double* M, double* Mi) { inv3(M, Mi); }
+
+// A2 literal: DerivFunction(dx,x,u) with the globals passed explicitly.
+// Btab is [rows][3]; Nglob = the script-global N (src/DerivFunction.jl:28), tspan = tf - t0 (:44).
+void orc_deriv8(const double* x8, const double* u, const double* Btab, int rows, int Nglob, const double* Jcm,
+                double tspan, double u_scale, double* dx8) {
+  Phys ph;
+  std::memcpy(ph.J, Jcm, sizeof(ph.J));
+  inv3(ph.J, ph.Jinv);
+  ph.u_scale = u_scale;
+  long idx = (long)std::floor(x8[7] * (double)Nglob + 1.0) - 1;  // Julia is 1-based
+  if (idx < 0) idx = 0;
+  if (idx > rows - 1) idx = rows - 1;
+  dyn7<double>(x8, u, Btab + 3 * idx, ph, dx8);
+  dx8[7] = 1.0 / tspan;
+}
+// A3 literal: attitude_dynamics(x,u,B_B,J) — body-frame field passed in, no unit scaling.
+void orc_attitude_dynamics(const double* x7, const double* u, const double* BB, const double* Jcm, double* xd) {
+  double Jinv[9];
+  inv3(Jcm, Jinv);
+  double w[3] = {x7[0], x7[1], x7[2]};
+  double nq = std::sqrt(x7[3] * x7[3] + x7[4] * x7[4] + x7[5] * x7[5] + x7[6] * x7[6]);
+  double q[4] = {x7[3] / nq, x7[4] / nq, x7[5] / nq, x7[6] / nq};
+  double p[4] = {0, w[0], w[1], w[2]}, qd[4], tau[3], Jw[3], wJw[3];
+  qmult<double>(q, p, qd);
+  cross3<double>(u, BB, tau);
+  for (int r = 0; r < 3; ++r) Jw[r] = Jcm[r] * w[0] + Jcm[r + 3] * w[1] + Jcm[r + 6] * w[2];
+  cross3<double>(w, Jw, wJw);
+  for (int r = 0; r < 3; ++r)
+    xd[r] = Jinv[r] * (tau[0] - wJw[0]) + Jinv[r + 3] * (tau[1] - wJw[1]) + Jinv[r + 6] * (tau[2] - wJw[2]);
+  for (int i = 0; i < 4; ++i) xd[3 + i] = 0.5 * qd[i];
+}
+void orc_dyn7(const double* x, const double* u, const double* b, const double* Jcm, double u_scale, double* xd) {
+  Phys ph;
+  std::memcpy(ph.J, Jcm, sizeof(ph.J));
+  inv3(ph.J, ph.Jinv);
+  ph.u_scale = u_scale;
+  dyn7<double>(x, u, b, ph, xd);
+}
+void orc_rk_step(int integ, const double* x, const double* u, const double* b0, const double* b1, const double* b2,
+                 double h, const double* Jcm, double u_scale, double* xn) {
+  Phys ph;
+  std::memcpy(ph.J, Jcm, sizeof(ph.J));
+  inv3(ph.J, ph.Jinv);
+  ph.u_scale = u_scale;
+  rk_step<double>(integ, x, u, b0, b1, b2, h, ph, xn);
+}
+// tableau check on the scalar test equation x' = lam x (order-of-accuracy test)
+double orc_rk_scalar(int integ, double lam, double x, double h) {
+  double k1 = lam * x * h, k2 = lam * (x + k1 / 2) * h;
+  if (integ == 3) { double k3 = lam * (x - k1 + 2 * k2) * h; return x + (k1 + 4 * k2 + k3) / 6; }
+  double k3 = lam * (x + k2 / 2) * h, k4 = lam * (x + k3) * h;
+  return x + (k1 + 2 * k2 + 2 * k3 + k4) / 6;
+}
+// A5: row-major A(7x7), B(7x3)
+void orc_discrete_jacobian(int integ, const double* x, const double* u, const double* b0, const double* b1,
+                           const double* b2, double h, const double* Jcm, double u_scale, double* A, double* B) {
+  Phys ph;
+  std::memcpy(ph.J, Jcm, sizeof(ph.J));
+  inv3(ph.J, ph.Jinv);
+  ph.u_scale = u_scale;
+  discrete_jacobian(integ, x, u, b0, b1, b2, h, ph, A, B);
+}
+
+// A6: src/quaternion_toolbox.jl:58-75 — 7-vector [dw; MRP(q2^-1 (x) q1); 0]
+void orc_quaternion_error(const double* X1, const double* X2, double* dx7) {
+  double qi[4], qe[4];
+  orc_qinv(X2 + 3, qi);
+  qmult<double>(qi, X1 + 3, qe);
+  for (int i = 0; i < 3; ++i) dx7[i] = X1[i] - X2[i];
+  for (int i = 0; i < 3; ++i) dx7[3 + i] = qe[1 + i] / (1.0 + qe[0]);
+  dx7[6] = 0.0;
+}
+// A6: src/attitude_controller.jl:59-81 — Ahat = E(q_{k+1})' A E(q_k) (6x6), Bhat = E(q_{k+1})' B (6x3);
+// A (7x7) and B (7x3) row-major in, row-major out.
+void orc_reduce_error_state(const double* A, const double* B, const double* qk, const double* qn, double* Ah, double* Bh) {
+  double Gk[12], Gn[12];
+  orc_gmat(qk, Gk);
+  orc_gmat(qn, Gn);
+  double Ek[7 * 6] = {0}, En[7 * 6] = {0};  // row-major 7x6
+  for (int i = 0; i < 3; ++i) { Ek[i * 6 + i] = 1.0; En[i * 6 + i] = 1.0; }
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 3; ++c) { Ek[(3 + r) * 6 + 3 + c] = Gk[r + 4 * c]; En[(3 + r) * 6 + 3 + c] = Gn[r + 4 * c]; }
+  double T[7 * 6];
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 6; ++j) { double a = 0; for (int m = 0; m < 7; ++m) a += A[i * 7 + m] * Ek[m * 6 + j]; T[i * 6 + j] = a; }
+  for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 6; ++j) { double a = 0; for (int m = 0; m < 7; ++m) a += En[m * 6 + i] * T[m * 6 + j]; Ah[i * 6 + j] = a; }
+    for (int c = 0; c < 3; ++c) { double a = 0; for (int m = 0; m < 7; ++m) a += En[m * 6 + i] * B[m * 3 + c]; Bh[i * 3 + c] = a; }
+  }
+}
+// A6: src/quaternion_toolbox.jl:15-36 on the 7-state (time row/column dropped): returns
+// Qxx = E'QE (6x6 row-major), Qx = E'(Q x + q) (6), for a full symmetric Q (7x7 row-major) and linear term q.
+void orc_quaternion_expansion(const double* Q, const double* qlin, const double* x, double* Qxx, double* Qx) {
+  double G[12];
+  orc_gmat(x + 3, G);
+  double E[7 * 6] = {0};
+  for (int i = 0; i < 3; ++i) E[i * 6 + i] = 1.0;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 3; ++c) E[(3 + r) * 6 + 3 + c] = G[r + 4 * c];
+  double g[7], T[7 * 6];
+  for (int i = 0; i < 7; ++i) { double a = qlin[i]; for (int m = 0; m < 7; ++m) a += Q[i * 7 + m] * x[m]; g[i] = a; }
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 6; ++j) { double a = 0; for (int m = 0; m < 7; ++m) a += Q[i * 7 + m] * E[m * 6 + j]; T[i * 6 + j] = a; }
+  for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 6; ++j) { double a = 0; for (int m = 0; m < 7; ++m) a += E[m * 6 + i] * T[m * 6 + j]; Qxx[i * 6 + j] = a; }
+    double a = 0; for (int m = 0; m < 7; ++m) a += E[m * 6 + i] * g[m]; Qx[i] = a;
+  }
+}
+
+// A7: src/attitude_controller.jl:83-92 — TVLQR Riccati on reduced blocks.
+// Ah: [N-1][6x6 row-major], Bh: [N-1][6x3 row-major], Q,Qf 6x6 row-major, R 3x3 row-major. K out: [N-1][3x6 row-major].
+void orc_tvlqr_riccati(int N, const double* Ah, const double* Bh, const double* Q, const double* R, const double* Qf, double* K) {
+  double S[36];
+  std::memcpy(S, Qf, sizeof(S));
+  for (int k = N - 2; k >= 0; --k) {
+    const double* A = Ah + (size_t)k * 36;
+    const double* B = Bh + (size_t)k * 18;
+    double SA[36], SB[18], Mi[9], BSA[18];
+    for (int i = 0; i < 6; ++i) {
+      for (int j = 0; j < 6; ++j) { double a = 0; for (int m = 0; m < 6; ++m) a += S[i * 6 + m] * A[m * 6 + j]; SA[i * 6 + j] = a; }
+      for (int c = 0; c < 3; ++c) { double a = 0; for (int m = 0; m < 6; ++m) a += S[i * 6 + m] * B[m * 3 + c]; SB[i * 3 + c] = a; }
+    }
+    double Mcm[9];
+    for (int c = 0; c < 3; ++c) {
+      for (int e = 0; e < 3; ++e) { double a = R[c * 3 + e]; for (int m = 0; m < 6; ++m) a += B[m * 3 + c] * SB[m * 3 + e]; Mcm[c + 3 * e] = a; }
+      for (int j = 0; j < 6; ++j) { double a = 0; for (int m = 0; m < 6; ++m) a += B[m * 3 + c] * SA[m * 6 + j]; BSA[c * 6 + j] = a; }
+    }
+    double Micm[9];
+    inv3(Mcm, Micm);
+    for (int c = 0; c < 3; ++c) for (int e = 0; e < 3; ++e) Mi[c * 3 + e] = Micm[c + 3 * e];
+    double* Kk = K + (size_t)k * 18;
+    for (int c = 0; c < 3; ++c)
+      for (int j = 0; j < 6; ++j) Kk[c * 6 + j] = Mi[c * 3 + 0] * BSA[0 * 6 + j] + Mi[c * 3 + 1] * BSA[1 * 6 + j] + Mi[c * 3 + 2] * BSA[2 * 6 + j];
+    // S = Q + K'RK + (A-BK)' S (A-BK)
+    double Acl[36], SAcl[36], RK[18], Sn[36];
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) { double a = A[i * 6 + j]; for (int c = 0; c < 3; ++c) a -= B[i * 3 + c] * Kk[c * 6 + j]; Acl[i * 6 + j] = a; }
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) { double a = 0; for (int m = 0; m < 6; ++m) a += S[i * 6 + m] * Acl[m * 6 + j]; SAcl[i * 6 + j] = a; }
+    for (int c = 0; c < 3; ++c)
+      for (int j = 0; j < 6; ++j) RK[c * 6 + j] = R[c * 3 + 0] * Kk[0 * 6 + j] + R[c * 3 + 1] * Kk[1 * 6 + j] + R[c * 3 + 2] * Kk[2 * 6 + j];
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        double a = Q[i * 6 + j];
+        for (int c = 0; c < 3; ++c) a += Kk[c * 6 + i] * RK[c * 6 + j];
+        for (int m = 0; m < 6; ++m) a += Acl[m * 6 + i] * SAcl[m * 6 + j];
+        Sn[i * 6 + j] = a;
+      }
+    std::memcpy(S, Sn, sizeof(S));
+  }
+}
+
+// pieces of the solver exposed for unit tests ------------------------------------------------------
+static Traj make_traj(const tsat_options* o, int64_t t, const double* x0, const double* xf, const double* Btab,
+                      const int32_t* btab_idx, const double* tau0, const double* dtau, const double* dt,
+                      const double* Jmat, const double* Qd, const double* Qfd, const double* Rd, const double* ulo,
+                      const double* uhi) {
+  Traj tr;
+  tr.N = o->n_knots; tr.n_tab = o->n_tab; tr.integ = o->integrator;
+  tr.x0 = x0 + 7 * t; tr.xf = xf + 7 * t;
+  int64_t bi = btab_idx ? btab_idx[t] : t;
+  tr.Bt = Btab + (size_t)bi * 3 * o->n_tab;
+  tr.tau0 = tau0[t]; tr.dtau = dtau[t]; tr.dt = dt[t];
+  std::memcpy(tr.ph.J, Jmat + 9 * t, sizeof(tr.ph.J));
+  inv3(tr.ph.J, tr.ph.Jinv);
+  tr.ph.u_scale = o->u_scale;
+  tr.Qd = Qd + 7 * t; tr.Qfd = Qfd + 7 * t; tr.Rd = Rd + 3 * t; tr.ulo = ulo + 3 * t; tr.uhi = uhi + 3 * t;
+  return tr;
+}
+
+/* Same argument list as tsat_solve_batch (include/tortoise_hip.h) minus the handle, plus:
+ *   nthreads    OpenMP threads over trajectories (1 = serial);
+ *   trace       optional 8 x trace_rows x T per-iteration log (see tsat_batch_trace).            */
+int orc_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab, const double* x0, const double* xf,
+                    const double* Btab, const int32_t* btab_idx, const double* tau0, const double* dtau,
+                    const double* dt, const double* Jmat, const double* Qd, const double* Qfd, const double* Rd,
+                    const double* ulo, const double* uhi, const double* U0, double* X, double* U, double* K,
+                    tsat_stats* stats, int nthreads, double* trace, int trace_rows) {
+  if (!o || o->n_knots < 2 || o->n_tab < 1 || (o->integrator != 3 && o->integrator != 4)) return -1;
+  if (o->max_linesearch < 1 || o->max_linesearch > TSAT_MAX_LINESEARCH) return -1;
+  if (o->error_state != 0) return -2;
+  if (!btab_idx && n_btab != T) return -1;
+  const int N = o->n_knots;
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int64_t t = 0; t < T; ++t) {
+    Traj tr = make_traj(o, t, x0, xf, Btab, btab_idx, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi);
+    solve_one(tr, *o, U0 + (size_t)3 * (N - 1) * t, X + (size_t)7 * N * t, U + (size_t)3 * (N - 1) * t,
+              K ? K + (size_t)21 * (N - 1) * t : nullptr, stats + t,
+              trace ? trace + (size_t)8 * trace_rows * t : nullptr, trace_rows);
+  }
+  return 0;
+}
+
+int orc_num_procs(void) {
+#ifdef _OPENMP
+  return omp_get_num_procs();
+#else
+  return 1;
+#endif
+}
+
+}  // extern "C"

@@ -1,0 +1,13 @@
+"""tortoisesat.jl_amd — MI355X-native batched AL-iLQR for TortoiseSat.jl's magnetorquer-only attitude slew.
+
+Only the hot path lives here: ``csrc/`` holds the hand-written HIP kernels and the C ABI
+(include/tortoise_hip.h); the Python modules are the thin host side above that ABI:
+
+  _abi        ctypes view of the C ABI (no fallback: raises if libtortoise_hip.so is not built)
+  slew_setup  problem setup the reference keeps in its scripts (weights, guesses, workloads)
+  trajopt     mirror of the TrajectoryOptimization.jl surface used at src/TortoiseSat.jl:145-199
+  sweep       Monte-Carlo sharding over GPUs + RCCL all-gather (src/monte_carlo.jl:118-235)
+"""
+from . import _abi, slew_setup  # noqa: F401
+
+__all__ = ["_abi", "slew_setup"]

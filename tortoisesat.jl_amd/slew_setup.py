@@ -1,0 +1,266 @@
+"""Host-side problem setup for the slew solve — the part the reference keeps in its driver scripts.
+
+Everything here is cheap O(N) NumPy that runs once per batch before the HIP solve; it mirrors, with
+file:line citations, what src/TortoiseSat.jl and src/monte_carlo.jl do between "pick an orbit" and
+"call solve!": inertia presets, the eigen-axis guess used only for Bryson weights, the weights themselves,
+and the synthetic B tables / workloads of BASELINE.json's configs.
+
+Array convention: the C ABI is column-major with the component fastest (reshape(X,7,N,T)); in NumPy that is
+the C-ordered shape (T, N, 7). All builders return C-contiguous float64 arrays in that convention.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+GM_EARTH = 3.986004418e14          # m^3/s^2 (src/input_parameters.jl:26, converted to SI)
+R_EARTH_KM = 6371.0                # src/input_parameters.jl:27
+MU_DIPOLE = 7.9e15                 # T*m^3   (src/comparison/psiaki2001_Period_LQR.jl:112)
+
+#: inertia presets, kg*m^2 (src/input_parameters.jl:29-51)
+INERTIA = {
+    "1U": np.diag([0.00125, 0.00125, 0.00125]),
+    "1P": np.diag([0.0001041667, 0.0001041667, 0.0001041667]),
+    "3U": np.diag([0.020833, 0.020833, 0.0041666]),
+}
+
+
+# --------------------------------------------------------------------------------------------------
+# quaternion helpers (scalar first), vectorised over leading axes
+# --------------------------------------------------------------------------------------------------
+def qmult(q1, q2):
+    """Hamilton product, src/DerivFunction.jl:54-56."""
+    q1 = np.asarray(q1, dtype=np.float64)
+    q2 = np.asarray(q2, dtype=np.float64)
+    s1, v1 = q1[..., :1], q1[..., 1:4]
+    s2, v2 = q2[..., :1], q2[..., 1:4]
+    s = s1 * s2 - np.sum(v1 * v2, axis=-1, keepdims=True)
+    v = s1 * v2 + s2 * v1 + np.cross(v1, v2)
+    return np.concatenate([s, v], axis=-1)
+
+
+def qrot(q, r):
+    """r + 2 v x (v x r + s r), src/DerivFunction.jl:50-52."""
+    q = np.asarray(q, dtype=np.float64)
+    r = np.asarray(r, dtype=np.float64)
+    s, v = q[..., :1], q[..., 1:4]
+    return r + 2.0 * np.cross(v, np.cross(v, r) + s * r)
+
+
+def q_inv(q):
+    """src/attitude_controller.jl:164-166."""
+    q = np.asarray(q, dtype=np.float64)
+    return np.concatenate([q[..., :1], -q[..., 1:4]], axis=-1)
+
+
+def axis_angle_quat(axis, angle_rad):
+    axis = np.asarray(axis, dtype=np.float64)
+    axis = axis / np.linalg.norm(axis)
+    return np.concatenate([[np.cos(angle_rad / 2.0)], axis * np.sin(angle_rad / 2.0)])
+
+
+# --------------------------------------------------------------------------------------------------
+# eigen-axis guess + Bryson weights
+# --------------------------------------------------------------------------------------------------
+def eigen_axis_slew(x0, xf, t):
+    """Versine eigen-axis guess (omega_guess (n,3), q_guess (n,4)), src/eigen_axis_slew.jl:1-38.
+
+    Reproduces the reference's line 16 literally: ``qmult([q2;-q2[2:4]],q1)`` only reads the first four
+    entries of its first argument, i.e. it multiplies by q2 itself, not by its conjugate.
+    """
+    x0 = np.asarray(x0, dtype=np.float64)
+    xf = np.asarray(xf, dtype=np.float64)
+    t = np.asarray(t, dtype=np.float64)
+    q1, q2 = x0[3:7], xf[3:7]
+    q_e = qmult(q2, q1)
+    theta_f = 2.0 * np.arccos(np.clip(q_e[0], -1.0, 1.0))
+    axis = -q_e[1:4] / np.sin(theta_f / 2.0)
+    alpha = np.pi / t[-1]
+    theta = theta_f * 0.5 * (1.0 - np.cos(alpha * t))
+    d_theta = np.diff(theta) / (t[1] - t[0])
+    d_theta = np.append(d_theta, d_theta[-1])
+    w_guess = d_theta[:, None] * axis[None, :]
+    dq = np.concatenate([np.cos(theta / 2.0)[:, None], axis[None, :] * np.sin(theta / 2.0)[:, None]], axis=1)
+    q_guess = qmult(q1[None, :], dq)
+    return w_guess, q_guess
+
+
+def bryson_weights(w_guess, J, dt, alpha, beta):
+    """Diagonal (Qd(7), Qfd(7), Rd(3)) per src/TortoiseSat.jl:157-168 / src/monte_carlo.jl:165-176.
+
+    ``tau_max`` is the *signed* maximum, as written in the reference (``maximum(J*diff(w)/dt)``).
+    """
+    w_max = np.max(np.abs(w_guess))
+    tau_max = np.max((J @ np.diff(w_guess, axis=0).T) / dt)
+    m_max = tau_max / 1.0e-5 * 1.0e2
+    Qd = np.concatenate([np.full(3, alpha / w_max**2), np.full(4, alpha * beta)])
+    Qfd = 10.0 * Qd
+    Rd = np.full(3, 1.0 / m_max**2)
+    return Qd, Qfd, Rd
+
+
+# --------------------------------------------------------------------------------------------------
+# synthetic B tables (tilted-dipole surrogate until the IGRF row §8f-1 exists)
+# --------------------------------------------------------------------------------------------------
+def dipole_btable(n_tab, dt_row, a_km, inc_deg, raan_deg=0.0, nu_deg=0.0):
+    """(n_tab, 3) field table in Tesla.
+
+    B(t) = Rz(RAAN) * mu_f/a^3 * [cos(w0 t + nu) sin i; -cos i; 2 sin(w0 t + nu) sin i]
+    — the reference's simplified dipole (src/comparison/psiaki2001_Period_LQR.jl:109-117) phased by the
+    true anomaly and rotated by the ascending node. Synthetic stand-in for magnetic_simulation
+    (src/magnetic_toolbox.jl:33-106); magnitudes 2-5e-5 T as with IGRF.
+    """
+    a = a_km * 1000.0
+    w0 = np.sqrt(GM_EARTH / a**3)
+    inc = np.deg2rad(inc_deg)
+    ph = w0 * dt_row * np.arange(n_tab) + np.deg2rad(nu_deg)
+    B = MU_DIPOLE / a**3 * np.stack([np.cos(ph) * np.sin(inc), -np.cos(inc) * np.ones_like(ph), 2.0 * np.sin(ph) * np.sin(inc)], axis=1)
+    c, s = np.cos(np.deg2rad(raan_deg)), np.sin(np.deg2rad(raan_deg))
+    Rz = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    return np.ascontiguousarray(B @ Rz.T)
+
+
+# --------------------------------------------------------------------------------------------------
+# batch container
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class SlewBatch:
+    """Plain arrays of one batch, in ABI order (see include/tortoise_hip.h: tsat_solve_batch)."""
+
+    N: int
+    n_tab: int
+    x0: np.ndarray      # (T,7)
+    xf: np.ndarray      # (T,7)
+    Btab: np.ndarray    # (n_btab, n_tab, 3)
+    btab_idx: np.ndarray  # (T,) int32
+    tau0: np.ndarray    # (T,)
+    dtau: np.ndarray    # (T,)
+    dt: np.ndarray      # (T,)
+    Jmat: np.ndarray    # (T,9) column-major 3x3
+    Qd: np.ndarray      # (T,7)
+    Qfd: np.ndarray     # (T,7)
+    Rd: np.ndarray      # (T,3)
+    ulo: np.ndarray     # (T,3)
+    uhi: np.ndarray     # (T,3)
+    U0: np.ndarray      # (T,N-1,3)
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def T(self):
+        return self.x0.shape[0]
+
+    def slice(self, lo, hi):
+        """Contiguous shard [lo, hi) of the batch (tables are kept whole, indices re-used)."""
+        s = slice(lo, hi)
+        c = np.ascontiguousarray
+        return SlewBatch(self.N, self.n_tab, c(self.x0[s]), c(self.xf[s]), self.Btab, c(self.btab_idx[s]),
+                         c(self.tau0[s]), c(self.dtau[s]), c(self.dt[s]), c(self.Jmat[s]), c(self.Qd[s]),
+                         c(self.Qfd[s]), c(self.Rd[s]), c(self.ulo[s]), c(self.uhi[s]), c(self.U0[s]),
+                         dict(self.meta))
+
+
+def jmat_cm(J):
+    """3x3 (or (T,3,3)) inertia -> column-major 9-vector(s) as the ABI wants."""
+    J = np.asarray(J, dtype=np.float64)
+    if J.ndim == 2:
+        return np.ascontiguousarray(J.T.reshape(9))
+    return np.ascontiguousarray(np.transpose(J, (0, 2, 1)).reshape(-1, 9))
+
+
+def make_batch(N, dt, q0, qf, J, Btab, btab_idx, alpha, beta, u_bnd, U0, w0=None, wf=None):
+    """Assemble a SlewBatch from per-trajectory initial/goal quaternions (T,4); weights per trajectory from
+    each trajectory's own eigen-axis guess (src/monte_carlo.jl:161-176)."""
+    q0 = np.atleast_2d(np.asarray(q0, dtype=np.float64))
+    qf = np.atleast_2d(np.asarray(qf, dtype=np.float64))
+    T = q0.shape[0]
+    if qf.shape[0] == 1 and T > 1:
+        qf = np.repeat(qf, T, axis=0)
+    w0 = np.zeros((T, 3)) if w0 is None else np.asarray(w0, dtype=np.float64)
+    wf = np.zeros((T, 3)) if wf is None else np.asarray(wf, dtype=np.float64)
+    x0 = np.ascontiguousarray(np.concatenate([w0, q0], axis=1))
+    xf = np.ascontiguousarray(np.concatenate([wf, qf], axis=1))
+    t = dt * np.arange(N + 1)  # t0:dt:t_final has N+1 points for N knots (src/TortoiseSat.jl:85-86)
+    Qd = np.empty((T, 7)); Qfd = np.empty((T, 7)); Rd = np.empty((T, 3))
+    for i in range(T):
+        wg, _ = eigen_axis_slew(x0[i], xf[i], t)
+        Qd[i], Qfd[i], Rd[i] = bryson_weights(wg, J, dt, alpha, beta)
+    Btab = np.ascontiguousarray(np.asarray(Btab, dtype=np.float64))
+    if Btab.ndim == 2:
+        Btab = Btab[None]
+    n_tab = Btab.shape[1]
+    u_bnd = np.broadcast_to(np.asarray(u_bnd, dtype=np.float64), (3,))
+    return SlewBatch(
+        N=N, n_tab=n_tab, x0=x0, xf=xf, Btab=Btab,
+        btab_idx=np.ascontiguousarray(np.asarray(btab_idx, dtype=np.int32)),
+        tau0=np.zeros(T), dtau=np.full(T, float(n_tab) / float(N)), dt=np.full(T, float(dt)),
+        Jmat=np.ascontiguousarray(np.repeat(jmat_cm(J)[None], T, axis=0)),
+        Qd=Qd, Qfd=Qfd, Rd=Rd,
+        ulo=np.ascontiguousarray(np.repeat(-u_bnd[None], T, axis=0)),
+        uhi=np.ascontiguousarray(np.repeat(u_bnd[None], T, axis=0)),
+        U0=np.ascontiguousarray(np.asarray(U0, dtype=np.float64).reshape(T, N - 1, 3)),
+    )
+
+
+def random_unit_quats(rng, T):
+    q = rng.standard_normal((T, 4))
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+# --------------------------------------------------------------------------------------------------
+# BASELINE.json workloads
+# --------------------------------------------------------------------------------------------------
+def workload_single_slew(N=500):
+    """configs[0]: the reference's own single slew (src/TortoiseSat.jl:117-199): ISS-like orbit, 1P inertia,
+    90 deg about [1,0,1]/sqrt2 to identity, dt 0.2, U0 = 0, |u| <= 1, alpha = 10, beta = 1e3, rk3, 20 x 50."""
+    dt = 0.2
+    a_km = R_EARTH_KM + 400.0
+    B = dipole_btable(N, dt, a_km, 51.6, 0.0, 90.0)
+    q0 = axis_angle_quat([1.0, 0.0, 1.0], np.deg2rad(90.0))
+    qf = np.array([1.0, 0.0, 0.0, 0.0])
+    b = make_batch(N, dt, q0[None], qf[None], INERTIA["1P"], B, np.zeros(1, np.int32), 10.0, 1.0e3, 1.0,
+                   np.zeros((1, N - 1, 3)))
+    b.meta = dict(name="single_slew", max_outer=20, max_inner=50, dj_counter_limit=10)
+    return b
+
+
+def workload_monte_carlo(T=1024, N=1000, seed=20190530, random_orbit=False):
+    """configs[1] (and [2] with random_orbit=True): Monte-Carlo of src/monte_carlo.jl:107-198 with the initial
+    attitude randomised — q0 uniform on S^3, qf = [sqrt2/2, sqrt2/2, 0, 0] (:114), 1U inertia (:31-33),
+    dt 0.2, U0 ~ U(0,1e-3) (:193), Bryson weights alpha = 0.1, beta = 1e3 (:170-176), |u| <= 19 (:179),
+    budget 5 x 10 with dJ_counter_limit 1 (:189-191), SSO i = 96.6 deg (:124)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    dt = 0.2
+    a_km = R_EARTH_KM + 400.0
+    q0 = random_unit_quats(rng, T)
+    qf = np.array([np.sqrt(2.0) / 2.0, np.sqrt(2.0) / 2.0, 0.0, 0.0])
+    U0 = rng.random((T, N - 1, 3)) / 1000.0
+    if random_orbit:
+        raan = rng.random(T) * 360.0
+        nu = rng.random(T) * 360.0
+        B = np.stack([dipole_btable(N, dt, a_km, 96.6, raan[i], nu[i]) for i in range(T)])
+        idx = np.arange(T, dtype=np.int32)
+    else:
+        B = dipole_btable(N, dt, a_km, 96.6, 0.0, 0.0)
+        idx = np.zeros(T, np.int32)
+    b = make_batch(N, dt, q0, qf[None], INERTIA["1U"], B, idx, 0.1, 1.0e3, 19.0, U0)
+    b.meta = dict(name="monte_carlo_random_orbit" if random_orbit else "monte_carlo", max_outer=5, max_inner=10,
+                  dj_counter_limit=1, seed=seed)
+    return b
+
+
+def workload_inclination_sweep(T=8192, N=1000, seed=20190601, j0=0, T_total=65536):
+    """configs[3] shard: deterministic inclination sweep i = 90 (j + 1/2)/T_total deg (the reference draws
+    rand*90, src/paper_images/heatmap.jl:120), random RAAN / true anomaly, q0 = [0,0,1,0] (heatmap.jl:106),
+    budget 3 x 50 (heatmap.jl:197-198). ``j0`` is the first global index of this shard."""
+    dt = 0.2
+    a_km = R_EARTH_KM + 400.0
+    rng = np.random.Generator(np.random.PCG64([seed, j0]))
+    inc = 90.0 * (np.arange(j0, j0 + T) + 0.5) / float(T_total)
+    raan = rng.random(T) * 360.0
+    nu = rng.random(T) * 360.0
+    B = np.stack([dipole_btable(N, dt, a_km, inc[i], raan[i], nu[i]) for i in range(T)])
+    q0 = np.repeat(np.array([[0.0, 0.0, 1.0, 0.0]]), T, axis=0)
+    qf = np.array([np.sqrt(2.0) / 2.0, np.sqrt(2.0) / 2.0, 0.0, 0.0])
+    U0 = rng.random((T, N - 1, 3)) / 1000.0
+    b = make_batch(N, dt, q0, qf[None], INERTIA["1U"], B, np.arange(T, dtype=np.int32), 0.1, 1.0e3, 19.0, U0)
+    b.meta = dict(name="inclination_sweep", max_outer=3, max_inner=50, dj_counter_limit=1, seed=seed)
+    return b
