@@ -1,0 +1,64 @@
+// tsat_emu.cpp — CPU lane-emulator of the HIP solve kernel (TEST INFRASTRUCTURE).
+//
+// Compiles tortoisesat.jl_amd/csrc/tsat_device.hpp — the very source hipcc compiles for gfx950 — with
+// TSAT_EMU: one wavefront = 64 host threads, __syncthreads() = std::barrier, LDS = a heap block.
+// Lets the CPU-only test tier check the kernel's indexing / lane roles / control flow against the oracle;
+// it is never used by the product and says nothing about performance.
+#define TSAT_EMU
+#include <barrier>
+#include <thread>
+#include <vector>
+#include <memory>
+
+namespace tsat_emu {
+thread_local int g_lane = 0;
+std::barrier<>* g_bar = nullptr;
+int lane() { return g_lane; }
+void sync() { g_bar->arrive_and_wait(); }
+}  // namespace tsat_emu
+
+#include "../../tortoisesat.jl_amd/csrc/tsat_host_pack.hpp"
+
+using namespace tsat;
+
+template <int INTEG>
+static void run_block(const KArgs<double>& a, int traj) {
+  std::vector<double> lds(LDS_REALS, 0.0);
+  std::barrier<> bar(WAVE);
+  tsat_emu::g_bar = &bar;
+  std::vector<std::thread> th;
+  for (int l = 0; l < WAVE; ++l)
+    th.emplace_back([&, l]() {
+      tsat_emu::g_lane = l;
+      solve_trajectory<double, INTEG>(a, traj, lds.data());
+    });
+  for (auto& t : th) t.join();
+}
+
+extern "C" int emu_lds_bytes(void) { return LDS_REALS * (int)sizeof(double); }
+
+extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab, const double* x0, const double* xf,
+                               const double* Btab, const int32_t* btab_idx, const double* tau0, const double* dtau,
+                               const double* dt, const double* Jmat, const double* Qd, const double* Qfd,
+                               const double* Rd, const double* ulo, const double* uhi, const double* U0, double* X,
+                               double* U, double* K, tsat_stats* stats, double* trace, int trace_rows) {
+  const int N = o->n_knots, n_tab = o->n_tab, max_ls = o->max_linesearch;
+  if (!check_options(*o, N, n_tab, max_ls).empty()) return -1;
+  std::vector<double> P((size_t)T * PSTRIDE), BT((size_t)n_btab * n_tab * 4);
+  std::vector<int> bidx(T);
+  pack_params<double>(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, P.data());
+  pack_btab<double>(n_btab, n_tab, Btab, BT.data());
+  for (int64_t t = 0; t < T; ++t) bidx[t] = btab_idx ? btab_idx[t] : (int)t;
+  std::vector<double> XU((size_t)T * N * XUW, 0.0), KD((size_t)T * (N - 1) * KDW, 0.0),
+      LAM((size_t)T * (N - 1) * LMW, 0.0), CAND((size_t)T * max_ls * N * XUW, 0.0);
+  KArgs<double> a;
+  a.T = (int)T; a.N = N; a.n_tab = n_tab; a.max_ls = max_ls; a.opt = *o;
+  a.P = P.data(); a.BT = BT.data(); a.bidx = bidx.data(); a.U0 = U0;
+  a.XU = XU.data(); a.KD = KD.data(); a.LAM = LAM.data(); a.CAND = CAND.data();
+  a.stats = stats; a.trace = trace; a.trace_rows = trace_rows;
+  for (int t = 0; t < (int)T; ++t) {
+    if (o->integrator == 3) run_block<3>(a, t); else run_block<4>(a, t);
+  }
+  for (int64_t e = 0; e < T * (int64_t)N; ++e) export_record<double>(e, N, XU.data(), KD.data(), X, U, K);
+  return 0;
+}

@@ -1,0 +1,920 @@
+// tsat_device.hpp — device code of the batched AL-iLQR slew solver (one trajectory per 64-lane wavefront).
+//
+// Replaces, for a whole batch, TrajectoryOptimization.solve!(prob, solver) (src/TortoiseSat.jl:199) and the
+// dynamics callback it drives (src/DerivFunction.jl:1-48). Algorithm semantics: SURVEY.md Appendix A.
+//
+// Mapping of the solve onto a CDNA4 wavefront:
+//   forward sweep  (sequential in k): lane j rolls out line-search candidate alpha = 2^-j — all backtracking
+//                   trials of one iteration run in ONE sweep; knot records (x̄,ū,K,d,λ,B rows) are staged
+//                   through LDS in CK-knot chunks by coalesced 16-byte loads and read back as broadcasts.
+//   Jacobians      (parallel in k):   lane l linearises knot k0+l (analytic forward-mode through the RK stages)
+//                   and leaves [A|B] + cost gradients in LDS for the Riccati step; nothing is stored to HBM.
+//   Riccati sweep  (sequential in k): the 64 lanes are the elements of the 8x10 / 7x7 / 3x7 blocks; operands are
+//                   broadcast through LDS; 4 dependent stages per knot.
+//   AL/cost/copy   (parallel in k):   lane-strided over knots + butterfly reductions.
+//
+// The file is plain C++ over a tiny lane abstraction so that tests/emu can run it on the CPU with 64 host
+// threads per wavefront (TSAT_EMU); the GPU build (tsat_kernels.hip) maps it onto threadIdx/__syncthreads.
+#pragma once
+#include <stdint.h>
+#include "../../include/tortoise_hip.h"
+
+#ifdef TSAT_EMU
+#include <cmath>
+namespace tsat_emu { int lane(); void sync(); }
+#define TSAT_DEV inline
+#define TSAT_LANE() (tsat_emu::lane())
+#define TSAT_SYNC() (tsat_emu::sync())
+#else
+#define TSAT_DEV __device__ __forceinline__
+#define TSAT_LANE() ((int)threadIdx.x)
+#define TSAT_SYNC() __syncthreads()
+#endif
+
+namespace tsat {
+
+constexpr int WAVE = 64;
+constexpr int CK = 32;    // knots per forward-sweep LDS chunk
+constexpr int CHB = 48;   // knots per backward-sweep LDS chunk (Jacobian lanes)
+constexpr int PSTRIDE = 64;
+// per-trajectory parameter record (reals)
+enum { P_X0 = 0, P_XF = 7, P_QD = 14, P_QFD = 21, P_RD = 28, P_ULO = 31, P_UHI = 34, P_J = 37, P_JI = 46,
+       P_TAU0 = 55, P_DTAU = 56, P_DT = 57 };
+// Jacobian record left in LDS per knot (reals): F=[A|B] column-major with column stride 8, then gradients
+constexpr int R_F = 0, R_LX = 80, R_LU = 87, R_LUU = 90, RECS = 93;
+// forward-sweep chunk arrays
+constexpr int KDW = 24, XUW = 10, LMW = 6, BSW = 9;
+
+template <typename real>
+struct KArgs {
+  int T, N, n_tab, max_ls;
+  tsat_options opt;
+  const real* P;      // [T][PSTRIDE]
+  const real* BT;     // [n_btab][n_tab][4]
+  const int* bidx;    // [T]
+  const real* U0;     // [T][N-1][3]
+  real* XU;           // [T][N][10]      nominal knot records x(7),u(3)
+  real* KD;           // [T][N-1][24]    K (3x7 row-major), d(3)
+  real* LAM;          // [T][N-1][6]     control-box multipliers [upper(3), lower(3)]
+  real* CAND;         // [T][max_ls][N][10] line-search candidates
+  tsat_stats* stats;  // [T]
+  double* trace;      // [T][trace_rows][8] or null
+  int trace_rows;
+};
+
+// LDS carve-up (in reals)
+constexpr int L_RED = 0;                 // 64 reduction scratch
+constexpr int L_ST = L_RED + 64;         // S~ : 8 rows x 9
+constexpr int L_WT = L_ST + 72;          // W~ : 10 cols x 9
+constexpr int L_HXX = L_WT + 90;         // 7 x 7 (+1)
+constexpr int L_HUX = L_HXX + 50;        // 3 x 8  (col 7 = Qu)
+constexpr int L_HUU = L_HUX + 24;        // 3 x 3 (+1)
+constexpr int L_KD = L_HUU + 10;         // 3 x 8  (col 7 = d)
+constexpr int L_UNION = L_KD + 24;       // 334
+constexpr int L_REC = L_UNION;           // CHB x RECS
+constexpr int L_KDC = L_UNION;           // CK x 24
+constexpr int L_XUC = L_KDC + CK * KDW;
+constexpr int L_LMC = L_XUC + CK * XUW;
+constexpr int L_BSC = L_LMC + CK * LMW;
+constexpr int L_FWD_END = L_BSC + CK * BSW;
+constexpr int L_BWD_END = L_REC + CHB * RECS;
+constexpr int LDS_REALS = (L_FWD_END > L_BWD_END ? L_FWD_END : L_BWD_END);
+
+// --------------------------------------------------------------------------------------------------
+// small math helpers
+// --------------------------------------------------------------------------------------------------
+template <typename real> TSAT_DEV real rsqrt_(real s);
+#ifdef TSAT_EMU
+template <> TSAT_DEV double rsqrt_<double>(double s) { return 1.0 / std::sqrt(s); }
+template <> TSAT_DEV float rsqrt_<float>(float s) { return 1.0f / std::sqrt(s); }
+TSAT_DEV double fabs_(double a) { return std::fabs(a); }
+TSAT_DEV double fmax_(double a, double b) { return a > b ? a : b; }   // NaN in b ignored, like v_max
+TSAT_DEV double floor_(double a) { return std::floor(a); }
+TSAT_DEV double fma_(double a, double b, double c) { return std::fma(a, b, c); }
+TSAT_DEV double rcp_(double a) { return 1.0 / a; }
+#else
+// v_rsq_f64 seed + two Newton steps: ~1 ulp for s in the normal range (|q| is O(1) here)
+template <> TSAT_DEV double rsqrt_<double>(double s) {
+  double y = __builtin_amdgcn_rsq(s);
+  double e = s * y * y;
+  y = y * __builtin_fma(-0.5, e, 1.5);
+  e = s * y * y;
+  y = y * __builtin_fma(-0.5, e, 1.5);
+  return y;
+}
+template <> TSAT_DEV float rsqrt_<float>(float s) { return __builtin_amdgcn_rsqf(s); }
+TSAT_DEV double fabs_(double a) { return __builtin_fabs(a); }
+TSAT_DEV double fmax_(double a, double b) { return a > b ? a : b; }
+TSAT_DEV double floor_(double a) { return __builtin_floor(a); }
+TSAT_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// v_rcp_f64 seed + two Newton steps
+TSAT_DEV double rcp_(double a) {
+  double y = __builtin_amdgcn_rcp(a);
+  y = y * __builtin_fma(-a, y, 2.0);
+  y = y * __builtin_fma(-a, y, 2.0);
+  return y;
+}
+#endif
+
+// a[i] for a register-resident array and a run-time i (select chain: keeps `a` out of scratch memory)
+template <typename real>
+TSAT_DEV real sel7(const real a[7], int i) {
+  real v = a[0];
+  for (int m = 1; m < 7; ++m) v = (i == m) ? a[m] : v;
+  return v;
+}
+
+// wave collectives through LDS scratch; identical butterfly order in the GPU and emulated builds
+template <typename real>
+TSAT_DEV real wave_sum(real v, real* red) {
+  const int lane = TSAT_LANE();
+  for (int s = 1; s < WAVE; s <<= 1) {
+    red[lane] = v;
+    TSAT_SYNC();
+    v = v + red[lane ^ s];
+    TSAT_SYNC();
+  }
+  return v;
+}
+template <typename real>
+TSAT_DEV real wave_max(real v, real* red) {
+  const int lane = TSAT_LANE();
+  for (int s = 1; s < WAVE; s <<= 1) {
+    red[lane] = v;
+    TSAT_SYNC();
+    real o = red[lane ^ s];
+    v = (o > v) ? o : v;
+    TSAT_SYNC();
+  }
+  return v;
+}
+template <typename real>
+TSAT_DEV real wave_bcast(real v, int src, real* red) {
+  const int lane = TSAT_LANE();
+  if (lane == src) red[0] = v;
+  TSAT_SYNC();
+  real r = red[0];
+  TSAT_SYNC();
+  return r;
+}
+// smallest lane index whose flag is set, or WAVE
+template <typename real>
+TSAT_DEV int wave_first(bool flag, real* red) {
+  real v = flag ? (real)TSAT_LANE() : (real)WAVE;
+  const int lane = TSAT_LANE();
+  for (int s = 1; s < WAVE; s <<= 1) {
+    red[lane] = v;
+    TSAT_SYNC();
+    real o = red[lane ^ s];
+    v = (o < v) ? o : v;
+    TSAT_SYNC();
+  }
+  return (int)v;
+}
+
+// --------------------------------------------------------------------------------------------------
+// per-trajectory constants (wave-uniform)
+// --------------------------------------------------------------------------------------------------
+template <typename real>
+struct Traj {
+  real xf[7], Qd[7], Qfd[7], Rd[3], ulo[3], uhi[3];
+  real J[9];    // row-major J(r,c) = J[3r+c]
+  real hJi[9];  // h * inv(J), row-major
+  real h, hh, us;
+  double tau0, dtau;
+  int N, n_tab;
+  const real* bt;  // [n_tab][4]
+};
+
+template <typename real>
+TSAT_DEV int brow_index(const Traj<real>& tr, int k, double c) {
+  // floor(fma(k + c, dtau, tau0)) clamped — the reference's B_ECI[floor(Int, t*N + 1), :] (src/DerivFunction.jl:28)
+  double r = floor_(fma_((double)k + c, tr.dtau, tr.tau0));
+  int i = (r >= 0.0) ? (r > (double)(tr.n_tab - 1) ? tr.n_tab - 1 : (int)r) : 0;
+  return i;
+}
+
+// h * f(x,u;b): src/DerivFunction.jl:4-44 on the 7-state. `us` = u * u_scale (:37). Intermediates needed by the
+// tangent pass are returned in `sb`.
+template <typename real>
+struct StageBase {
+  real w[3], qh[4], rn, c[3], BB[3], Jw[3];
+};
+
+template <typename real>
+TSAT_DEV void dyn_h(const Traj<real>& tr, const real x[7], const real us[3], const real b[3], real k[7],
+                    StageBase<real>& sb) {
+  const real w0 = x[0], w1 = x[1], w2 = x[2];
+  const real s = x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6];
+  const real rn = rsqrt_<real>(s);
+  const real q0 = x[3] * rn, q1 = x[4] * rn, q2 = x[5] * rn, q3 = x[6] * rn;
+  // qdot = 0.5 qmult(q,[0;w])  (:24)
+  k[3] = -tr.hh * (q1 * w0 + q2 * w1 + q3 * w2);
+  k[4] = tr.hh * (q0 * w0 + (q2 * w2 - q3 * w1));
+  k[5] = tr.hh * (q0 * w1 + (q3 * w0 - q1 * w2));
+  k[6] = tr.hh * (q0 * w2 + (q1 * w1 - q2 * w0));
+  // B_B = qrot(q,b) = b + 2 v x (v x b + s b)  (:28,:50-52)
+  const real c0 = (q2 * b[2] - q3 * b[1]) + q0 * b[0];
+  const real c1 = (q3 * b[0] - q1 * b[2]) + q0 * b[1];
+  const real c2 = (q1 * b[1] - q2 * b[0]) + q0 * b[2];
+  const real B0 = b[0] + 2 * (q2 * c2 - q3 * c1);
+  const real B1 = b[1] + 2 * (q3 * c0 - q1 * c2);
+  const real B2 = b[2] + 2 * (q1 * c1 - q2 * c0);
+  // tau_c = cross(u*1e-2, B_B)  (:37)
+  const real t0 = us[1] * B2 - us[2] * B1;
+  const real t1 = us[2] * B0 - us[0] * B2;
+  const real t2 = us[0] * B1 - us[1] * B0;
+  // wdot = inv(J) (tau_c - w x Jw)  (:41)
+  const real Jw0 = tr.J[0] * w0 + tr.J[1] * w1 + tr.J[2] * w2;
+  const real Jw1 = tr.J[3] * w0 + tr.J[4] * w1 + tr.J[5] * w2;
+  const real Jw2 = tr.J[6] * w0 + tr.J[7] * w1 + tr.J[8] * w2;
+  const real r0 = t0 - (w1 * Jw2 - w2 * Jw1);
+  const real r1 = t1 - (w2 * Jw0 - w0 * Jw2);
+  const real r2 = t2 - (w0 * Jw1 - w1 * Jw0);
+  k[0] = tr.hJi[0] * r0 + tr.hJi[1] * r1 + tr.hJi[2] * r2;
+  k[1] = tr.hJi[3] * r0 + tr.hJi[4] * r1 + tr.hJi[5] * r2;
+  k[2] = tr.hJi[6] * r0 + tr.hJi[7] * r1 + tr.hJi[8] * r2;
+  sb.w[0] = w0; sb.w[1] = w1; sb.w[2] = w2;
+  sb.qh[0] = q0; sb.qh[1] = q1; sb.qh[2] = q2; sb.qh[3] = q3;
+  sb.rn = rn;
+  sb.c[0] = c0; sb.c[1] = c1; sb.c[2] = c2;
+  sb.BB[0] = B0; sb.BB[1] = B1; sb.BB[2] = B2;
+  sb.Jw[0] = Jw0; sb.Jw[1] = Jw1; sb.Jw[2] = Jw2;
+}
+
+// directional derivative of h*f at a stage (applied to a tangent instead of forming F):
+// dx = [dw; dq] tangent of the stage state, dus = u_scale * du.
+template <typename real>
+TSAT_DEV void dyn_h_jvp(const Traj<real>& tr, const StageBase<real>& sb, const real us[3], const real b[3],
+                        const real dx[7], const real dus[3], real dk[7]) {
+  const real dw0 = dx[0], dw1 = dx[1], dw2 = dx[2];
+  const real q0 = sb.qh[0], q1 = sb.qh[1], q2 = sb.qh[2], q3 = sb.qh[3];
+  // d qhat = rn (dq - qhat (qhat . dq))   (normalisation inside f, src/DerivFunction.jl:5)
+  const real t = q0 * dx[3] + q1 * dx[4] + q2 * dx[5] + q3 * dx[6];
+  const real e0 = sb.rn * (dx[3] - q0 * t);
+  const real e1 = sb.rn * (dx[4] - q1 * t);
+  const real e2 = sb.rn * (dx[5] - q2 * t);
+  const real e3 = sb.rn * (dx[6] - q3 * t);
+  const real w0 = sb.w[0], w1 = sb.w[1], w2 = sb.w[2];
+  dk[3] = -tr.hh * ((e1 * w0 + e2 * w1 + e3 * w2) + (q1 * dw0 + q2 * dw1 + q3 * dw2));
+  dk[4] = tr.hh * ((e0 * w0 + (e2 * w2 - e3 * w1)) + (q0 * dw0 + (q2 * dw2 - q3 * dw1)));
+  dk[5] = tr.hh * ((e0 * w1 + (e3 * w0 - e1 * w2)) + (q0 * dw1 + (q3 * dw0 - q1 * dw2)));
+  dk[6] = tr.hh * ((e0 * w2 + (e1 * w1 - e2 * w0)) + (q0 * dw2 + (q1 * dw1 - q2 * dw0)));
+  // dc = dv x b + ds b ; dBB = 2 (dv x c + v x dc)
+  const real dc0 = (e2 * b[2] - e3 * b[1]) + e0 * b[0];
+  const real dc1 = (e3 * b[0] - e1 * b[2]) + e0 * b[1];
+  const real dc2 = (e1 * b[1] - e2 * b[0]) + e0 * b[2];
+  const real dB0 = 2 * ((e2 * sb.c[2] - e3 * sb.c[1]) + (q2 * dc2 - q3 * dc1));
+  const real dB1 = 2 * ((e3 * sb.c[0] - e1 * sb.c[2]) + (q3 * dc0 - q1 * dc2));
+  const real dB2 = 2 * ((e1 * sb.c[1] - e2 * sb.c[0]) + (q1 * dc1 - q2 * dc0));
+  // dtau = dus x BB + us x dBB
+  const real t0 = (dus[1] * sb.BB[2] - dus[2] * sb.BB[1]) + (us[1] * dB2 - us[2] * dB1);
+  const real t1 = (dus[2] * sb.BB[0] - dus[0] * sb.BB[2]) + (us[2] * dB0 - us[0] * dB2);
+  const real t2 = (dus[0] * sb.BB[1] - dus[1] * sb.BB[0]) + (us[0] * dB1 - us[1] * dB0);
+  // d(w x Jw) = dw x Jw + w x J dw
+  const real dJ0 = tr.J[0] * dw0 + tr.J[1] * dw1 + tr.J[2] * dw2;
+  const real dJ1 = tr.J[3] * dw0 + tr.J[4] * dw1 + tr.J[5] * dw2;
+  const real dJ2 = tr.J[6] * dw0 + tr.J[7] * dw1 + tr.J[8] * dw2;
+  const real r0 = t0 - ((dw1 * sb.Jw[2] - dw2 * sb.Jw[1]) + (w1 * dJ2 - w2 * dJ1));
+  const real r1 = t1 - ((dw2 * sb.Jw[0] - dw0 * sb.Jw[2]) + (w2 * dJ0 - w0 * dJ2));
+  const real r2 = t2 - ((dw0 * sb.Jw[1] - dw1 * sb.Jw[0]) + (w0 * dJ1 - w1 * dJ0));
+  dk[0] = tr.hJi[0] * r0 + tr.hJi[1] * r1 + tr.hJi[2] * r2;
+  dk[1] = tr.hJi[3] * r0 + tr.hJi[4] * r1 + tr.hJi[5] * r2;
+  dk[2] = tr.hJi[6] * r0 + tr.hJi[7] * r1 + tr.hJi[8] * r2;
+}
+
+// one RK step (rk3: src/attitude_controller.jl:178-187; rk4: :122-132); b0/b1/b2 = rows at tau, tau+dtau/2, tau+dtau
+template <typename real, int INTEG>
+TSAT_DEV void rk_step(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3], const real b1[3],
+                      const real b2[3], real xn[7]) {
+  const real us[3] = {u[0] * tr.us, u[1] * tr.us, u[2] * tr.us};
+  real k1[7], k2[7], k3[7], t[7];
+  StageBase<real> sb;
+  dyn_h(tr, x, us, b0, k1, sb);
+  for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k1[i];
+  dyn_h(tr, t, us, b1, k2, sb);
+  if (INTEG == 3) {
+    for (int i = 0; i < 7; ++i) t[i] = x[i] - k1[i] + 2 * k2[i];
+    dyn_h(tr, t, us, b2, k3, sb);
+    for (int i = 0; i < 7; ++i) xn[i] = x[i] + (k1[i] + 4 * k2[i] + k3[i]) * (real)(1.0 / 6.0);
+  } else {
+    real k4[7];
+    for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k2[i];
+    dyn_h(tr, t, us, b1, k3, sb);
+    for (int i = 0; i < 7; ++i) t[i] = x[i] + k3[i];
+    dyn_h(tr, t, us, b2, k4, sb);
+    for (int i = 0; i < 7; ++i) xn[i] = x[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) * (real)(1.0 / 6.0);
+  }
+}
+
+// discrete Jacobians of one RK step, column by column, written to LDS record `F` (column stride 8).
+// Equivalent of ForwardDiff.jacobian! over the discretised dynamics (src/attitude_controller.jl:95-119).
+template <typename real, int INTEG>
+TSAT_DEV void rk_jacobian(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3],
+                          const real b1[3], const real b2[3], real* F) {
+  const real us[3] = {u[0] * tr.us, u[1] * tr.us, u[2] * tr.us};
+  real k1[7], k2[7], k3[7], t[7];
+  StageBase<real> s1, s2, s3, s4;
+  dyn_h(tr, x, us, b0, k1, s1);
+  for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k1[i];
+  dyn_h(tr, t, us, b1, k2, s2);
+  if (INTEG == 3) {
+    for (int i = 0; i < 7; ++i) t[i] = x[i] - k1[i] + 2 * k2[i];
+    dyn_h(tr, t, us, b2, k3, s3);
+  } else {
+    for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k2[i];
+    dyn_h(tr, t, us, b1, k3, s3);
+    for (int i = 0; i < 7; ++i) t[i] = x[i] + k3[i];
+    real k4[7];
+    dyn_h(tr, t, us, b2, k4, s4);
+  }
+#ifndef TSAT_EMU
+#pragma unroll 1
+#endif
+  for (int c = 0; c < 10; ++c) {
+    real ex[7], du[3];
+    for (int i = 0; i < 7; ++i) ex[i] = (i == c) ? (real)1 : (real)0;
+    for (int a = 0; a < 3; ++a) du[a] = (c == 7 + a) ? tr.us : (real)0;
+    real v1[7], v2[7], v3[7], arg[7];
+    dyn_h_jvp(tr, s1, us, b0, ex, du, v1);
+    for (int i = 0; i < 7; ++i) arg[i] = ex[i] + (real)0.5 * v1[i];
+    dyn_h_jvp(tr, s2, us, b1, arg, du, v2);
+    if (INTEG == 3) {
+      for (int i = 0; i < 7; ++i) arg[i] = ex[i] - v1[i] + 2 * v2[i];
+      dyn_h_jvp(tr, s3, us, b2, arg, du, v3);
+      for (int i = 0; i < 7; ++i) F[c * 8 + i] = ex[i] + (v1[i] + 4 * v2[i] + v3[i]) * (real)(1.0 / 6.0);
+    } else {
+      real v4[7];
+      for (int i = 0; i < 7; ++i) arg[i] = ex[i] + (real)0.5 * v2[i];
+      dyn_h_jvp(tr, s3, us, b1, arg, du, v3);
+      for (int i = 0; i < 7; ++i) arg[i] = ex[i] + v3[i];
+      dyn_h_jvp(tr, s4, us, b2, arg, du, v4);
+      for (int i = 0; i < 7; ++i) F[c * 8 + i] = ex[i] + (v1[i] + 2 * v2[i] + 2 * v3[i] + v4[i]) * (real)(1.0 / 6.0);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// cost pieces (A8/A9): LQR objective (src/TortoiseSat.jl:169) + AL terms of the control box (:178) and the
+// terminal goal constraint (:182)
+// --------------------------------------------------------------------------------------------------
+template <typename real>
+TSAT_DEV real stage_cost(const Traj<real>& tr, const real x[7], const real u[3], const real lam[6], real mu,
+                         bool with_al) {
+  real l = 0;
+  for (int i = 0; i < 7; ++i) { real e = x[i] - tr.xf[i]; l += (real)0.5 * tr.Qd[i] * e * e; }
+  for (int a = 0; a < 3; ++a) l += (real)0.5 * tr.Rd[a] * u[a] * u[a];
+  if (with_al) {
+    for (int a = 0; a < 3; ++a) {
+      real c = u[a] - tr.uhi[a], lm = lam[a];
+      l += lm * c;
+      real act = (c > 0 || lm > 0) ? mu : (real)0;
+      l += (real)0.5 * act * c * c;
+    }
+    for (int a = 0; a < 3; ++a) {
+      real c = tr.ulo[a] - u[a], lm = lam[3 + a];
+      l += lm * c;
+      real act = (c > 0 || lm > 0) ? mu : (real)0;
+      l += (real)0.5 * act * c * c;
+    }
+  }
+  return l;
+}
+template <typename real>
+TSAT_DEV real term_cost(const Traj<real>& tr, const real x[7], const real nu[7], real mu, int mask, bool with_al) {
+  real l = 0;
+  for (int i = 0; i < 7; ++i) { real e = x[i] - tr.xf[i]; l += (real)0.5 * tr.Qfd[i] * e * e; }
+  if (with_al)
+    for (int i = 0; i < 7; ++i)
+      if ((mask >> i) & 1) { real e = x[i] - tr.xf[i]; l += nu[i] * e + (real)0.5 * mu * e * e; }
+  return l;
+}
+
+// cooperative copy of `n` reals (n even, 16-byte aligned both sides) global -> LDS
+template <typename real>
+TSAT_DEV void coop_load(real* dst, const real* src, int n) {
+  const int lane = TSAT_LANE();
+  struct alignas(2 * sizeof(real)) R2 { real a, b; };
+  const R2* s2 = reinterpret_cast<const R2*>(src);
+  R2* d2 = reinterpret_cast<R2*>(dst);
+  for (int i = lane; i < (n >> 1); i += WAVE) d2[i] = s2[i];
+}
+
+// --------------------------------------------------------------------------------------------------
+// forward sweep: all line-search candidates at once (lane j: alpha = 2^-j). Returns this lane's AL cost;
+// *ok = rollout stayed within max_state. Candidate knot records go to CAND[traj][lane].
+// --------------------------------------------------------------------------------------------------
+template <typename real, int INTEG>
+TSAT_DEV real forward_sweep(const KArgs<real>& a, const Traj<real>& tr, int traj, bool closed, int n_cand,
+                            const real nu[7], real mu, real* lds, bool* ok) {
+  const int lane = TSAT_LANE();
+  const int N = tr.N;
+  const real* P = a.P + (size_t)traj * PSTRIDE;
+  real alpha = 1;
+  for (int j = 0; j < lane && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (real)0.5;
+  real x[7];
+  for (int i = 0; i < 7; ++i) x[i] = P[P_X0 + i];
+  real J = 0, amax = 0;
+  const real* XUg = a.XU + (size_t)traj * N * XUW;
+  const real* KDg = a.KD + (size_t)traj * (N - 1) * KDW;
+  const real* LMg = a.LAM + (size_t)traj * (N - 1) * LMW;
+  real* Cg = a.CAND + ((size_t)traj * a.max_ls + (lane < n_cand ? lane : 0)) * (size_t)N * XUW;
+  real* KDc = lds + L_KDC;
+  real* XUc = lds + L_XUC;
+  real* LMc = lds + L_LMC;
+  real* BSc = lds + L_BSC;
+  for (int k0 = 0; k0 < N - 1; k0 += CK) {
+    const int nk = (N - 1 - k0 < CK) ? (N - 1 - k0) : CK;
+    if (closed) coop_load(KDc, KDg + (size_t)k0 * KDW, nk * KDW);
+    coop_load(XUc, XUg + (size_t)k0 * XUW, nk * XUW);
+    coop_load(LMc, LMg + (size_t)k0 * LMW, nk * LMW);
+    for (int e = lane; e < nk * 3; e += WAVE) {
+      const int kk = e / 3, st = e - 3 * kk;
+      const int row = brow_index(tr, k0 + kk, 0.5 * (double)st);
+      const real* br = tr.bt + (size_t)row * 4;
+      BSc[kk * BSW + st * 3 + 0] = br[0];
+      BSc[kk * BSW + st * 3 + 1] = br[1];
+      BSc[kk * BSW + st * 3 + 2] = br[2];
+    }
+    TSAT_SYNC();
+    for (int kk = 0; kk < nk; ++kk) {
+      const real* xu = XUc + kk * XUW;
+      real u[3] = {xu[7], xu[8], xu[9]};
+      if (closed) {
+        const real* kd = KDc + kk * KDW;
+        real dx[7];
+        for (int i = 0; i < 7; ++i) dx[i] = x[i] - xu[i];
+        for (int c = 0; c < 3; ++c) {
+          real v = u[c];
+          for (int j = 0; j < 7; ++j) v += kd[c * 7 + j] * dx[j];
+          u[c] = v + alpha * kd[21 + c];
+        }
+      }
+      for (int i = 0; i < 7; ++i) amax = fmax_(amax, fabs_(x[i]));
+      for (int c = 0; c < 3; ++c) amax = fmax_(amax, fabs_(u[c]));
+      J += stage_cost(tr, x, u, LMc + kk * LMW, mu, true);
+      if (lane < n_cand) {
+        real* cr = Cg + (size_t)(k0 + kk) * XUW;
+        for (int i = 0; i < 7; ++i) cr[i] = x[i];
+        for (int c = 0; c < 3; ++c) cr[7 + c] = u[c];
+      }
+      real xn[7];
+      const real* bs = BSc + kk * BSW;
+      rk_step<real, INTEG>(tr, x, u, bs, bs + 3, bs + 6, xn);
+      for (int i = 0; i < 7; ++i) x[i] = xn[i];
+    }
+    TSAT_SYNC();
+  }
+  for (int i = 0; i < 7; ++i) amax = fmax_(amax, fabs_(x[i]));
+  J += term_cost(tr, x, nu, mu, a.opt.terminal_mask, true);
+  if (lane < n_cand) {
+    real* cr = Cg + (size_t)(N - 1) * XUW;
+    for (int i = 0; i < 7; ++i) cr[i] = x[i];
+    for (int c = 0; c < 3; ++c) cr[7 + c] = 0;
+  }
+  *ok = (amax <= (real)a.opt.max_state) && (J == J);
+  return J;
+}
+
+// --------------------------------------------------------------------------------------------------
+// backward sweep = Jacobian lanes + Riccati recursion. Returns false (wave-uniform) when some Quu_reg is not PD.
+// --------------------------------------------------------------------------------------------------
+TSAT_DEV void pair28(int L, int& i, int& j) {  // L in [0,28) -> (i<=j) of a 7x7 upper triangle, row by row
+  int r = 0, base = 0;
+  while (L >= base + (7 - r)) { base += 7 - r; ++r; }
+  i = r;
+  j = r + (L - base);
+}
+
+template <typename real, int INTEG>
+TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int traj, const real nu[7], real mu,
+                             real rho, real* lds, real* dV1_out, real* dV2_out) {
+  const int lane = TSAT_LANE();
+  const int N = tr.N;
+  const real* XUg = a.XU + (size_t)traj * N * XUW;
+  const real* LMg = a.LAM + (size_t)traj * (N - 1) * LMW;
+  real* KDg = a.KD + (size_t)traj * (N - 1) * KDW;
+  real* St = lds + L_ST;
+  real* Wt = lds + L_WT;
+  real* Hxx = lds + L_HXX;
+  real* Hux = lds + L_HUX;
+  real* Huu = lds + L_HUU;
+  real* KDs = lds + L_KD;
+  real* rec = lds + L_REC;
+
+  // lane roles --------------------------------------------------------------------------------
+  const int r1 = lane & 7, c1 = lane >> 3;          // step 1: W~[r1][c1], and W~[r1][8+c1] for c1 < 2
+  int colA = 0, colB = 0, o1 = -1, o2 = -1;          // step 2: dot(F[:,colA], W[:,colB]) -> lds[o1], lds[o2]
+  real diag2 = 0; int luu2 = -1;
+  if (lane < 28) {
+    int i, j; pair28(lane, i, j);
+    colA = i; colB = j; o1 = L_HXX + i * 7 + j; o2 = L_HXX + j * 7 + i;
+    if (i == j) diag2 = sel7(tr.Qd, i);
+  } else if (lane < 49) {
+    int aa = (lane - 28) / 7, j = (lane - 28) % 7;
+    colA = 7 + aa; colB = j; o1 = L_HUX + aa * 8 + j; o2 = o1;
+  } else if (lane < 55) {
+    const int L = lane - 49;                        // (0,0)(0,1)(0,2)(1,1)(1,2)(2,2)
+    const int aa = (L < 3) ? 0 : (L < 5 ? 1 : 2);
+    const int bb = (L < 3) ? L : (L < 5 ? L - 2 : 2);
+    colA = 7 + aa; colB = 7 + bb; o1 = L_HUU + aa * 3 + bb; o2 = L_HUU + bb * 3 + aa;
+    if (aa == bb) luu2 = aa;
+  } else if (lane < 58) {                           // Qu[a] = lu[a] + W~[7][7+a]  -> Hux[a][7]
+    o1 = -2;
+  }
+  const int a3 = lane >> 3, j3 = lane & 7;           // step 3: K[a3][j3] (j3 == 7: d[a3]) for a3 < 3
+  int i4 = 0, j4 = 0;                                // step 4: S[i4][j4] (lane < 28), s[lane-28] (28..34)
+  if (lane < 28) pair28(lane, i4, j4);
+
+  // terminal cost-to-go: Sxx = Qf + mu*mask, Sx = Qf e + mask (nu + mu e)   (Appendix A backward)
+  {
+    const real* xN = XUg + (size_t)(N - 1) * XUW;
+    if (c1 < 7) {
+      real v = 0;
+      const real qf = sel7(tr.Qfd, c1);
+      const real e = xN[c1] - sel7(tr.xf, c1);
+      const bool m = (a.opt.terminal_mask >> c1) & 1;
+      if (r1 < 7) {
+        if (r1 == c1) v = qf + (m ? mu : (real)0);
+      } else {
+        v = qf * e + (m ? (sel7(nu, c1) + mu * e) : (real)0);
+      }
+      St[r1 * 9 + c1] = v;
+    }
+  }
+  real dV1 = 0, dV2 = 0;
+  bool pd_ok = true;
+  TSAT_SYNC();
+
+  const int nchunks = (N - 1 + CHB - 1) / CHB;
+  for (int ch = nchunks - 1; ch >= 0 && pd_ok; --ch) {
+    const int k0 = ch * CHB;
+    const int nk = (N - 1 - k0 < CHB) ? (N - 1 - k0) : CHB;
+    // ---- Jacobian lanes: knot k0 + lane -------------------------------------------------------
+    if (lane < nk) {
+      const int k = k0 + lane;
+      const real* xu = XUg + (size_t)k * XUW;
+      real x[7], u[3], lam[6], b0[3], b1[3], b2[3];
+      for (int i = 0; i < 7; ++i) x[i] = xu[i];
+      for (int c = 0; c < 3; ++c) u[c] = xu[7 + c];
+      for (int c = 0; c < 6; ++c) lam[c] = LMg[(size_t)k * LMW + c];
+      const real* p0 = tr.bt + (size_t)brow_index(tr, k, 0.0) * 4;
+      const real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
+      const real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
+      for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
+      real* rc = rec + lane * RECS;
+      rk_jacobian<real, INTEG>(tr, x, u, b0, b1, b2, rc + R_F);
+      for (int i = 0; i < 7; ++i) rc[R_LX + i] = tr.Qd[i] * (x[i] - tr.xf[i]);
+      for (int c = 0; c < 3; ++c) {
+        real lu = tr.Rd[c] * u[c], luu = tr.Rd[c];
+        real cc = u[c] - tr.uhi[c], lm = lam[c];
+        bool act = (cc > 0 || lm > 0);
+        lu += lm + (act ? mu * cc : (real)0);
+        luu += act ? mu : (real)0;
+        cc = tr.ulo[c] - u[c]; lm = lam[3 + c];
+        act = (cc > 0 || lm > 0);
+        lu -= lm + (act ? mu * cc : (real)0);
+        luu += act ? mu : (real)0;
+        rc[R_LU + c] = lu;
+        rc[R_LUU + c] = luu;
+      }
+    }
+    TSAT_SYNC();
+    // ---- Riccati recursion over the chunk, last knot first -----------------------------------
+    for (int l = nk - 1; l >= 0; --l) {
+      const real* rc = rec + l * RECS;
+      const real* F = rc + R_F;
+      // step 1: W~ = [S; s'] [A|B]   (8 x 10)
+      {
+        real acc = 0, acc2 = 0;
+        for (int m = 0; m < 7; ++m) {
+          const real sv = St[r1 * 9 + m];
+          acc += sv * F[c1 * 8 + m];
+          if (c1 < 2) acc2 += sv * F[(8 + c1) * 8 + m];
+        }
+        Wt[c1 * 9 + r1] = acc;
+        if (c1 < 2) Wt[(8 + c1) * 9 + r1] = acc2;
+      }
+      TSAT_SYNC();
+      // step 2: Qxx = Q + A'SA, Qux = B'SA, Quu = luu + B'SB, Qu = lu + B's
+      if (o1 >= 0) {
+        real acc = diag2;
+        if (luu2 >= 0) acc = rc[R_LUU + luu2];
+        for (int m = 0; m < 7; ++m) acc += F[colA * 8 + m] * Wt[colB * 9 + m];
+        lds[o1] = acc;
+        lds[o2] = acc;
+      } else if (o1 == -2) {
+        const int aa = lane - 55;
+        Hux[aa * 8 + 7] = rc[R_LU + aa] + Wt[(7 + aa) * 9 + 7];
+      }
+      TSAT_SYNC();
+      // step 3: regularise, PD test (Sylvester), adjugate inverse, K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu
+      real Qi0, Qi1, Qi2;
+      {
+        const real q00 = Huu[0] + rho, q11 = Huu[4] + rho, q22 = Huu[8] + rho;
+        const real q10 = Huu[1], q20 = Huu[2], q21 = Huu[5];
+        const real c00 = q11 * q22 - q21 * q21;
+        const real c01 = q20 * q21 - q10 * q22;
+        const real c02 = q10 * q21 - q20 * q11;
+        const real c11 = q00 * q22 - q20 * q20;
+        const real c12 = q10 * q20 - q00 * q21;
+        const real c22 = q00 * q11 - q10 * q10;
+        const real det = q00 * c00 + q10 * c01 + q20 * c02;
+        if (!(q00 > 0 && c22 > 0 && det > 0)) pd_ok = false;
+        const real id = rcp_(det);
+        // row a3 of the inverse
+        Qi0 = ((a3 == 0) ? c00 : (a3 == 1 ? c01 : c02)) * id;
+        Qi1 = ((a3 == 0) ? c01 : (a3 == 1 ? c11 : c12)) * id;
+        Qi2 = ((a3 == 0) ? c02 : (a3 == 1 ? c12 : c22)) * id;
+      }
+      if (!pd_ok) break;  // wave-uniform: every lane read the same Huu
+      if (a3 < 3) {
+        const real v = -(Qi0 * Hux[0 * 8 + j3] + Qi1 * Hux[1 * 8 + j3] + Qi2 * Hux[2 * 8 + j3]);
+        KDs[a3 * 8 + j3] = v;
+        KDg[(size_t)(k0 + l) * KDW + ((j3 < 7) ? (a3 * 7 + j3) : (21 + a3))] = v;
+      }
+      TSAT_SYNC();
+      // step 4: cost-to-go. With K = -Quu_reg^-1 Qux: Quu K + Qux = -rho K, so
+      //   Sxx = Qxx + sym(Qux'K) - rho K'K ;  Sx = Qx + Qux'd - rho K'd   (Appendix A, compacted)
+      {
+        const real d0 = KDs[7], d1 = KDs[15], d2 = KDs[23];
+        const real qu0 = Hux[7], qu1 = Hux[15], qu2 = Hux[23];
+        dV1 += d0 * qu0 + d1 * qu1 + d2 * qu2;
+        const real t0 = Huu[0] * d0 + Huu[1] * d1 + Huu[2] * d2;
+        const real t1 = Huu[3] * d0 + Huu[4] * d1 + Huu[5] * d2;
+        const real t2 = Huu[6] * d0 + Huu[7] * d1 + Huu[8] * d2;
+        dV2 += (real)0.5 * (d0 * t0 + d1 * t1 + d2 * t2);
+        if (lane < 28) {
+          real acc = Hxx[i4 * 7 + j4];
+          real sy = 0, kk = 0;
+          for (int c = 0; c < 3; ++c) {
+            sy += Hux[c * 8 + i4] * KDs[c * 8 + j4] + Hux[c * 8 + j4] * KDs[c * 8 + i4];
+            kk += KDs[c * 8 + i4] * KDs[c * 8 + j4];
+          }
+          acc += (real)0.5 * sy - rho * kk;
+          St[i4 * 9 + j4] = acc;
+          St[j4 * 9 + i4] = acc;
+        } else if (lane < 35) {
+          const int i = lane - 28;
+          real acc = rc[R_LX + i] + Wt[i * 9 + 7];
+          acc += (Hux[0 * 8 + i] * d0 + Hux[1 * 8 + i] * d1 + Hux[2 * 8 + i] * d2);
+          acc -= rho * (KDs[0 * 8 + i] * d0 + KDs[1 * 8 + i] * d1 + KDs[2 * 8 + i] * d2);
+          St[7 * 9 + i] = acc;
+        }
+      }
+      TSAT_SYNC();
+    }
+    TSAT_SYNC();
+  }
+  *dV1_out = dV1;
+  *dV2_out = dV2;
+  return pd_ok;
+}
+
+// --------------------------------------------------------------------------------------------------
+// parallel-in-k passes
+// --------------------------------------------------------------------------------------------------
+// AL (or plain LQR) cost of the nominal trajectory
+template <typename real>
+TSAT_DEV real nominal_cost(const KArgs<real>& a, const Traj<real>& tr, int traj, const real nu[7], real mu,
+                           bool with_al, real* lds) {
+  const int lane = TSAT_LANE();
+  const int N = tr.N;
+  const real* XUg = a.XU + (size_t)traj * N * XUW;
+  const real* LMg = a.LAM + (size_t)traj * (N - 1) * LMW;
+  real J = 0;
+  for (int k = lane; k < N; k += WAVE) {
+    real x[7], u[3], lam[6];
+    for (int i = 0; i < 7; ++i) x[i] = XUg[(size_t)k * XUW + i];
+    if (k < N - 1) {
+      for (int c = 0; c < 3; ++c) u[c] = XUg[(size_t)k * XUW + 7 + c];
+      for (int c = 0; c < 6; ++c) lam[c] = LMg[(size_t)k * LMW + c];
+      J += stage_cost(tr, x, u, lam, mu, with_al);
+    } else {
+      J += term_cost(tr, x, nu, mu, a.opt.terminal_mask, with_al);
+    }
+  }
+  return wave_sum(J, lds + L_RED);
+}
+
+// max constraint violation of the nominal trajectory
+template <typename real>
+TSAT_DEV real nominal_violation(const KArgs<real>& a, const Traj<real>& tr, int traj, real* lds) {
+  const int lane = TSAT_LANE();
+  const int N = tr.N;
+  const real* XUg = a.XU + (size_t)traj * N * XUW;
+  real c = 0;
+  for (int k = lane; k < N; k += WAVE) {
+    if (k < N - 1) {
+      for (int m = 0; m < 3; ++m) {
+        const real u = XUg[(size_t)k * XUW + 7 + m];
+        c = fmax_(c, u - tr.uhi[m]);
+        c = fmax_(c, tr.ulo[m] - u);
+      }
+    } else {
+      for (int i = 0; i < 7; ++i)
+        if ((a.opt.terminal_mask >> i) & 1) c = fmax_(c, fabs_(XUg[(size_t)k * XUW + i] - tr.xf[i]));
+    }
+  }
+  return wave_max(c, lds + L_RED);
+}
+
+// dual update of the control-box multipliers (Appendix A "solve_AL")
+template <typename real>
+TSAT_DEV void dual_update(const KArgs<real>& a, const Traj<real>& tr, int traj, real mu) {
+  const int lane = TSAT_LANE();
+  const int N = tr.N;
+  const real* XUg = a.XU + (size_t)traj * N * XUW;
+  real* LMg = a.LAM + (size_t)traj * (N - 1) * LMW;
+  const real dmax = (real)a.opt.dual_max;
+  for (int k = lane; k < N - 1; k += WAVE) {
+    for (int m = 0; m < 3; ++m) {
+      const real u = XUg[(size_t)k * XUW + 7 + m];
+      real l = LMg[(size_t)k * LMW + m] + mu * (u - tr.uhi[m]);
+      l = l > 0 ? l : (real)0; l = l < dmax ? l : dmax;
+      LMg[(size_t)k * LMW + m] = l;
+      l = LMg[(size_t)k * LMW + 3 + m] + mu * (tr.ulo[m] - u);
+      l = l > 0 ? l : (real)0; l = l < dmax ? l : dmax;
+      LMg[(size_t)k * LMW + 3 + m] = l;
+    }
+  }
+}
+
+// adopt candidate `jw` as the nominal trajectory (or keep it when jw < 0) and return the Todorov gradient
+// mean_k max_i |d_k,i| / (|u_k,i| + 1) evaluated with the (new) nominal controls.
+template <typename real>
+TSAT_DEV real adopt_and_gradient(const KArgs<real>& a, const Traj<real>& tr, int traj, int jw, real* lds) {
+  const int lane = TSAT_LANE();
+  const int N = tr.N;
+  real* XUg = a.XU + (size_t)traj * N * XUW;
+  const real* KDg = a.KD + (size_t)traj * (N - 1) * KDW;
+  const real* Cg = a.CAND + ((size_t)traj * a.max_ls + (jw >= 0 ? jw : 0)) * (size_t)N * XUW;
+  real g = 0;
+  for (int k = lane; k < N; k += WAVE) {
+    real r[10];
+    const real* src = (jw >= 0) ? (Cg + (size_t)k * XUW) : (XUg + (size_t)k * XUW);
+    for (int i = 0; i < 10; ++i) r[i] = src[i];
+    if (jw >= 0)
+      for (int i = 0; i < 10; ++i) XUg[(size_t)k * XUW + i] = r[i];
+    if (k < N - 1) {
+      real m = 0;
+      for (int c = 0; c < 3; ++c) m = fmax_(m, fabs_(KDg[(size_t)k * KDW + 21 + c]) / (fabs_(r[7 + c]) + (real)1));
+      g += m;
+    }
+  }
+  g = wave_sum(g, lds + L_RED);
+  return g / (real)(N - 1);
+}
+
+// --------------------------------------------------------------------------------------------------
+// the whole AL-iLQR solve of one trajectory by one wavefront
+// --------------------------------------------------------------------------------------------------
+template <typename real, int INTEG>
+TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, real* lds) {
+  const int lane = TSAT_LANE();
+  const tsat_options& o = a.opt;
+  const int N = a.N;
+  const real* P = a.P + (size_t)traj * PSTRIDE;
+  Traj<real> tr;
+  for (int i = 0; i < 7; ++i) { tr.xf[i] = P[P_XF + i]; tr.Qd[i] = P[P_QD + i]; tr.Qfd[i] = P[P_QFD + i]; }
+  for (int i = 0; i < 3; ++i) { tr.Rd[i] = P[P_RD + i]; tr.ulo[i] = P[P_ULO + i]; tr.uhi[i] = P[P_UHI + i]; }
+  tr.h = P[P_DT];
+  tr.hh = (real)0.5 * tr.h;
+  for (int i = 0; i < 9; ++i) { tr.J[i] = P[P_J + i]; tr.hJi[i] = tr.h * P[P_JI + i]; }
+  tr.us = (real)o.u_scale;
+  tr.tau0 = (double)P[P_TAU0];
+  tr.dtau = (double)P[P_DTAU];
+  tr.N = N;
+  tr.n_tab = a.n_tab;
+  tr.bt = a.BT + (size_t)a.bidx[traj] * a.n_tab * 4;
+
+  real* XUg = a.XU + (size_t)traj * N * XUW;
+  real* LMg = a.LAM + (size_t)traj * (N - 1) * LMW;
+  const real* U0g = a.U0 + (size_t)traj * (N - 1) * 3;
+  double* trace = a.trace ? a.trace + (size_t)traj * a.trace_rows * 8 : nullptr;
+  int trow = 0;
+
+  // initial_controls!(prob, U0) (src/TortoiseSat.jl:191) + zero multipliers
+  for (int k = lane; k < N; k += WAVE) {
+    for (int i = 0; i < 7; ++i) XUg[(size_t)k * XUW + i] = 0;
+    for (int c = 0; c < 3; ++c) XUg[(size_t)k * XUW + 7 + c] = (k < N - 1) ? U0g[(size_t)k * 3 + c] : (real)0;
+    if (k < N - 1)
+      for (int c = 0; c < 6; ++c) LMg[(size_t)k * LMW + c] = 0;
+  }
+  real nu[7];
+  for (int i = 0; i < 7; ++i) nu[i] = 0;
+  real mu = (real)o.penalty_init;
+  TSAT_SYNC();
+
+  int status = TSAT_MAX_OUTER, outer_iters = 0, inner_iters = 0, ls_trials = 0, n_backward = 0, n_forward = 0,
+      bp_restarts = 0, fp_fails = 0;
+  real grad = 0;
+
+  // open-loop rollout of U0
+  bool ok;
+  real J0 = forward_sweep<real, INTEG>(a, tr, traj, false, 1, nu, mu, lds, &ok);
+  n_forward++;
+  J0 = wave_bcast(J0, 0, lds + L_RED);
+  const int ok0 = wave_first<real>(!ok, lds + L_RED) > 0;  // lane 0 ok?
+  (void)adopt_and_gradient(a, tr, traj, 0, lds);
+  TSAT_SYNC();
+  if (!ok0 || !(J0 - J0 == 0)) {
+    status = TSAT_DIVERGED;
+  } else {
+    for (int outer = 1; outer <= o.max_outer; ++outer) {
+      real Jprev = nominal_cost(a, tr, traj, nu, mu, true, lds);
+      real rho = (real)o.reg_init, drho = 0;
+      int djz = 0;
+      bool regfail = false;
+      for (int it = 1; it <= o.max_inner; ++it) {
+        real dV1 = 0, dV2 = 0;
+        for (;;) {
+          n_backward++;
+          if (backward_sweep<real, INTEG>(a, tr, traj, nu, mu, rho, lds, &dV1, &dV2)) break;
+          bp_restarts++;
+          drho = (drho * (real)o.reg_scale > (real)o.reg_scale) ? drho * (real)o.reg_scale : (real)o.reg_scale;
+          rho = (rho * drho > (real)o.reg_min) ? rho * drho : (real)o.reg_min;
+          if (rho > (real)o.reg_max) { regfail = true; break; }
+        }
+        if (regfail) break;
+        const real rho_used = rho;
+        {  // regularisation decrease
+          const real inv = (real)1 / (real)o.reg_scale;
+          drho = (drho / (real)o.reg_scale < inv) ? drho / (real)o.reg_scale : inv;
+          const real r = rho * drho;
+          rho = (r > (real)o.reg_min) ? r : (real)0;
+        }
+        TSAT_SYNC();
+        // all backtracking trials in one sweep
+        const real Jc = forward_sweep<real, INTEG>(a, tr, traj, true, o.max_linesearch, nu, mu, lds, &ok);
+        n_forward++;
+        real alpha = 1;
+        for (int j = 0; j < lane && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (real)0.5;
+        const real expected = -alpha * (dV1 + alpha * dV2);
+        const real z = (expected > 0) ? (Jprev - Jc) / expected : (real)-1;
+        const bool acc = (lane < o.max_linesearch) && ok &&
+                         ((z > (real)o.ls_lower && z <= (real)o.ls_upper) || Jc < Jprev);
+        const int jw = wave_first<real>(acc, lds + L_RED);
+        real J;
+        if (jw < WAVE) {
+          J = wave_bcast(Jc, jw, lds + L_RED);
+          ls_trials += jw + 1;
+          grad = adopt_and_gradient(a, tr, traj, jw, lds);
+        } else {
+          J = Jprev;
+          ls_trials += o.max_linesearch;
+          fp_fails++;
+          drho = (drho * (real)o.reg_scale > (real)o.reg_scale) ? drho * (real)o.reg_scale : (real)o.reg_scale;
+          rho = (rho * drho > (real)o.reg_min) ? rho * drho : (real)o.reg_min;
+          rho += (real)o.reg_fp;
+          grad = adopt_and_gradient(a, tr, traj, -1, lds);
+        }
+        TSAT_SYNC();
+        real dJ = J - Jprev;
+        dJ = dJ < 0 ? -dJ : dJ;
+        if (trace && lane == 0 && trow < a.trace_rows) {
+          double* r = trace + 8 * trow;
+          r[0] = outer; r[1] = it; r[2] = (double)Jprev; r[3] = (double)J; r[4] = (jw < WAVE) ? jw : -1;
+          r[5] = (double)rho_used; r[6] = (double)dV1; r[7] = (double)dV2;
+        }
+        trow++;
+        Jprev = J;
+        djz = (dJ == 0) ? djz + 1 : 0;
+        inner_iters++;
+        if (0 < dJ && dJ < (real)o.cost_tol) break;
+        if (grad < (real)o.grad_tol) break;
+        if (djz > o.dj_counter_limit) break;
+      }
+      outer_iters = outer;
+      const real cmax = nominal_violation(a, tr, traj, lds);
+      if (regfail) { status = TSAT_REG_FAIL; break; }
+      if (cmax < (real)o.constraint_tol) { status = TSAT_CONVERGED; break; }
+      if (outer == o.max_outer) break;
+      dual_update(a, tr, traj, mu);
+      {
+        const real* xN = XUg + (size_t)(N - 1) * XUW;
+        const real dmax = (real)o.dual_max;
+        for (int i = 0; i < 7; ++i)
+          if ((o.terminal_mask >> i) & 1) {
+            real v = nu[i] + mu * (xN[i] - tr.xf[i]);
+            v = v > -dmax ? v : -dmax; v = v < dmax ? v : dmax;
+            nu[i] = v;
+          }
+      }
+      mu = (mu * (real)o.penalty_scale < (real)o.penalty_max) ? mu * (real)o.penalty_scale : (real)o.penalty_max;
+      TSAT_SYNC();
+    }
+  }
+  TSAT_SYNC();
+  const real cmax = nominal_violation(a, tr, traj, lds);
+  const real cost = nominal_cost(a, tr, traj, nu, mu, false, lds);
+  const real cost_al = nominal_cost(a, tr, traj, nu, mu, true, lds);
+  if (lane == 0) {
+    tsat_stats& st = a.stats[traj];
+    st.status = status; st.outer_iters = outer_iters; st.inner_iters = inner_iters; st.ls_trials = ls_trials;
+    st.n_backward = n_backward; st.n_forward = n_forward; st.bp_restarts = bp_restarts; st.fp_fails = fp_fails;
+    st.cost = (double)cost; st.cost_al = (double)cost_al; st.c_max = (double)cmax; st.grad = (double)grad;
+  }
+}
+
+}  // namespace tsat

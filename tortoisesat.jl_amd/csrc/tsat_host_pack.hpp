@@ -1,0 +1,114 @@
+// tsat_host_pack.hpp — host-side marshalling between the C ABI arrays (include/tortoise_hip.h) and the
+// device-resident layouts of tsat_device.hpp. Pure C++ (no HIP) so the CPU lane-emulator in tests/emu
+// exercises exactly the same packing code as libtortoise_hip.so.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "tsat_device.hpp"
+
+namespace tsat {
+
+// closed-form inverse of the 3x3 inertia (column-major in, row-major out); replaces inv(p.J) evaluated on every
+// dynamics call by the reference (src/DerivFunction.jl:41)
+inline void inertia_inverse_rm(const double* Jcm, double* Jrm, double* Jirm) {
+  auto m = [&](int r, int c) { return Jcm[r + 3 * c]; };
+  const double c00 = m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1);
+  const double c01 = m(1, 2) * m(2, 0) - m(1, 0) * m(2, 2);
+  const double c02 = m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0);
+  const double det = m(0, 0) * c00 + m(0, 1) * c01 + m(0, 2) * c02;
+  const double id = 1.0 / det;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Jrm[3 * r + c] = m(r, c);
+  Jirm[0] = c00 * id;
+  Jirm[3] = c01 * id;
+  Jirm[6] = c02 * id;
+  Jirm[1] = (m(0, 2) * m(2, 1) - m(0, 1) * m(2, 2)) * id;
+  Jirm[4] = (m(0, 0) * m(2, 2) - m(0, 2) * m(2, 0)) * id;
+  Jirm[7] = (m(0, 1) * m(2, 0) - m(0, 0) * m(2, 1)) * id;
+  Jirm[2] = (m(0, 1) * m(1, 2) - m(0, 2) * m(1, 1)) * id;
+  Jirm[5] = (m(0, 2) * m(1, 0) - m(0, 0) * m(1, 2)) * id;
+  Jirm[8] = (m(0, 0) * m(1, 1) - m(0, 1) * m(1, 0)) * id;
+}
+
+// validate an options block against a reserved batch; returns "" or an error text
+inline std::string check_options(const tsat_options& o, int N, int n_tab, int max_ls_reserved) {
+  if (o.n_knots != N) return "options.n_knots does not match the reserved batch";
+  if (o.n_tab != n_tab) return "options.n_tab does not match the reserved batch";
+  if (N < 2) return "n_knots must be >= 2";
+  if (n_tab < 1) return "n_tab must be >= 1";
+  if (o.integrator != 3 && o.integrator != 4) return "integrator must be 3 (rk3) or 4 (rk4)";
+  if (o.precision != 64) return "only precision = 64 is implemented";
+  if (o.error_state != 0) return "error_state = 1 is reserved (not implemented)";
+  if (o.max_linesearch < 1 || o.max_linesearch > TSAT_MAX_LINESEARCH) return "max_linesearch must be in [1,32]";
+  if (o.max_linesearch > max_ls_reserved) return "max_linesearch exceeds the reserved candidate slots";
+  if (o.max_outer < 1 || o.max_inner < 1) return "iteration budgets must be >= 1";
+  if (!(o.reg_scale > 1.0)) return "reg_scale must be > 1";
+  if (!(o.penalty_scale >= 1.0) || !(o.penalty_init > 0.0)) return "penalty_init > 0 and penalty_scale >= 1 required";
+  return "";
+}
+
+// pack per-trajectory parameters into [T][PSTRIDE] records
+template <typename real>
+void pack_params(int64_t T, const double* x0, const double* xf, const double* tau0, const double* dtau,
+                 const double* dt, const double* Jmat, const double* Qd, const double* Qfd, const double* Rd,
+                 const double* ulo, const double* uhi, real* P) {
+  for (int64_t t = 0; t < T; ++t) {
+    real* p = P + (size_t)t * PSTRIDE;
+    for (int i = 0; i < PSTRIDE; ++i) p[i] = 0;
+    for (int i = 0; i < 7; ++i) {
+      p[P_X0 + i] = (real)x0[7 * t + i];
+      p[P_XF + i] = (real)xf[7 * t + i];
+      p[P_QD + i] = (real)Qd[7 * t + i];
+      p[P_QFD + i] = (real)Qfd[7 * t + i];
+    }
+    for (int i = 0; i < 3; ++i) {
+      p[P_RD + i] = (real)Rd[3 * t + i];
+      p[P_ULO + i] = (real)ulo[3 * t + i];
+      p[P_UHI + i] = (real)uhi[3 * t + i];
+    }
+    double Jr[9], Ji[9];
+    inertia_inverse_rm(Jmat + 9 * t, Jr, Ji);
+    for (int i = 0; i < 9; ++i) { p[P_J + i] = (real)Jr[i]; p[P_JI + i] = (real)Ji[i]; }
+    p[P_TAU0] = (real)tau0[t];
+    p[P_DTAU] = (real)dtau[t];
+    p[P_DT] = (real)dt[t];
+  }
+}
+
+// B tables [n_btab][n_tab][3] -> [n_btab][n_tab][4] (rows padded to 32 bytes for aligned 16-byte loads)
+template <typename real>
+void pack_btab(int64_t n_btab, int n_tab, const double* Btab, real* BT) {
+  for (int64_t i = 0; i < n_btab * (int64_t)n_tab; ++i) {
+    BT[4 * i + 0] = (real)Btab[3 * i + 0];
+    BT[4 * i + 1] = (real)Btab[3 * i + 1];
+    BT[4 * i + 2] = (real)Btab[3 * i + 2];
+    BT[4 * i + 3] = 0;
+  }
+}
+
+// element-wise export of the resident records into the ABI result arrays; `e` indexes knot records.
+//   X (T,N,7) <- XU[.,.,0:7];  U (T,N-1,3) <- XU[.,.,7:10];  K (T,N-1,7,3)[t][k][j][a] <- KD[t][k][a*7+j]
+template <typename real>
+TSAT_DEV void export_record(int64_t e, int N, const real* XU, const real* KD, double* X, double* U, double* K) {
+  const int64_t t = e / N;
+  const int k = (int)(e - t * N);
+  const real* r = XU + (size_t)e * XUW;
+  if (X)
+    for (int i = 0; i < 7; ++i) X[(size_t)e * 7 + i] = (double)r[i];
+  if (k < N - 1) {
+    const size_t ek = (size_t)t * (N - 1) + k;
+    if (U)
+      for (int c = 0; c < 3; ++c) U[ek * 3 + c] = (double)r[7 + c];
+    if (K) {
+      const real* kd = KD + ek * KDW;
+      for (int j = 0; j < 7; ++j)
+        for (int c = 0; c < 3; ++c) K[ek * 21 + j * 3 + c] = (double)kd[c * 7 + j];
+    }
+  }
+}
+
+}  // namespace tsat

@@ -1,0 +1,294 @@
+// tsat_kernels.hip — gfx950 kernels + the C ABI of include/tortoise_hip.h (libtortoise_hip.so).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared tsat_kernels.hip -o libtortoise_hip.so
+// One wavefront (a 64-thread workgroup) owns one trajectory for the whole AL-iLQR solve; see tsat_device.hpp.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "tsat_host_pack.hpp"
+
+using namespace tsat;
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+template <typename real, int INTEG>
+__global__ __launch_bounds__(64) void tsat_solve_kernel(KArgs<real> a) {
+  extern __shared__ __align__(16) unsigned char tsat_smem[];
+  const int traj = blockIdx.x;
+  if (traj >= a.T) return;
+  solve_trajectory<real, INTEG>(a, traj, reinterpret_cast<real*>(tsat_smem));
+}
+
+template <typename real>
+__global__ __launch_bounds__(256) void tsat_export_kernel(int64_t n_rec, int N, const real* XU, const real* KD,
+                                                          double* X, double* U, double* K) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_rec) export_record<real>(e, N, XU, KD, X, U, K);
+}
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+struct tsat_handle {
+  int dev = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  // reserved batch
+  int64_t T = 0, n_btab = 0;
+  int N = 0, n_tab = 0, max_ls = 0, trace_rows = 0;
+  bool uploaded = false, solved = false;
+  double *P = nullptr, *BT = nullptr, *U0 = nullptr, *XU = nullptr, *KD = nullptr, *LAM = nullptr, *CAND = nullptr;
+  int* bidx = nullptr;
+  tsat_stats* stats = nullptr;
+  double* trace = nullptr;
+  int64_t bytes = 0;
+};
+
+namespace {
+
+int fail(tsat_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+#define TSAT_HIP(h, call)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail((h), -10, std::string(#call) + ": " + hipGetErrorString(e_));                \
+  } while (0)
+
+void release(tsat_handle* h) {
+  void* ptrs[] = {h->P, h->BT, h->U0, h->XU, h->KD, h->LAM, h->CAND, h->bidx, h->stats, h->trace};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  h->P = h->BT = h->U0 = h->XU = h->KD = h->LAM = h->CAND = nullptr;
+  h->bidx = nullptr; h->stats = nullptr; h->trace = nullptr;
+  h->T = 0; h->bytes = 0; h->uploaded = h->solved = false;
+}
+
+template <typename Tp>
+int dev_alloc(tsat_handle* h, Tp** p, size_t n) {
+  const size_t b = n * sizeof(Tp);
+  TSAT_HIP(h, hipMalloc(reinterpret_cast<void**>(p), b ? b : 16));
+  h->bytes += (int64_t)b;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsat_version(void) { return 100; }
+
+void tsat_default_options(tsat_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->integrator = 3; o->precision = 64;
+  o->max_outer = 20; o->max_inner = 50;            // src/TortoiseSat.jl:195-196
+  o->max_linesearch = 20; o->dj_counter_limit = 10;
+  o->cost_tol = 1e-4; o->grad_tol = 1e-5; o->constraint_tol = 1e-3;
+  o->penalty_init = 1.0; o->penalty_scale = 10.0; o->penalty_max = 1e8; o->dual_max = 1e8;
+  o->reg_init = 0.0; o->reg_scale = 1.6; o->reg_min = 1e-8; o->reg_max = 1e8; o->reg_fp = 10.0;
+  o->ls_lower = 1e-8; o->ls_upper = 10.0; o->max_state = 1e8;
+  o->u_scale = 1e-2;                               // src/DerivFunction.jl:37
+  o->terminal_mask = 0x7f; o->error_state = 0;
+}
+
+int tsat_create(tsat_handle** out, int device_id) {
+  if (!out) return -1;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -2;  // no GPU: there is no CPU fallback
+  if (device_id < 0 || device_id >= n) return -3;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return -4;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return -5;  // code object is gfx950-only
+  if (hipSetDevice(device_id) != hipSuccess) return -6;
+  tsat_handle* h = new tsat_handle();
+  h->dev = device_id;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    delete h;
+    return -7;
+  }
+  *out = h;
+  return 0;
+}
+
+int tsat_destroy(tsat_handle* h) {
+  if (!h) return -1;
+  (void)hipSetDevice(h->dev);
+  release(h);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+const char* tsat_last_error(const tsat_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int64_t tsat_batch_bytes(const tsat_handle* h) { return h ? h->bytes : 0; }
+
+int tsat_batch_reserve(tsat_handle* h, int64_t T, int32_t n_knots, int32_t n_tab, int64_t n_btab,
+                       int32_t max_linesearch) {
+  if (!h) return -1;
+  if (T < 1 || n_knots < 2 || n_tab < 1 || n_btab < 1) return fail(h, -1, "bad batch dimensions");
+  if (max_linesearch < 1 || max_linesearch > TSAT_MAX_LINESEARCH) return fail(h, -1, "max_linesearch must be in [1,32]");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  if (h->T == T && h->N == n_knots && h->n_tab == n_tab && h->n_btab == n_btab && h->max_ls == max_linesearch)
+    return 0;
+  const int trows = h->trace_rows;
+  release(h);
+  const size_t N = (size_t)n_knots, Tn = (size_t)T;
+  int rc = 0;
+  rc |= dev_alloc(h, &h->P, Tn * PSTRIDE);
+  rc |= dev_alloc(h, &h->BT, (size_t)n_btab * n_tab * 4);
+  rc |= dev_alloc(h, &h->bidx, Tn);
+  rc |= dev_alloc(h, &h->U0, Tn * (N - 1) * 3);
+  rc |= dev_alloc(h, &h->XU, Tn * N * XUW);
+  rc |= dev_alloc(h, &h->KD, Tn * (N - 1) * KDW);
+  rc |= dev_alloc(h, &h->LAM, Tn * (N - 1) * LMW);
+  rc |= dev_alloc(h, &h->CAND, Tn * (size_t)max_linesearch * N * XUW);
+  rc |= dev_alloc(h, &h->stats, Tn);
+  if (trows > 0) rc |= dev_alloc(h, &h->trace, Tn * (size_t)trows * 8);
+  if (rc) { release(h); return -10; }
+  h->T = T; h->N = n_knots; h->n_tab = n_tab; h->n_btab = n_btab; h->max_ls = max_linesearch;
+  h->trace_rows = trows;
+  return 0;
+}
+
+int tsat_batch_trace(tsat_handle* h, int32_t rows) {
+  if (!h || rows < 0) return -1;
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  if (h->trace) { (void)hipFree(h->trace); h->trace = nullptr; }
+  h->trace_rows = rows;
+  if (rows > 0 && h->T > 0) {
+    if (dev_alloc(h, &h->trace, (size_t)h->T * rows * 8)) return -10;
+  }
+  return 0;
+}
+
+int tsat_batch_upload(tsat_handle* h, const double* x0, const double* xf, const double* Btab,
+                      const int32_t* btab_idx, const double* tau0, const double* dtau, const double* dt,
+                      const double* Jmat, const double* Qd, const double* Qfd, const double* Rd,
+                      const double* ulo, const double* uhi, const double* U0) {
+  if (!h) return -1;
+  if (h->T < 1) return fail(h, -1, "tsat_batch_reserve has not been called");
+  if (!x0 || !xf || !Btab || !tau0 || !dtau || !dt || !Jmat || !Qd || !Qfd || !Rd || !ulo || !uhi || !U0)
+    return fail(h, -1, "null input array");
+  if (!btab_idx && h->n_btab != h->T) return fail(h, -1, "btab_idx is NULL but n_btab != T");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  const int64_t T = h->T;
+  std::vector<int> bi((size_t)T);
+  for (int64_t t = 0; t < T; ++t) {
+    const int64_t v = btab_idx ? btab_idx[t] : t;
+    if (v < 0 || v >= h->n_btab) return fail(h, -1, "btab_idx out of range");
+    bi[(size_t)t] = (int)v;
+  }
+  for (int64_t t = 0; t < T; ++t)
+    if (!(dt[t] > 0.0)) return fail(h, -1, "dt must be positive");
+  std::vector<double> P((size_t)T * PSTRIDE), BT((size_t)h->n_btab * h->n_tab * 4);
+  pack_params<double>(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, P.data());
+  pack_btab<double>(h->n_btab, h->n_tab, Btab, BT.data());
+  TSAT_HIP(h, hipMemcpy(h->P, P.data(), P.size() * sizeof(double), hipMemcpyHostToDevice));
+  TSAT_HIP(h, hipMemcpy(h->BT, BT.data(), BT.size() * sizeof(double), hipMemcpyHostToDevice));
+  TSAT_HIP(h, hipMemcpy(h->bidx, bi.data(), bi.size() * sizeof(int), hipMemcpyHostToDevice));
+  TSAT_HIP(h, hipMemcpy(h->U0, U0, (size_t)T * (h->N - 1) * 3 * sizeof(double), hipMemcpyHostToDevice));
+  h->uploaded = true;
+  h->solved = false;
+  return 0;
+}
+
+int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
+  if (!h || !o) return -1;
+  if (!h->uploaded) return fail(h, -1, "tsat_batch_upload has not been called");
+  const std::string why = check_options(*o, h->N, h->n_tab, h->max_ls);
+  if (!why.empty()) return fail(h, -1, why);
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  KArgs<double> a;
+  a.T = (int)h->T; a.N = h->N; a.n_tab = h->n_tab; a.max_ls = h->max_ls; a.opt = *o;
+  a.P = h->P; a.BT = h->BT; a.bidx = h->bidx; a.U0 = h->U0;
+  a.XU = h->XU; a.KD = h->KD; a.LAM = h->LAM; a.CAND = h->CAND;
+  a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
+  const size_t lds = (size_t)LDS_REALS * sizeof(double);
+  auto kern = (o->integrator == 3) ? tsat_solve_kernel<double, 3> : tsat_solve_kernel<double, 4>;
+  TSAT_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (h->trace) TSAT_HIP(h, hipMemsetAsync(h->trace, 0, (size_t)h->T * h->trace_rows * 8 * sizeof(double), h->stream));
+  TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(kern, dim3((unsigned)h->T), dim3(64), lds, h->stream, a);
+  TSAT_HIP(h, hipGetLastError());
+  TSAT_HIP(h, hipEventRecord(h->ev1, h->stream));
+  TSAT_HIP(h, hipStreamSynchronize(h->stream));
+  if (kernel_ms) TSAT_HIP(h, hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
+  h->solved = true;
+  return 0;
+}
+
+int tsat_batch_export_device(tsat_handle* h, void* X_dev, void* U_dev, void* K_dev, void* stats_dev) {
+  if (!h) return -1;
+  if (!h->solved) return fail(h, -1, "tsat_batch_run has not been called");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  const int64_t n_rec = h->T * (int64_t)h->N;
+  if (X_dev || U_dev || K_dev) {
+    const unsigned blocks = (unsigned)((n_rec + 255) / 256);
+    hipLaunchKernelGGL(tsat_export_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, n_rec, h->N, h->XU, h->KD,
+                       (double*)X_dev, (double*)U_dev, (double*)K_dev);
+    TSAT_HIP(h, hipGetLastError());
+  }
+  if (stats_dev)
+    TSAT_HIP(h, hipMemcpyAsync(stats_dev, h->stats, (size_t)h->T * sizeof(tsat_stats), hipMemcpyDeviceToDevice, h->stream));
+  TSAT_HIP(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int tsat_batch_download(tsat_handle* h, double* X, double* U, double* K, tsat_stats* stats) {
+  if (!h) return -1;
+  if (!h->solved) return fail(h, -1, "tsat_batch_run has not been called");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  const size_t T = (size_t)h->T, N = (size_t)h->N;
+  double *dX = nullptr, *dU = nullptr, *dK = nullptr;
+  int rc = 0;
+  if (X && hipMalloc((void**)&dX, T * N * 7 * sizeof(double)) != hipSuccess) rc = -10;
+  if (!rc && U && hipMalloc((void**)&dU, T * (N - 1) * 3 * sizeof(double)) != hipSuccess) rc = -10;
+  if (!rc && K && hipMalloc((void**)&dK, T * (N - 1) * 21 * sizeof(double)) != hipSuccess) rc = -10;
+  if (!rc) rc = tsat_batch_export_device(h, dX, dU, dK, nullptr);
+  if (!rc && X && hipMemcpy(X, dX, T * N * 7 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && U && hipMemcpy(U, dU, T * (N - 1) * 3 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && K && hipMemcpy(K, dK, T * (N - 1) * 21 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && stats && hipMemcpy(stats, h->stats, T * sizeof(tsat_stats), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (dX) (void)hipFree(dX);
+  if (dU) (void)hipFree(dU);
+  if (dK) (void)hipFree(dK);
+  if (rc == -10) h->err = "device allocation or copy failed in tsat_batch_download";
+  return rc;
+}
+
+int tsat_batch_trace_download(tsat_handle* h, double* trace) {
+  if (!h || !trace) return -1;
+  if (!h->trace) return fail(h, -1, "tracing is disabled");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  TSAT_HIP(h, hipMemcpy(trace, h->trace, (size_t)h->T * h->trace_rows * 8 * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int tsat_solve_batch(tsat_handle* h, const tsat_options* o, int64_t T, int64_t n_btab, const double* x0,
+                     const double* xf, const double* Btab, const int32_t* btab_idx, const double* tau0,
+                     const double* dtau, const double* dt, const double* Jmat, const double* Qd,
+                     const double* Qfd, const double* Rd, const double* ulo, const double* uhi, const double* U0,
+                     double* X, double* U, double* K, tsat_stats* stats) {
+  if (!h || !o) return -1;
+  int rc = tsat_batch_reserve(h, T, o->n_knots, o->n_tab, n_btab, o->max_linesearch);
+  if (rc) return rc;
+  rc = tsat_batch_upload(h, x0, xf, Btab, btab_idx, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, U0);
+  if (rc) return rc;
+  rc = tsat_batch_run(h, o, nullptr);
+  if (rc) return rc;
+  return tsat_batch_download(h, X, U, K, stats);
+}
+
+}  // extern "C"
