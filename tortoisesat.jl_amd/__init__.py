@@ -8,6 +8,6 @@ Only the hot path lives here: ``csrc/`` holds the hand-written H
   trajopt     mirror of the TrajectoryOptimization.jl surface used at src/TortoiseSat.jl:145-199
   sweep       Monte-Carlo sharding over GPUs + RCCL all-gather (src/monte_carlo.jl:118-235)
 """
-from . import _abi, slew_setup  # noqa: F401
+from . import _abi, slew_setup, sweep, trajopt  # noqa: F401
 
-__all__ = ["_abi", "slew_setup"]
+__all__ = ["_abi", "slew_setup", "sweep", "trajopt"]

@@ -1,0 +1,110 @@
+"""Monte-Carlo sweep over GPUs: shard the independent slews, solve, all-gather the results.
+
+The reference runs its Monte-Carlo as a serial loop whose iterations share nothing but the result lists they
+append to (src/monte_carlo.jl:118-235; src/paper_images/heatmap.jl:114-243). Here each rank (one process per
+GPU) owns a contiguous block of trajectories; there is no communication during the solve and exactly one
+exchange at the end — an all-gather of the per-trajectory results (RCCL over xGMI on GPUs, gloo in CPU tests).
+"""
+import numpy as np
+
+from . import _abi
+
+
+def shard_range(T_total, rank, world):
+    """Contiguous block [lo, hi) of rank `rank`; blocks differ by at most one trajectory."""
+    base, rem = divmod(int(T_total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _all_gather_rows(t, world, group=None):
+    """all-gather along dim 0 of equally-shaped tensors (CUDA: all_gather_into_tensor; CPU/gloo: all_gather)."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return t
+    if t.is_cuda:
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+        return out
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous(), group=group)
+    return torch.cat(parts, dim=0)
+
+
+def gather_results(res, world, group=None, device=None):
+    """All-gather a result dict of equal-size shards (X (T,N,7), U (T,N-1,3), stats) -> dict over world*T
+    trajectories in rank order. NumPy in, NumPy out (tensors are staged on `device` if given)."""
+    import torch
+
+    out = {}
+    for k in ("X", "U"):
+        t = torch.from_numpy(np.ascontiguousarray(res[k]))
+        if device is not None:
+            t = t.to(device)
+        out[k] = _all_gather_rows(t, world, group).cpu().numpy()
+    sb = torch.from_numpy(np.ascontiguousarray(res["stats"]).view(np.uint8).reshape(len(res["stats"]), -1).copy())
+    if device is not None:
+        sb = sb.to(device)
+    g = _all_gather_rows(sb, world, group).cpu().numpy()
+    out["stats"] = np.ascontiguousarray(g).view(_abi.STATS_DTYPE).reshape(-1)
+    return out
+
+
+def monte_carlo_sweep(make_shard, solve_shard, T_total, rank, world, group=None, device=None):
+    """Sharded sweep: ``make_shard(lo, hi)`` builds this rank's SlewBatch, ``solve_shard(batch)`` returns its
+    result dict; results of all ranks come back concatenated in global trajectory order.
+    Ragged totals are padded to equal shard sizes for the collective and trimmed afterwards."""
+    lo, hi = shard_range(T_total, rank, world)
+    per = -(-int(T_total) // int(world))
+    res = solve_shard(make_shard(lo, hi)) if hi > lo else None
+    n_loc = hi - lo
+    if res is None:
+        raise ValueError("more ranks than trajectories")
+    if n_loc < per:  # pad with copies of the last row so every rank contributes `per` rows
+        pad = per - n_loc
+        res = dict(X=np.concatenate([res["X"], np.repeat(res["X"][-1:], pad, 0)]),
+                   U=np.concatenate([res["U"], np.repeat(res["U"][-1:], pad, 0)]),
+                   stats=np.concatenate([res["stats"], np.repeat(res["stats"][-1:], pad, 0)]))
+    g = gather_results(res, world, group, device)
+    keep = np.concatenate([np.arange(r * per, r * per + (shard_range(T_total, r, world)[1] - shard_range(T_total, r, world)[0]))
+                           for r in range(world)])
+    return dict(X=g["X"][keep], U=g["U"][keep], stats=g["stats"][keep])
+
+
+class ResultGather:
+    """Per-step exchange used by bench.py: unpack the resident batch straight into torch device tensors
+    (tsat_batch_export_device) and all-gather them across ranks without touching the host."""
+
+    def __init__(self, solver, T, N, world, device, mode="full", group=None):
+        import torch
+
+        self.solver, self.world, self.mode, self.group = solver, world, mode, group
+        self.stats = torch.empty((T, _abi.STATS_DTYPE.itemsize), dtype=torch.uint8, device=device)
+        self.X = self.U = None
+        if mode == "full":
+            self.X = torch.empty((T, N, 7), dtype=torch.float64, device=device)
+            self.U = torch.empty((T, N - 1, 3), dtype=torch.float64, device=device)
+        self.gathered = {}
+        if world > 1 and mode != "none":
+            self.gathered["stats"] = torch.empty((world * T, _abi.STATS_DTYPE.itemsize), dtype=torch.uint8, device=device)
+            if mode == "full":
+                self.gathered["X"] = torch.empty((world * T, N, 7), dtype=torch.float64, device=device)
+                self.gathered["U"] = torch.empty((world * T, N - 1, 3), dtype=torch.float64, device=device)
+
+    def gather(self):
+        if self.mode == "none":
+            return None
+        import torch.distributed as dist
+
+        self.solver.export_device(self.X.data_ptr() if self.X is not None else None,
+                                  self.U.data_ptr() if self.U is not None else None,
+                                  None, self.stats.data_ptr())
+        if self.world == 1:
+            return dict(X=self.X, U=self.U, stats=self.stats)
+        dist.all_gather_into_tensor(self.gathered["stats"], self.stats, group=self.group)
+        if self.mode == "full":
+            dist.all_gather_into_tensor(self.gathered["X"], self.X, group=self.group)
+            dist.all_gather_into_tensor(self.gathered["U"], self.U, group=self.group)
+        return self.gathered
