@@ -1,0 +1,86 @@
+"""Shared test plumbing. CPU tier: `pytest -m "not gpu"`; GPU tier: `pytest -m gpu` (needs an MI355X)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu`)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    from tsat_loader import load_package
+
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def ol():
+    import oracle_lib
+
+    oracle_lib.build()
+    oracle_lib.load()
+    return oracle_lib
+
+
+class Emu:
+    """ctypes binding of tests/emu/libtsat_emu.so (the HIP kernel source run by 64 host threads per wave)."""
+
+    def __init__(self, abi):
+        d = os.path.join(ROOT, "tests", "emu")
+        subprocess.check_call(["make", "-C", d, "libtsat_emu.so"], stdout=subprocess.DEVNULL)
+        self.lib = C.CDLL(os.path.join(d, "libtsat_emu.so"))
+        self.abi = abi
+
+    def solve(self, batch, opts, trace_rows=0):
+        T, N = batch.T, batch.N
+        o = opts.copy()
+        o.n_knots, o.n_tab = N, batch.n_tab
+        X = np.zeros((T, N, 7)); U = np.zeros((T, N - 1, 3)); K = np.zeros((T, N - 1, 7, 3))
+        stats = np.zeros(T, dtype=self.abi.STATS_DTYPE)
+        trace = np.zeros((T, max(trace_rows, 1), 8))
+        d = self.abi.as_dp
+        rc = self.lib.emu_solve_batch(
+            C.byref(o), C.c_int64(T), C.c_int64(batch.Btab.shape[0]), d(batch.x0), d(batch.xf), d(batch.Btab),
+            self.abi.as_ip(batch.btab_idx), d(batch.tau0), d(batch.dtau), d(batch.dt), d(batch.Jmat), d(batch.Qd),
+            d(batch.Qfd), d(batch.Rd), d(batch.ulo), d(batch.uhi), d(batch.U0), d(X), d(U), d(K),
+            stats.ctypes.data_as(C.c_void_p), d(trace) if trace_rows else None, C.c_int(trace_rows))
+        if rc != 0:
+            raise RuntimeError(f"emu_solve_batch rc={rc}")
+        return dict(X=X, U=U, K=K, stats=stats, trace=trace)
+
+
+@pytest.fixture(scope="session")
+def emu(pkg):
+    return Emu(pkg._abi)
+
+
+def oracle_options(ol, **kw):
+    o = ol.default_options()
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+COUNT_FIELDS = ("status", "outer_iters", "inner_iters", "ls_trials", "n_backward", "bp_restarts", "fp_fails")
+
+
+def assert_same_solution(ref, got, tol=1e-9, counts=True):
+    """fp64 parity bar: 1e-9 absolute on X and U at equal iteration counts."""
+    if counts:
+        for f in COUNT_FIELDS:
+            assert np.array_equal(ref["stats"][f], got["stats"][f]), f
+    assert np.max(np.abs(ref["X"] - got["X"])) < tol
+    assert np.max(np.abs(ref["U"] - got["U"])) < tol
+    np.testing.assert_allclose(got["stats"]["cost"], ref["stats"]["cost"], rtol=1e-9)
+    np.testing.assert_allclose(got["stats"]["c_max"], ref["stats"]["c_max"], rtol=1e-7, atol=1e-10)

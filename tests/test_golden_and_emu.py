@@ -1,0 +1,110 @@
+"""CPU tier: (1) the oracle reproduces its committed golden vectors; (2) the HIP kernel *source*, run by the
+64-threads-per-wave emulator (tests/emu), reproduces the oracle — fixtures, integrators, ragged chunk sizes,
+active bounds, line-search failures, regularisation restarts, REG_FAIL and DIVERGED exits."""
+import numpy as np
+import pytest
+
+import helpers
+from conftest import assert_same_solution, oracle_options
+
+
+@pytest.mark.parametrize("name", helpers.golden_cases())
+def test_oracle_reproduces_golden(pkg, ol, name):
+    b, o, ref = helpers.load_case(name, pkg, ol)
+    got = ol.solve_batch(b, o)
+    assert_same_solution(ref, got, tol=1e-10)
+    np.testing.assert_allclose(got["K"], ref["K"], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", helpers.golden_cases())
+def test_emulated_kernel_reproduces_golden(pkg, ol, emu, name):
+    b, o, ref = helpers.load_case(name, pkg, ol)
+    got = emu.solve(b, o)
+    assert_same_solution(ref, got, tol=1e-9)
+    scale = np.max(np.abs(ref["K"]))
+    assert np.max(np.abs(got["K"] - ref["K"])) < 1e-9 * max(scale, 1.0)
+
+
+def test_golden_covers_the_edge_paths(pkg, ol):
+    st = np.concatenate([helpers.load_case(n, pkg, ol)[2]["stats"] for n in helpers.golden_cases()])
+    assert st["bp_restarts"].sum() > 0      # non-PD Quu -> regularisation restart
+    assert st["fp_fails"].sum() > 0         # line search exhausted
+    assert np.any(st["ls_trials"] > st["inner_iters"])  # alpha < 1 accepted
+
+
+@pytest.mark.parametrize("N", [2, 3, 33, 34, 49, 50])
+def test_emulated_kernel_ragged_knot_counts(pkg, ol, emu, N):
+    """N-1 below / at / just above the forward (32) and backward (48) LDS chunk sizes; N = 2 is the minimum."""
+    b = pkg.slew_setup.workload_monte_carlo(T=1, N=N, seed=100 + N)
+    o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1)
+    assert_same_solution(ol.solve_batch(b, o), emu.solve(b, o))
+
+
+def test_emulated_kernel_linesearch_extremes(pkg, ol, emu):
+    b = pkg.slew_setup.workload_monte_carlo(T=1, N=40, seed=9)
+    for ls in (1, 32):
+        o = oracle_options(ol, max_outer=2, max_inner=4, max_linesearch=ls)
+        assert_same_solution(ol.solve_batch(b, o), emu.solve(b, o))
+
+
+def test_emulated_kernel_no_terminal_constraint_and_partial_mask(pkg, ol, emu):
+    b = pkg.slew_setup.workload_monte_carlo(T=1, N=45, seed=21)
+    for mask in (0, 0b0000111, 0b1111000):
+        o = oracle_options(ol, max_outer=3, max_inner=4, terminal_mask=mask)
+        assert_same_solution(ol.solve_batch(b, o), emu.solve(b, o))
+
+
+def test_emulated_kernel_reg_fail_and_diverged_status(pkg, ol, emu):
+    ss = pkg.slew_setup
+    b = ss.workload_monte_carlo(T=1, N=40, seed=5)
+    b.Rd[:] = -1e-4
+    o = oracle_options(ol, max_outer=2, max_inner=3, reg_max=1e-6)   # rho cannot grow enough -> REG_FAIL
+    r, g = ol.solve_batch(b, o), emu.solve(b, o)
+    assert r["stats"]["status"][0] == pkg._abi.TSAT_REG_FAIL
+    assert_same_solution(r, g)
+    b2 = ss.workload_monte_carlo(T=1, N=40, seed=5)
+    b2.U0[:] = 1e12                                                   # initial rollout leaves max_state -> DIVERGED
+    o2 = oracle_options(ol, max_outer=2, max_inner=3)
+    r2, g2 = ol.solve_batch(b2, o2), emu.solve(b2, o2)
+    assert r2["stats"]["status"][0] == g2["stats"]["status"][0] == pkg._abi.TSAT_DIVERGED
+
+
+def test_emulated_kernel_table_playback_rate(pkg, ol, emu):
+    """table rows advance at dtau rows per knot from tau0 (floor lookup at stage times)."""
+    b = pkg.slew_setup.workload_monte_carlo(T=2, N=50, seed=2)
+    b.dtau[:] = [0.37, 1.9]      # slow replay (as with the reference's global tf) / faster than one row per knot (clamped)
+    b.tau0[:] = [3.2, 0.0]
+    o = oracle_options(ol, max_outer=2, max_inner=3)
+    assert_same_solution(ol.solve_batch(b, o), emu.solve(b, o))
+
+
+def test_solver_invariants_on_oracle(pkg, ol):
+    """properties the algorithm guarantees: the returned (X,U) is a dynamically consistent rollout; the AL cost
+    never increases inside an inner solve; stats are self-consistent."""
+    ss = pkg.slew_setup
+    b = ss.workload_monte_carlo(T=3, N=120, seed=77)
+    o = oracle_options(ol, max_outer=4, max_inner=8, dj_counter_limit=1)
+    r = ol.solve_batch(b, o, trace_rows=40)
+    J = np.diag([0.00125] * 3)
+    for t in range(b.T):
+        assert np.array_equal(r["X"][t, 0], b.x0[t])
+        for k in range(b.N - 1):
+            xn = ol.rk_step(3, r["X"][t, k], r["U"][t, k], b.Btab[0, k], b.Btab[0, k], b.Btab[0, min(k + 1, b.n_tab - 1)], 0.2, J)
+            np.testing.assert_allclose(r["X"][t, k + 1], xn, rtol=0, atol=1e-14)
+        tr = r["trace"][t]
+        tr = tr[tr[:, 0] > 0]
+        assert np.all(tr[:, 3] <= tr[:, 2])                       # J_new <= J_prev
+        assert len(tr) == r["stats"]["inner_iters"][t]
+        # LQR cost recomputed from the returned trajectory
+        e = r["X"][t] - b.xf[t]
+        cost = 0.5 * np.sum(b.Qd[t] * e[:-1] ** 2) + 0.5 * np.sum(b.Rd[t] * r["U"][t] ** 2) + 0.5 * np.sum(b.Qfd[t] * e[-1] ** 2)
+        np.testing.assert_allclose(r["stats"]["cost"][t], cost, rtol=1e-12)
+        cmax = max(np.max(np.abs(r["U"][t]) - 19.0), np.max(np.abs(e[-1])), 0.0)
+        np.testing.assert_allclose(r["stats"]["c_max"][t], cmax, rtol=1e-12)
+
+
+def test_oracle_openmp_matches_serial(pkg, ol):
+    b = pkg.slew_setup.workload_monte_carlo(T=6, N=40, seed=1)
+    o = oracle_options(ol, max_outer=2, max_inner=3)
+    a, c = ol.solve_batch(b, o, nthreads=1), ol.solve_batch(b, o, nthreads=4)
+    assert np.array_equal(a["X"], c["X"]) and np.array_equal(a["U"], c["U"])

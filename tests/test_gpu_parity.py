@@ -1,0 +1,255 @@
+"""GPU tier (`pytest -m gpu`): the HIP path, called through the C ABI, against the CPU oracle on identical
+inputs (bar: 1e-9 absolute on X and U at equal iteration counts, fp64 — BASELINE.md §3), against the committed
+golden fixtures, and — at BASELINE.json's full size — through size-independent properties."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+from conftest import assert_same_solution, oracle_options
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver(pkg):
+    import torch
+
+    assert torch.cuda.is_available(), "the gpu tier needs an MI355X"
+    s = pkg.trajopt.AugmentedLagrangianSolver(None, None, device=0)   # raises if the HIP library cannot open a gfx950 GPU
+    yield s
+    s.close()
+
+
+def gpu_solve(pkg, solver, b, o, trace_rows=0):
+    a = helpers.abi_options_like(o, pkg, b.N, b.n_tab)
+    solver.upload(b, a.max_linesearch)
+    solver.trace(trace_rows)
+    solver.run(a)
+    res = solver.download()
+    res["trace"] = solver.trace_download() if trace_rows else None
+    return res
+
+
+def k_close(ref, got, rel=1e-9):
+    scale = max(float(np.max(np.abs(ref["K"]))), 1.0)
+    assert np.max(np.abs(ref["K"] - got["K"])) < rel * scale
+
+
+# ----------------------------------------------------------------------------------------------- fixtures
+@pytest.mark.parametrize("name", helpers.golden_cases())
+def test_gpu_reproduces_golden(pkg, ol, solver, name):
+    b, o, ref = helpers.load_case(name, pkg, ol)
+    got = gpu_solve(pkg, solver, b, o)
+    assert_same_solution(ref, got, tol=1e-9)
+    k_close(ref, got)
+
+
+# ----------------------------------------------------------------------------------------------- oracle parity
+@pytest.mark.parametrize("N", [2, 3, 33, 34, 49, 50, 97])
+def test_gpu_ragged_knot_counts(pkg, ol, solver, N):
+    b = pkg.slew_setup.workload_monte_carlo(T=5, N=N, seed=100 + N)
+    o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1)
+    assert_same_solution(ol.solve_batch(b, o), gpu_solve(pkg, solver, b, o))
+
+
+@pytest.mark.parametrize("integ", [3, 4])
+def test_gpu_monte_carlo_1000_knots(pkg, ol, solver, integ):
+    """configs[1] at full horizon, a slice the oracle finishes in seconds"""
+    b = pkg.slew_setup.workload_monte_carlo(T=24, N=1000)
+    o = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, integrator=integ)
+    ref = ol.solve_batch(b, o, nthreads=min(16, ol.num_procs()), trace_rows=64)
+    got = gpu_solve(pkg, solver, b, o, trace_rows=64)
+    assert_same_solution(ref, got, tol=1e-9)
+    k_close(ref, got)
+    # identical line-search decisions, iteration by iteration
+    assert np.array_equal(ref["trace"][:, :, 4], got["trace"][:, :, 4])
+    np.testing.assert_allclose(got["trace"][:, :, 3], ref["trace"][:, :, 3], rtol=1e-11)
+
+
+def test_gpu_single_slew_config0(pkg, ol, solver):
+    """configs[0]: the reference's own case (src/TortoiseSat.jl:117-199) — 500 knots, |u| <= 1, 20 x 50 budget"""
+    b = pkg.slew_setup.workload_single_slew(N=500)
+    o = oracle_options(ol, max_outer=20, max_inner=50)
+    ref = ol.solve_batch(b, o)
+    got = gpu_solve(pkg, solver, b, o)
+    assert_same_solution(ref, got, tol=1e-9)
+
+
+def test_gpu_random_orbit_tables(pkg, ol, solver):
+    b = pkg.slew_setup.workload_monte_carlo(T=12, N=200, seed=20190531, random_orbit=True)   # configs[2] inputs (fp64)
+    o = oracle_options(ol, max_outer=3, max_inner=6, dj_counter_limit=1)
+    assert_same_solution(ol.solve_batch(b, o, nthreads=4), gpu_solve(pkg, solver, b, o))
+
+
+def test_gpu_inclination_sweep_inputs(pkg, ol, solver):
+    b = pkg.slew_setup.workload_inclination_sweep(T=8, N=150, j0=4096, T_total=65536)         # configs[3] inputs
+    o = oracle_options(ol, max_outer=3, max_inner=8, dj_counter_limit=1)
+    assert_same_solution(ol.solve_batch(b, o, nthreads=4), gpu_solve(pkg, solver, b, o))
+
+
+def test_gpu_edge_options(pkg, ol, solver):
+    ss = pkg.slew_setup
+    b = ss.workload_monte_carlo(T=3, N=45, seed=21)
+    for kw in (dict(max_linesearch=1), dict(max_linesearch=32), dict(terminal_mask=0), dict(terminal_mask=0b1111000),
+               dict(penalty_init=10.0, penalty_scale=3.0), dict(reg_init=1e-3)):
+        o = oracle_options(ol, max_outer=3, max_inner=4, **kw)
+        assert_same_solution(ol.solve_batch(b, o), gpu_solve(pkg, solver, b, o))
+    b.dtau[:] = [0.37, 1.9, 1.0]
+    b.tau0[:] = [3.2, 0.0, 7.0]
+    o = oracle_options(ol, max_outer=2, max_inner=3)
+    assert_same_solution(ol.solve_batch(b, o), gpu_solve(pkg, solver, b, o))
+
+
+def test_gpu_full_inertia_tensor(pkg, ol, solver):
+    ss = pkg.slew_setup
+    b = ss.workload_monte_carlo(T=2, N=60, seed=8)
+    J = np.array([[2.0e-3, 1.0e-4, -2.0e-4], [1.0e-4, 1.5e-3, 3.0e-4], [-2.0e-4, 3.0e-4, 2.5e-3]])
+    b.Jmat[:] = ss.jmat_cm(J)
+    o = oracle_options(ol, max_outer=2, max_inner=4)
+    assert_same_solution(ol.solve_batch(b, o), gpu_solve(pkg, solver, b, o))
+
+
+def test_gpu_failure_statuses(pkg, ol, solver):
+    ss, abi = pkg.slew_setup, pkg._abi
+    b = ss.workload_monte_carlo(T=2, N=40, seed=5)
+    b.Rd[:] = -1e-4
+    o = oracle_options(ol, max_outer=2, max_inner=3, reg_max=1e-6)
+    r, g = ol.solve_batch(b, o), gpu_solve(pkg, solver, b, o)
+    assert np.all(g["stats"]["status"] == abi.TSAT_REG_FAIL)
+    assert_same_solution(r, g)
+    b2 = ss.workload_monte_carlo(T=2, N=40, seed=5)
+    b2.U0[0] = 1e12
+    o2 = oracle_options(ol, max_outer=2, max_inner=3)
+    r2, g2 = ol.solve_batch(b2, o2), gpu_solve(pkg, solver, b2, o2)
+    assert g2["stats"]["status"][0] == abi.TSAT_DIVERGED and np.array_equal(r2["stats"]["status"], g2["stats"]["status"])
+    np.testing.assert_allclose(g2["X"][1], r2["X"][1], atol=1e-9)   # the healthy neighbour is unaffected
+
+
+def test_gpu_api_errors_are_codes_not_crashes(pkg, ol, solver):
+    lib, abi = pkg._abi.load(), pkg._abi
+    b = pkg.slew_setup.workload_monte_carlo(T=2, N=30)
+    o = helpers.abi_options_like(oracle_options(ol, max_outer=1, max_inner=1), pkg, b.N, b.n_tab)
+    solver.upload(b, o.max_linesearch)
+    for field, bad in (("integrator", 5), ("precision", 32), ("error_state", 1), ("max_linesearch", 33), ("n_knots", 31)):
+        o2 = o.copy()
+        setattr(o2, field, bad)
+        rc = lib.tsat_batch_run(solver._h, C.byref(o2), None)
+        assert rc < 0 and lib.tsat_last_error(solver._h)
+    assert lib.tsat_batch_reserve(solver._h, 0, 30, 30, 1, 20) < 0
+    assert lib.tsat_batch_run(solver._h, C.byref(o), None) == 0      # the handle is still usable
+
+
+def test_gpu_one_call_abi_entry(pkg, ol, solver):
+    """tsat_solve_batch: the single call a Julia `ccall` would make in place of solve!(prob, solver)"""
+    lib, abi = pkg._abi.load(), pkg._abi
+    b = pkg.slew_setup.workload_monte_carlo(T=3, N=50, seed=4)
+    oo = oracle_options(ol, max_outer=2, max_inner=4)
+    o = helpers.abi_options_like(oo, pkg, b.N, b.n_tab)
+    X = np.zeros((3, 50, 7)); U = np.zeros((3, 49, 3)); K = np.zeros((3, 49, 7, 3))
+    st = np.zeros(3, dtype=abi.STATS_DTYPE)
+    d = abi.as_dp
+    rc = lib.tsat_solve_batch(solver._h, C.byref(o), 3, 1, d(b.x0), d(b.xf), d(b.Btab), abi.as_ip(b.btab_idx), d(b.tau0),
+                              d(b.dtau), d(b.dt), d(b.Jmat), d(b.Qd), d(b.Qfd), d(b.Rd), d(b.ulo), d(b.uhi), d(b.U0),
+                              d(X), d(U), d(K), st.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    ref = ol.solve_batch(b, oo)
+    assert_same_solution(ref, dict(X=X, U=U, K=K, stats=st))
+    k_close(ref, dict(K=K))
+
+
+def test_gpu_trajopt_surface_end_to_end(pkg, ol):
+    """the reference script's call sequence (src/TortoiseSat.jl:145-203) on the GPU"""
+    ss, to = pkg.slew_setup, pkg.trajopt
+    N = 120
+    ref_b = ss.workload_single_slew(N=N)
+    n, m = 8, 3
+    x0, xf = np.r_[ref_b.x0[0], 0.0], np.r_[ref_b.xf[0], 1.0]
+    model_d = to.rk3(to.Model(to.DerivFunction(ss.INERTIA["1P"], ref_b.Btab[0]), n, m))
+    Q = np.zeros((n, n)); Qf = np.zeros((n, n))
+    Q[:7, :7] = np.diag(ref_b.Qd[0]); Qf[:7, :7] = np.diag(ref_b.Qfd[0])
+    obj = to.LQRObjective(Q, np.diag(ref_b.Rd[0]), Qf, xf, N)
+    constraints = to.Constraints(N)
+    for k in range(1, N):
+        constraints[k] += to.BoundConstraint(n, m, u_max=1, u_min=-1)
+    constraints[N] += to.goal_constraint(xf)
+    sat = to.Problem(model_d, obj, constraints=constraints, x0=x0, xf=xf, N=N, dt=0.2)
+    to.initial_controls_(sat, np.zeros((3, N + 1)))
+    opts_al = to.AugmentedLagrangianSolverOptions()
+    opts_al.opts_uncon.iterations = 12
+    opts_al.iterations = 4
+    s = to.AugmentedLagrangianSolver(sat, opts_al)
+    to.solve_(sat, s)
+    s.close()
+    ref = ol.solve_batch(ref_b, oracle_options(ol, max_outer=4, max_inner=12))
+    assert sat.X.shape == (7, N) and sat.U.shape == (3, N - 1) and sat.K.shape == (3, 7, N - 1)
+    np.testing.assert_allclose(sat.X.T, ref["X"][0], atol=1e-9)
+    np.testing.assert_allclose(sat.U.T, ref["U"][0], atol=1e-9)
+    np.testing.assert_allclose(sat.K.transpose(2, 1, 0), ref["K"][0], rtol=1e-8, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------------------------- full size
+def test_gpu_full_size_properties(pkg, ol, solver):
+    """BASELINE.json configs[1] in full (1024 x 1000 knots, 5 x 10): properties that need no oracle run —
+    determinism, shard-concatenation, dynamic consistency of the returned rollout, cost/violation recomputation."""
+    ss = pkg.slew_setup
+    T, N = 1024, 1000
+    b = ss.workload_monte_carlo(T=T, N=N)
+    o = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1)
+    g = gpu_solve(pkg, solver, b, o)
+    st = g["stats"]
+    assert np.all(np.isin(st["status"], (0, 1))) and np.all(st["inner_iters"] >= 5) and np.all(st["inner_iters"] <= 50)
+    assert np.all(np.isfinite(g["X"])) and np.all(np.isfinite(g["U"])) and np.all(np.isfinite(g["K"]))
+    # (1) bitwise deterministic re-run
+    g2 = gpu_solve(pkg, solver, b, o)
+    assert np.array_equal(g["X"], g2["X"]) and np.array_equal(g["U"], g2["U"]) and np.array_equal(st, g2["stats"])
+    # (2) a shard solved alone equals the same rows of the full batch, bit for bit (what the multi-GPU sweep relies on)
+    gs = gpu_solve(pkg, solver, b.slice(512, 640), o)
+    assert np.array_equal(gs["X"], g["X"][512:640]) and np.array_equal(gs["U"], g["U"][512:640])
+    # (3) x_{k+1} = rk3(x_k, u_k) along every trajectory (vectorised NumPy restatement of the step)
+    X, U = g["X"], g["U"]
+    assert np.array_equal(X[:, 0], b.x0)
+    xn = _rk3_numpy(X[:, :-1], U, b)
+    assert np.max(np.abs(xn - X[:, 1:])) < 1e-12
+    # (4) reported cost / violation match a recomputation from the returned arrays
+    e = X - b.xf[:, None, :]
+    cost = 0.5 * np.sum(b.Qd[:, None] * e[:, :-1] ** 2, axis=(1, 2)) + 0.5 * np.sum(b.Rd[:, None] * U ** 2, axis=(1, 2)) \
+        + 0.5 * np.sum(b.Qfd * e[:, -1] ** 2, axis=1)
+    np.testing.assert_allclose(st["cost"], cost, rtol=1e-11)
+    cmax = np.maximum(np.maximum(np.max(U - b.uhi[:, None], axis=(1, 2)), np.max(b.ulo[:, None] - U, axis=(1, 2))),
+                      np.max(np.abs(e[:, -1]), axis=1))
+    np.testing.assert_allclose(st["c_max"], np.maximum(cmax, 0.0), rtol=1e-11, atol=1e-14)
+    assert np.array_equal(st["status"] == 0, st["c_max"] < 1e-3)
+    # (5) the solve did its job: terminal attitude error far below the initial one
+    assert np.median(np.linalg.norm(e[:, -1, 3:], axis=1)) < 0.05 * np.median(np.linalg.norm(e[:, 0, 3:], axis=1))
+    # (6) spot-check 8 random trajectories of the full batch against the oracle
+    idx = np.random.default_rng(0).choice(T, 8, replace=False)
+    for i in idx:
+        r = ol.solve_batch(b.slice(int(i), int(i) + 1), o)
+        assert np.max(np.abs(r["X"][0] - X[i])) < 1e-9 and np.max(np.abs(r["U"][0] - U[i])) < 1e-9
+        assert r["stats"]["inner_iters"][0] == st["inner_iters"][i]
+
+
+def _rk3_numpy(x, u, b):
+    """vectorised rk3 of the slew dynamics for (T, N-1, .) arrays; rows k, k, k+1 (dtau = 1, tau0 = 0)"""
+    Bt = b.Btab[b.btab_idx]                       # (T, n_tab, 3)
+    Jd = np.array([b.Jmat[0, 0], b.Jmat[0, 4], b.Jmat[0, 8]])   # diagonal inertia in this workload
+    h = 0.2
+
+    def f(x, bb):
+        w, q = x[..., :3], x[..., 3:]
+        q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+        s, v = q[..., :1], q[..., 1:]
+        qd = 0.5 * np.concatenate([-np.sum(v * w, -1, keepdims=True), s * w + np.cross(v, w)], -1)
+        BB = bb + 2 * np.cross(v, np.cross(v, bb) + s * bb)
+        tau = np.cross(u * 1e-2, BB)
+        wd = (tau - np.cross(w, Jd * w)) / Jd
+        return np.concatenate([wd, qd], -1)
+
+    b0 = Bt[:, :-1]
+    b2 = Bt[:, 1:]
+    k1 = f(x, b0) * h
+    k2 = f(x + k1 / 2, b0) * h
+    k3 = f(x - k1 + 2 * k2, b2) * h
+    return x + (k1 + 4 * k2 + k3) / 6

@@ -1,0 +1,114 @@
+"""CPU tier: host-side logic above the C ABI — problem setup mirrored from the reference scripts and the
+TrajectoryOptimization-style surface."""
+import numpy as np
+import pytest
+
+import refmath as rm
+
+
+def test_eigen_axis_slew_matches_reference_text(pkg):
+    ss = pkg.slew_setup
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        q0 = ss.random_unit_quats(rng, 1)[0]
+        x0 = np.r_[0, 0, 0, q0]
+        xf = np.r_[0, 0, 0, np.sqrt(2) / 2, np.sqrt(2) / 2, 0, 0]
+        t = 0.2 * np.arange(101)
+        w, q = ss.eigen_axis_slew(x0, xf, t)
+        wr, qr = rm.eigen_axis_slew(x0, xf, t)
+        np.testing.assert_allclose(w, wr, atol=1e-14)
+        np.testing.assert_allclose(q, qr, atol=1e-14)
+        np.testing.assert_allclose(q[0], q0, atol=1e-14)
+        assert np.allclose(np.linalg.norm(q, axis=1), 1.0)
+
+
+def test_bryson_weights_follow_tortoisesat_lines_157_168(pkg):
+    ss = pkg.slew_setup
+    b = ss.workload_single_slew(N=100)
+    t = 0.2 * np.arange(101)
+    w, _ = rm.eigen_axis_slew(b.x0[0], b.xf[0], t)
+    J = ss.INERTIA["1P"]
+    w_max = np.max(np.abs(w))
+    tau_max = np.max(J @ np.diff(w.T, axis=1) / 0.2)
+    m_max = tau_max / 1e-5 * 1e2
+    np.testing.assert_allclose(b.Qd[0], np.r_[np.full(3, 10 / w_max**2), np.full(4, 1e4)], rtol=1e-12)
+    np.testing.assert_allclose(b.Qfd[0], 10 * b.Qd[0])
+    np.testing.assert_allclose(b.Rd[0], np.full(3, 1 / m_max**2), rtol=1e-12)
+    # q0 = 90 deg about [1,0,1]/sqrt2 (src/TortoiseSat.jl:121-123)
+    np.testing.assert_allclose(b.x0[0, 3:], [np.cos(np.pi / 4), 0.5, 0, 0.5], atol=1e-15)
+    assert np.all(b.uhi == 1) and np.all(b.ulo == -1) and np.all(b.U0 == 0)
+
+
+def test_workload_monte_carlo_is_deterministic_and_config2_shaped(pkg):
+    ss = pkg.slew_setup
+    a, b = ss.workload_monte_carlo(T=16, N=50), ss.workload_monte_carlo(T=16, N=50)
+    for f in ("x0", "U0", "Qd", "Rd", "Btab"):
+        assert np.array_equal(getattr(a, f), getattr(b, f))
+    assert a.Btab.shape == (1, 50, 3) and np.all(a.btab_idx == 0)           # one orbit
+    assert np.allclose(np.linalg.norm(a.x0[:, 3:], axis=1), 1.0)
+    assert np.all(a.uhi == 19) and a.meta["max_outer"] == 5 and a.meta["max_inner"] == 10
+    assert 1e-5 < np.linalg.norm(a.Btab[0], axis=1).min() and np.linalg.norm(a.Btab[0], axis=1).max() < 7e-5
+    c = ss.workload_monte_carlo(T=4, N=50, random_orbit=True)
+    assert c.Btab.shape == (4, 50, 3) and np.array_equal(c.btab_idx, np.arange(4))
+    s = a.slice(4, 9)
+    assert s.T == 5 and np.array_equal(s.x0, a.x0[4:9])
+
+
+def test_trajopt_surface_builds_the_same_batch_as_arrays(pkg):
+    """Problem/Model/LQRObjective/Constraints used exactly as at src/TortoiseSat.jl:145-191."""
+    ss, to = pkg.slew_setup, pkg.trajopt
+    N, dt = 60, 0.2
+    ref = ss.workload_single_slew(N=N)
+    B = ref.Btab[0]
+    J = ss.INERTIA["1P"]
+    n, m = 8, 3
+    x0 = np.r_[ref.x0[0], 0.0]
+    xf = np.r_[ref.xf[0], 1.0]
+    model = to.Model(to.DerivFunction(J, B), n, m)
+    model_d = to.rk3(model)
+    Q = np.zeros((n, n)); Qf = np.zeros((n, n))
+    Q[:7, :7] = np.diag(ref.Qd[0]); Qf[:7, :7] = np.diag(ref.Qfd[0])
+    R = np.diag(ref.Rd[0])
+    obj = to.LQRObjective(Q, R, Qf, xf, N)
+    bnd = to.BoundConstraint(n, m, u_max=1, u_min=-1)
+    goal = to.goal_constraint(xf)
+    constraints = to.Constraints(N)
+    for k in range(1, N):
+        constraints[k] += bnd
+    constraints[N] += goal
+    sat = to.Problem(model_d, obj, constraints=constraints, x0=x0, xf=xf, N=N, dt=dt)
+    to.initial_controls_(sat, np.zeros((3, N + 1)))
+    bp = to.BatchProblem([sat])
+    for f in ("x0", "xf", "Qd", "Qfd", "Rd", "ulo", "uhi", "U0", "Jmat", "dt", "tau0", "dtau"):
+        np.testing.assert_allclose(getattr(bp.arrays, f), getattr(ref, f), rtol=0, atol=0, err_msg=f)
+    assert bp.integrator == 3 and bp.terminal_mask == 0x7F
+    opts = to.AugmentedLagrangianSolverOptions()
+    opts.opts_uncon.iterations = 50
+    opts.iterations = 20
+    o = opts.to_abi(N, B.shape[0], 3)
+    assert (o.max_outer, o.max_inner, o.n_knots, o.n_tab) == (20, 50, N, N)
+
+
+def test_trajopt_surface_rejects_what_the_kernel_cannot_do(pkg):
+    to = pkg.trajopt
+    with pytest.raises(ValueError):
+        to.Model(to.DerivFunction(np.eye(3), np.zeros((4, 3))), 6, 3)
+    obj = to.LQRObjective(np.ones((8, 8)), np.eye(3), np.eye(8), np.zeros(8), 10)
+    with pytest.raises(ValueError, match="diagonal"):
+        obj.diagonals()
+    p = to.Problem(to.Model(to.DerivFunction(np.eye(3), np.zeros((10, 3))), 8, 3), None, N=10)
+    with pytest.raises(ValueError, match="rk3"):
+        to.BatchProblem([p])
+
+
+def test_shard_range_partitions_exactly(pkg):
+    sr = pkg.sweep.shard_range
+    for T in (1, 7, 8, 1024, 65536, 1000):
+        for W in (1, 2, 3, 8):
+            if W > T:
+                continue
+            blocks = [sr(T, r, W) for r in range(W)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == T
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(W - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1

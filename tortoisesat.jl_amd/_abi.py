@@ -1,7 +1,7 @@
 """ctypes view of include/tortoise_hip.h (struct layouts + function prototypes).
 
-The structs here are the single Python definition of ``tsat_options`` / ``tsat_stats``; the test-side oracle
-binding (oracle/oracle_lib.py) re-uses them so the checker and the product agree on the layout.
+The structs here are the single Python definition of ``tsat_options`` / ``tsat_stats``; the test-side checker
+binds the same classes so that checker and product agree on the layout.
 """
 import ctypes as C
 import os
