@@ -36,6 +36,7 @@ def test_golden_covers_the_edge_paths(pkg, ol):
 def test_emulated_kernel_ragged_knot_counts(pkg, ol, emu, N):
     """N-1 below / at / just above the forward (32) and backward (48) LDS chunk sizes; N = 2 is the minimum."""
     b = pkg.slew_setup.workload_monte_carlo(T=1, N=N, seed=100 + N)
+    b.Rd[~np.isfinite(b.Rd)] = 0.03      # N = 2: the eigen-axis guess has no acceleration sample -> Bryson R undefined
     o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1)
     assert_same_solution(ol.solve_batch(b, o), emu.solve(b, o))
 
