@@ -25,10 +25,22 @@ namespace tsat_emu { int lane(); void sync(); }
 #define TSAT_DEV inline
 #define TSAT_LANE() (tsat_emu::lane())
 #define TSAT_SYNC() (tsat_emu::sync())
+#define TSAT_SYNC_LDS() (tsat_emu::sync())
 #else
 #define TSAT_DEV __device__ __forceinline__
 #define TSAT_LANE() ((int)threadIdx.x)
+// full fence: orders global AND LDS traffic between the lanes of the wave (s_waitcnt vmcnt(0) lgkmcnt(0))
 #define TSAT_SYNC() __syncthreads()
+// LDS-only ordering between the lanes of ONE wavefront. A wave's DS instructions execute in issue order, so a
+// ds_write followed in program order by another lane's ds_read of the same address needs no s_waitcnt; all that
+// is required is that the compiler keeps the order. Crucially this does NOT drain vmcnt, so global stores issued
+// inside a sequential sweep (K/d, candidates) stay in flight instead of stalling every knot on their write-ack.
+#define TSAT_SYNC_LDS()                                       \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+  } while (0)
 #endif
 
 namespace tsat {
@@ -130,9 +142,9 @@ TSAT_DEV real wave_sum(real v, real* red) {
   const int lane = TSAT_LANE();
   for (int s = 1; s < WAVE; s <<= 1) {
     red[lane] = v;
-    TSAT_SYNC();
+    TSAT_SYNC_LDS();
     v = v + red[lane ^ s];
-    TSAT_SYNC();
+    TSAT_SYNC_LDS();
   }
   return v;
 }
@@ -141,10 +153,10 @@ TSAT_DEV real wave_max(real v, real* red) {
   const int lane = TSAT_LANE();
   for (int s = 1; s < WAVE; s <<= 1) {
     red[lane] = v;
-    TSAT_SYNC();
+    TSAT_SYNC_LDS();
     real o = red[lane ^ s];
     v = (o > v) ? o : v;
-    TSAT_SYNC();
+    TSAT_SYNC_LDS();
   }
   return v;
 }
@@ -152,9 +164,9 @@ template <typename real>
 TSAT_DEV real wave_bcast(real v, int src, real* red) {
   const int lane = TSAT_LANE();
   if (lane == src) red[0] = v;
-  TSAT_SYNC();
+  TSAT_SYNC_LDS();
   real r = red[0];
-  TSAT_SYNC();
+  TSAT_SYNC_LDS();
   return r;
 }
 // smallest lane index whose flag is set, or WAVE
@@ -164,10 +176,10 @@ TSAT_DEV int wave_first(bool flag, real* red) {
   const int lane = TSAT_LANE();
   for (int s = 1; s < WAVE; s <<= 1) {
     red[lane] = v;
-    TSAT_SYNC();
+    TSAT_SYNC_LDS();
     real o = red[lane ^ s];
     v = (o < v) ? o : v;
-    TSAT_SYNC();
+    TSAT_SYNC_LDS();
   }
   return (int)v;
 }
@@ -463,7 +475,7 @@ TSAT_DEV real forward_sweep(const KArgs<real>& a, const Traj<real>& tr, int traj
       rk_step<real, INTEG>(tr, x, u, bs, bs + 3, bs + 6, xn);
       for (int i = 0; i < 7; ++i) x[i] = xn[i];
     }
-    TSAT_SYNC();
+    TSAT_SYNC_LDS();  // the next chunk's staging writes must not overtake this chunk's LDS reads
   }
   for (int i = 0; i < 7; ++i) amax = fmax_(amax, fabs_(x[i]));
   J += term_cost(tr, x, nu, mu, a.opt.terminal_mask, true);
@@ -595,7 +607,7 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
         Wt[c1 * 9 + r1] = acc;
         if (c1 < 2) Wt[(8 + c1) * 9 + r1] = acc2;
       }
-      TSAT_SYNC();
+      TSAT_SYNC_LDS();
       // step 2: Qxx = Q + A'SA, Qux = B'SA, Quu = luu + B'SB, Qu = lu + B's
       if (o1 >= 0) {
         real acc = diag2;
@@ -607,7 +619,7 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
         const int aa = lane - 55;
         Hux[aa * 8 + 7] = rc[R_LU + aa] + Wt[(7 + aa) * 9 + 7];
       }
-      TSAT_SYNC();
+      TSAT_SYNC_LDS();
       // step 3: regularise, PD test (Sylvester), adjugate inverse, K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu
       real Qi0, Qi1, Qi2;
       {
@@ -633,7 +645,7 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
         KDs[a3 * 8 + j3] = v;
         KDg[(size_t)(k0 + l) * KDW + ((j3 < 7) ? (a3 * 7 + j3) : (21 + a3))] = v;
       }
-      TSAT_SYNC();
+      TSAT_SYNC_LDS();
       // step 4: cost-to-go. With K = -Quu_reg^-1 Qux: Quu K + Qux = -rho K, so
       //   Sxx = Qxx + sym(Qux'K) - rho K'K ;  Sx = Qx + Qux'd - rho K'd   (Appendix A, compacted)
       {
@@ -662,7 +674,7 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
           St[7 * 9 + i] = acc;
         }
       }
-      TSAT_SYNC();
+      TSAT_SYNC_LDS();
     }
     TSAT_SYNC();
   }
