@@ -1,0 +1,30 @@
+"""Developer tool: run the diagnostic build (libtortoise_hip_prof.so, -DTSAT_PROFILE) on the bench workload and
+print where a wavefront spends its shader-clock cycles (forward sweep / Jacobian lanes / Riccati / parallel passes).
+The stamped build is slower than the product; read SHARES, not absolute time."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from tsat_loader import load_package
+pkg = load_package()
+pkg._abi.LIB_NAME = "libtortoise_hip_prof.so"
+from tortoisesat_jl_amd import trajopt as to, slew_setup as ss
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+b = ss.workload_monte_carlo(T=T, N=N)
+opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = 5
+opts.opts_uncon.iterations = 10; opts.opts_uncon.dJ_counter_limit = 1
+solver = to.AugmentedLagrangianSolver(None, opts)
+o = opts.to_abi(b.N, b.n_tab, 3)
+solver.upload(b, o.max_linesearch); solver.trace(1)
+ms = solver.run(o); ms = solver.run(o)
+tr = solver.trace_download()[:, 0, :]
+it = tr[:, 4]; nb = tr[:, 5]
+tot = tr[:, :4].sum(1)
+print(f"kernel {ms:.2f} ms (stamped build); mean inner its {it.mean():.1f}")
+for i, name in enumerate(("forward sweep", "jacobian lanes", "riccati", "parallel passes")):
+    print(f"  {name:16s}: {tr[:, i].mean()/1e6:8.2f} Mcycles/wave  ({100*tr[:, i].sum()/tot.sum():5.1f} %)  "
+          f"per iteration {np.mean(tr[:, i]/np.maximum(it,1))/1e3:8.1f} kcycles; per knot-iteration {np.mean(tr[:, i]/np.maximum(it,1))/N:7.1f} cycles")
+print(f"  sum of stamped phases {tot.mean()/1e6:.1f} Mcycles/wave = {tot.mean()/ (ms*1e-3)/1e9:.2f} GHz-equivalent of the kernel time")
+solver.close()

@@ -47,7 +47,7 @@ namespace tsat {
 
 constexpr int WAVE = 64;
 constexpr int CK = 32;    // knots per forward-sweep LDS chunk
-constexpr int CHB = 48;   // knots per backward-sweep LDS chunk (Jacobian lanes)
+constexpr int CHB = 40;   // knots per backward-sweep LDS chunk (Jacobian lanes)
 constexpr int PSTRIDE = 64;
 // per-trajectory parameter record (reals)
 enum { P_X0 = 0, P_XF = 7, P_QD = 14, P_QFD = 21, P_RD = 28, P_ULO = 31, P_UHI = 34, P_J = 37, P_JI = 46,
@@ -82,14 +82,17 @@ constexpr int L_HXX = L_WT + 90;         // 7 x 7 (+1)
 constexpr int L_HUX = L_HXX + 50;        // 3 x 8  (col 7 = Qu)
 constexpr int L_HUU = L_HUX + 24;        // 3 x 3 (+1)
 constexpr int L_KD = L_HUU + 10;         // 3 x 8  (col 7 = d)
-constexpr int L_UNION = L_KD + 24;       // 334
+constexpr int L_ZERO = L_KD + 24;        // a constant 0 (branch-free "no initial value" source)
+constexpr int L_SINK = L_ZERO + 1;       // write target of lanes without a role in a step
+constexpr int L_UNION = L_SINK + 1;      // 336 (16-byte aligned)
 constexpr int L_REC = L_UNION;           // CHB x RECS
+constexpr int L_KDB = L_REC + CHB * RECS;  // CHB x 24: K,d of the chunk, flushed to HBM once per chunk
 constexpr int L_KDC = L_UNION;           // CK x 24
 constexpr int L_XUC = L_KDC + CK * KDW;
 constexpr int L_LMC = L_XUC + CK * XUW;
 constexpr int L_BSC = L_LMC + CK * LMW;
 constexpr int L_FWD_END = L_BSC + CK * BSW;
-constexpr int L_BWD_END = L_REC + CHB * RECS;
+constexpr int L_BWD_END = L_KDB + CHB * KDW;
 constexpr int LDS_REALS = (L_FWD_END > L_BWD_END ? L_FWD_END : L_BWD_END);
 
 // --------------------------------------------------------------------------------------------------
@@ -127,6 +130,17 @@ TSAT_DEV double rcp_(double a) {
   return y;
 }
 #endif
+
+// phase timing for the diagnostic build (-DTSAT_PROFILE): shader-clock stamps accumulated per phase and written to
+// the trace buffer's row 0 of each trajectory; the production build compiles all of it away.
+#if defined(TSAT_PROFILE) && !defined(TSAT_EMU)
+TSAT_DEV unsigned long long tick_() { return __builtin_amdgcn_s_memtime(); }
+#else
+TSAT_DEV unsigned long long tick_() { return 0ull; }
+#endif
+struct PhaseClock {
+  unsigned long long fwd = 0, jac = 0, ric = 0, par = 0;
+};
 
 // a[i] for a register-resident array and a run-time i (select chain: keeps `a` out of scratch memory)
 template <typename real>
@@ -500,43 +514,58 @@ TSAT_DEV void pair28(int L, int& i, int& j) {  // L in [0,28) -> (i<=j) of a 7x7
 
 template <typename real, int INTEG>
 TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int traj, const real nu[7], real mu,
-                             real rho, real* lds, real* dV1_out, real* dV2_out) {
+                             real rho, real* lds, real* dV1_out, real* dV2_out, PhaseClock& pc) {
   const int lane = TSAT_LANE();
   const int N = tr.N;
   const real* XUg = a.XU + (size_t)traj * N * XUW;
   const real* LMg = a.LAM + (size_t)traj * (N - 1) * LMW;
   real* KDg = a.KD + (size_t)traj * (N - 1) * KDW;
   real* St = lds + L_ST;
-  real* Wt = lds + L_WT;
-  real* Hxx = lds + L_HXX;
-  real* Hux = lds + L_HUX;
-  real* Huu = lds + L_HUU;
-  real* KDs = lds + L_KD;
   real* rec = lds + L_REC;
 
-  // lane roles --------------------------------------------------------------------------------
-  const int r1 = lane & 7, c1 = lane >> 3;          // step 1: W~[r1][c1], and W~[r1][8+c1] for c1 < 2
-  int colA = 0, colB = 0, o1 = -1, o2 = -1;          // step 2: dot(F[:,colA], W[:,colB]) -> lds[o1], lds[o2]
-  real diag2 = 0; int luu2 = -1;
-  if (lane < 28) {
+  // ---- lane roles. Every step is branch-free: each lane owns LDS offsets for its operands and outputs; lanes
+  // without a role in a step compute on harmless operands and write to L_SINK. -----------------------------
+  // step 1: W~[r1][c1] = sum_m S~[r1][m] F[m][c1], plus columns 8,9 on the lanes with c1 < 2
+  const int r1 = lane & 7, c1 = lane >> 3;
+  const int s1_st = L_ST + r1 * 9;
+  const int s1_fa = c1 * 8, s1_fb = (8 + (c1 & 1)) * 8;           // relative to the knot record
+  const int s1_oa = L_WT + c1 * 9 + r1;
+  const int s1_ob = (c1 < 2) ? (L_WT + (8 + c1) * 9 + r1) : L_SINK;
+  // step 2: acc = diag + init + dot(F[:,colA], opB[0..6]) -> lds[o1], lds[o2]
+  int s2_fa = 0, s2_b = L_WT, s2_init = -1, s2_o1 = L_SINK, s2_o2 = L_SINK;
+  real s2_diag = 0;
+  if (lane < 28) {                                   // Qxx(i,j), i <= j  = Q + A'SA
     int i, j; pair28(lane, i, j);
-    colA = i; colB = j; o1 = L_HXX + i * 7 + j; o2 = L_HXX + j * 7 + i;
-    if (i == j) diag2 = sel7(tr.Qd, i);
-  } else if (lane < 49) {
-    int aa = (lane - 28) / 7, j = (lane - 28) % 7;
-    colA = 7 + aa; colB = j; o1 = L_HUX + aa * 8 + j; o2 = o1;
-  } else if (lane < 55) {
-    const int L = lane - 49;                        // (0,0)(0,1)(0,2)(1,1)(1,2)(2,2)
+    s2_fa = i * 8; s2_b = L_WT + j * 9; s2_o1 = L_HXX + i * 7 + j; s2_o2 = L_HXX + j * 7 + i;
+    if (i == j) s2_diag = sel7(tr.Qd, i);
+  } else if (lane < 49) {                            // Qux(a,j) = B'SA
+    const int aa = (lane - 28) / 7, j = (lane - 28) % 7;
+    s2_fa = (7 + aa) * 8; s2_b = L_WT + j * 9; s2_o1 = s2_o2 = L_HUX + aa * 8 + j;
+  } else if (lane < 55) {                            // Quu(a,b), a <= b = luu + B'SB
+    const int L = lane - 49;                         // (0,0)(0,1)(0,2)(1,1)(1,2)(2,2)
     const int aa = (L < 3) ? 0 : (L < 5 ? 1 : 2);
     const int bb = (L < 3) ? L : (L < 5 ? L - 2 : 2);
-    colA = 7 + aa; colB = 7 + bb; o1 = L_HUU + aa * 3 + bb; o2 = L_HUU + bb * 3 + aa;
-    if (aa == bb) luu2 = aa;
-  } else if (lane < 58) {                           // Qu[a] = lu[a] + W~[7][7+a]  -> Hux[a][7]
-    o1 = -2;
+    s2_fa = (7 + aa) * 8; s2_b = L_WT + (7 + bb) * 9; s2_o1 = L_HUU + aa * 3 + bb; s2_o2 = L_HUU + bb * 3 + aa;
+    if (aa == bb) s2_init = R_LUU + aa;
+  } else if (lane < 58) {                            // Qu(a) = lu + B's'  -> Hux[a][7]
+    const int aa = lane - 55;
+    s2_fa = (7 + aa) * 8; s2_b = L_ST + 7 * 9; s2_init = R_LU + aa; s2_o1 = s2_o2 = L_HUX + aa * 8 + 7;
   }
-  const int a3 = lane >> 3, j3 = lane & 7;           // step 3: K[a3][j3] (j3 == 7: d[a3]) for a3 < 3
-  int i4 = 0, j4 = 0;                                // step 4: S[i4][j4] (lane < 28), s[lane-28] (28..34)
-  if (lane < 28) pair28(lane, i4, j4);
+  // step 3: K[a3][j3] (j3 == 7: d[a3]) on the lanes with a3 < 3
+  const int a3 = lane >> 3, j3 = lane & 7;
+  const int a3c = (a3 < 3) ? a3 : 2;
+  const int s3_o = (a3 < 3) ? (L_KD + a3 * 8 + j3) : L_SINK;
+  const int s3_slot = (a3 < 3) ? ((j3 < 7) ? (a3 * 7 + j3) : (21 + a3)) : -1;   // position inside the K,d record
+  // step 4: S(i,j), i <= j on lanes 0..27; s(i) on lanes 28..34 written as the "column 7" of the same formula
+  int i4 = 0, j4 = 0, s4_b1 = L_ZERO, s4_b1rel = -1, s4_b2 = L_ZERO, s4_o1 = L_SINK, s4_o2 = L_SINK;
+  if (lane < 28) {
+    pair28(lane, i4, j4);
+    s4_b1 = L_HXX + i4 * 7 + j4; s4_o1 = L_ST + i4 * 9 + j4; s4_o2 = L_ST + j4 * 9 + i4;
+  } else if (lane < 35) {
+    i4 = lane - 28; j4 = 7;
+    s4_b1rel = R_LX + i4; s4_b2 = L_WT + i4 * 9 + 7; s4_o1 = s4_o2 = L_ST + 7 * 9 + i4;
+  }
+  const int s4_hi = L_HUX + i4, s4_hj = L_HUX + j4, s4_ki = L_KD + i4, s4_kj = L_KD + j4;
 
   // terminal cost-to-go: Sxx = Qf + mu*mask, Sx = Qf e + mask (nu + mu e)   (Appendix A backward)
   {
@@ -553,6 +582,7 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
       }
       St[r1 * 9 + c1] = v;
     }
+    if (lane == 0) { lds[L_ZERO] = 0; lds[L_SINK] = 0; }
   }
   real dV1 = 0, dV2 = 0;
   bool pd_ok = true;
@@ -563,6 +593,7 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
     const int k0 = ch * CHB;
     const int nk = (N - 1 - k0 < CHB) ? (N - 1 - k0) : CHB;
     // ---- Jacobian lanes: knot k0 + lane -------------------------------------------------------
+    const unsigned long long t_j0 = tick_();
     if (lane < nk) {
       const int k = k0 + lane;
       const real* xu = XUg + (size_t)k * XUW;
@@ -592,39 +623,39 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
       }
     }
     TSAT_SYNC();
+    const unsigned long long t_j1 = tick_();
+    pc.jac += t_j1 - t_j0;
     // ---- Riccati recursion over the chunk, last knot first -----------------------------------
+    int l_done = nk;  // knots [l_done, nk) of the chunk have their K,d in the LDS buffer
     for (int l = nk - 1; l >= 0; --l) {
-      const real* rc = rec + l * RECS;
-      const real* F = rc + R_F;
+      const int rcb = L_REC + l * RECS;
       // step 1: W~ = [S; s'] [A|B]   (8 x 10)
       {
         real acc = 0, acc2 = 0;
         for (int m = 0; m < 7; ++m) {
-          const real sv = St[r1 * 9 + m];
-          acc += sv * F[c1 * 8 + m];
-          if (c1 < 2) acc2 += sv * F[(8 + c1) * 8 + m];
+          const real sv = lds[s1_st + m];
+          acc += sv * lds[rcb + s1_fa + m];
+          acc2 += sv * lds[rcb + s1_fb + m];
         }
-        Wt[c1 * 9 + r1] = acc;
-        if (c1 < 2) Wt[(8 + c1) * 9 + r1] = acc2;
+        lds[s1_oa] = acc;
+        lds[s1_ob] = acc2;
       }
       TSAT_SYNC_LDS();
       // step 2: Qxx = Q + A'SA, Qux = B'SA, Quu = luu + B'SB, Qu = lu + B's
-      if (o1 >= 0) {
-        real acc = diag2;
-        if (luu2 >= 0) acc = rc[R_LUU + luu2];
-        for (int m = 0; m < 7; ++m) acc += F[colA * 8 + m] * Wt[colB * 9 + m];
-        lds[o1] = acc;
-        lds[o2] = acc;
-      } else if (o1 == -2) {
-        const int aa = lane - 55;
-        Hux[aa * 8 + 7] = rc[R_LU + aa] + Wt[(7 + aa) * 9 + 7];
+      {
+        real acc = s2_diag + lds[(s2_init >= 0) ? (rcb + s2_init) : L_ZERO];
+        for (int m = 0; m < 7; ++m) acc += lds[rcb + s2_fa + m] * lds[s2_b + m];
+        lds[s2_o1] = acc;
+        lds[s2_o2] = acc;
       }
       TSAT_SYNC_LDS();
       // step 3: regularise, PD test (Sylvester), adjugate inverse, K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu
-      real Qi0, Qi1, Qi2;
       {
+        const real* Huu = lds + L_HUU;
+        const real* Hux = lds + L_HUX;
         const real q00 = Huu[0] + rho, q11 = Huu[4] + rho, q22 = Huu[8] + rho;
         const real q10 = Huu[1], q20 = Huu[2], q21 = Huu[5];
+        const real h0 = Hux[0 * 8 + j3], h1 = Hux[1 * 8 + j3], h2 = Hux[2 * 8 + j3];
         const real c00 = q11 * q22 - q21 * q21;
         const real c01 = q20 * q21 - q10 * q22;
         const real c02 = q10 * q21 - q20 * q11;
@@ -633,50 +664,53 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
         const real c22 = q00 * q11 - q10 * q10;
         const real det = q00 * c00 + q10 * c01 + q20 * c02;
         if (!(q00 > 0 && c22 > 0 && det > 0)) pd_ok = false;
-        const real id = rcp_(det);
-        // row a3 of the inverse
-        Qi0 = ((a3 == 0) ? c00 : (a3 == 1 ? c01 : c02)) * id;
-        Qi1 = ((a3 == 0) ? c01 : (a3 == 1 ? c11 : c12)) * id;
-        Qi2 = ((a3 == 0) ? c02 : (a3 == 1 ? c12 : c22)) * id;
+        const real nid = -rcp_(det);
+        // row a3 of the inverse (negated)
+        const real Qi0 = ((a3c == 0) ? c00 : (a3c == 1 ? c01 : c02)) * nid;
+        const real Qi1 = ((a3c == 0) ? c01 : (a3c == 1 ? c11 : c12)) * nid;
+        const real Qi2 = ((a3c == 0) ? c02 : (a3c == 1 ? c12 : c22)) * nid;
+        const real v = Qi0 * h0 + Qi1 * h1 + Qi2 * h2;
+        lds[s3_o] = v;
+        lds[(s3_slot >= 0) ? (L_KDB + l * KDW + s3_slot) : L_SINK] = v;
       }
       if (!pd_ok) break;  // wave-uniform: every lane read the same Huu
-      if (a3 < 3) {
-        const real v = -(Qi0 * Hux[0 * 8 + j3] + Qi1 * Hux[1 * 8 + j3] + Qi2 * Hux[2 * 8 + j3]);
-        KDs[a3 * 8 + j3] = v;
-        KDg[(size_t)(k0 + l) * KDW + ((j3 < 7) ? (a3 * 7 + j3) : (21 + a3))] = v;
-      }
+      l_done = l;
       TSAT_SYNC_LDS();
       // step 4: cost-to-go. With K = -Quu_reg^-1 Qux: Quu K + Qux = -rho K, so
-      //   Sxx = Qxx + sym(Qux'K) - rho K'K ;  Sx = Qx + Qux'd - rho K'd   (Appendix A, compacted)
+      //   Sxx = Qxx + sym(Qux'K) - rho K'K ;  Sx = Qx + sym(Qux'd, Qu'K) - rho K'd   (Appendix A, compacted;
+      //   Qux'd = Qu'K in exact arithmetic, so the s-lanes run the very same formula with j = "column 7")
       {
-        const real d0 = KDs[7], d1 = KDs[15], d2 = KDs[23];
-        const real qu0 = Hux[7], qu1 = Hux[15], qu2 = Hux[23];
+        const real* Huu = lds + L_HUU;
+        const real d0 = lds[L_KD + 7], d1 = lds[L_KD + 15], d2 = lds[L_KD + 23];
+        const real qu0 = lds[L_HUX + 7], qu1 = lds[L_HUX + 15], qu2 = lds[L_HUX + 23];
         dV1 += d0 * qu0 + d1 * qu1 + d2 * qu2;
         const real t0 = Huu[0] * d0 + Huu[1] * d1 + Huu[2] * d2;
         const real t1 = Huu[3] * d0 + Huu[4] * d1 + Huu[5] * d2;
         const real t2 = Huu[6] * d0 + Huu[7] * d1 + Huu[8] * d2;
         dV2 += (real)0.5 * (d0 * t0 + d1 * t1 + d2 * t2);
-        if (lane < 28) {
-          real acc = Hxx[i4 * 7 + j4];
-          real sy = 0, kk = 0;
-          for (int c = 0; c < 3; ++c) {
-            sy += Hux[c * 8 + i4] * KDs[c * 8 + j4] + Hux[c * 8 + j4] * KDs[c * 8 + i4];
-            kk += KDs[c * 8 + i4] * KDs[c * 8 + j4];
-          }
-          acc += (real)0.5 * sy - rho * kk;
-          St[i4 * 9 + j4] = acc;
-          St[j4 * 9 + i4] = acc;
-        } else if (lane < 35) {
-          const int i = lane - 28;
-          real acc = rc[R_LX + i] + Wt[i * 9 + 7];
-          acc += (Hux[0 * 8 + i] * d0 + Hux[1 * 8 + i] * d1 + Hux[2 * 8 + i] * d2);
-          acc -= rho * (KDs[0 * 8 + i] * d0 + KDs[1 * 8 + i] * d1 + KDs[2 * 8 + i] * d2);
-          St[7 * 9 + i] = acc;
+        real acc = lds[(s4_b1rel >= 0) ? (rcb + s4_b1rel) : s4_b1] + lds[s4_b2];
+        real sy = 0, kk = 0;
+        for (int c = 0; c < 3; ++c) {
+          const real hi = lds[s4_hi + c * 8], hj = lds[s4_hj + c * 8], ki = lds[s4_ki + c * 8], kj = lds[s4_kj + c * 8];
+          sy += hi * kj + hj * ki;
+          kk += ki * kj;
         }
+        acc += (real)0.5 * sy - rho * kk;
+        lds[s4_o1] = acc;
+        lds[s4_o2] = acc;
       }
       TSAT_SYNC_LDS();
     }
+    // flush the chunk's K,d records (contiguous in HBM) with coalesced 16-byte stores
+    {
+      struct alignas(2 * sizeof(real)) R2 { real a, b; };
+      const R2* src = reinterpret_cast<const R2*>(lds + L_KDB + l_done * KDW);
+      R2* dst = reinterpret_cast<R2*>(KDg + (size_t)(k0 + l_done) * KDW);
+      const int n2 = (nk - l_done) * (KDW / 2);
+      for (int i = lane; i < n2; i += WAVE) dst[i] = src[i];
+    }
     TSAT_SYNC();
+    pc.ric += tick_() - t_j1;
   }
   *dV1_out = dV1;
   *dV2_out = dV2;
@@ -822,6 +856,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, real* lds) {
       bp_restarts = 0, fp_fails = 0;
   real grad = 0;
 
+  PhaseClock pc;
   // open-loop rollout of U0
   bool ok;
   real J0 = forward_sweep<real, INTEG>(a, tr, traj, false, 1, nu, mu, lds, &ok);
@@ -842,7 +877,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, real* lds) {
         real dV1 = 0, dV2 = 0;
         for (;;) {
           n_backward++;
-          if (backward_sweep<real, INTEG>(a, tr, traj, nu, mu, rho, lds, &dV1, &dV2)) break;
+          if (backward_sweep<real, INTEG>(a, tr, traj, nu, mu, rho, lds, &dV1, &dV2, pc)) break;
           bp_restarts++;
           drho = (drho * (real)o.reg_scale > (real)o.reg_scale) ? drho * (real)o.reg_scale : (real)o.reg_scale;
           rho = (rho * drho > (real)o.reg_min) ? rho * drho : (real)o.reg_min;
@@ -858,7 +893,10 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, real* lds) {
         }
         TSAT_SYNC();
         // all backtracking trials in one sweep
+        const unsigned long long t_f0 = tick_();
         const real Jc = forward_sweep<real, INTEG>(a, tr, traj, true, o.max_linesearch, nu, mu, lds, &ok);
+        const unsigned long long t_f1 = tick_();
+        pc.fwd += t_f1 - t_f0;
         n_forward++;
         real alpha = 1;
         for (int j = 0; j < lane && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (real)0.5;
@@ -882,6 +920,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, real* lds) {
           grad = adopt_and_gradient(a, tr, traj, -1, lds);
         }
         TSAT_SYNC();
+        pc.par += tick_() - t_f1;
         real dJ = J - Jprev;
         dJ = dJ < 0 ? -dJ : dJ;
         if (trace && lane == 0 && trow < a.trace_rows) {
@@ -926,6 +965,12 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, real* lds) {
     st.status = status; st.outer_iters = outer_iters; st.inner_iters = inner_iters; st.ls_trials = ls_trials;
     st.n_backward = n_backward; st.n_forward = n_forward; st.bp_restarts = bp_restarts; st.fp_fails = fp_fails;
     st.cost = (double)cost; st.cost_al = (double)cost_al; st.c_max = (double)cmax; st.grad = (double)grad;
+#ifdef TSAT_PROFILE
+    if (trace && a.trace_rows > 0) {  // diagnostic build only: row 0 carries the phase clocks instead of iteration 1
+      trace[0] = (double)pc.fwd; trace[1] = (double)pc.jac; trace[2] = (double)pc.ric; trace[3] = (double)pc.par;
+      trace[4] = (double)inner_iters; trace[5] = (double)n_backward;
+    }
+#endif
   }
 }
 
