@@ -13,8 +13,10 @@
 namespace tsat_emu {
 thread_local int g_lane = 0;
 std::barrier<>* g_bar = nullptr;
+void* g_lds = nullptr;     // one emulated wavefront at a time
 int lane() { return g_lane; }
 void sync() { g_bar->arrive_and_wait(); }
+void* lds() { return g_lds; }
 }  // namespace tsat_emu
 
 #include "../../tortoisesat.jl_amd/csrc/tsat_host_pack.hpp"
@@ -26,11 +28,12 @@ static void run_block(const KArgs<double>& a, int traj) {
   std::vector<double> lds(LDS_REALS, 0.0);
   std::barrier<> bar(WAVE);
   tsat_emu::g_bar = &bar;
+  tsat_emu::g_lds = lds.data();
   std::vector<std::thread> th;
   for (int l = 0; l < WAVE; ++l)
     th.emplace_back([&, l]() {
       tsat_emu::g_lane = l;
-      solve_trajectory<double, INTEG>(a, traj, lds.data());
+      solve_trajectory<double, INTEG>(a, traj);
     });
   for (auto& t : th) t.join();
 }

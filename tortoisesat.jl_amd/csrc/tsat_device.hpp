@@ -21,33 +21,48 @@
 
 #ifdef TSAT_EMU
 #include <cmath>
-namespace tsat_emu { int lane(); void sync(); }
+namespace tsat_emu { int lane(); void sync(); void* lds(); }
 #define TSAT_DEV inline
+#define TSAT_PHASE inline
+#define TSAT_GLOBAL
 #define TSAT_LANE() (tsat_emu::lane())
 #define TSAT_SYNC() (tsat_emu::sync())
 #define TSAT_SYNC_LDS() (tsat_emu::sync())
 #else
 #define TSAT_DEV __device__ __forceinline__
+// Each sweep is its own (non-inlined) function: the register allocator then works on one hot loop at a time
+// instead of on the whole solve, which otherwise spills loop invariants of every phase into every other phase.
+#define TSAT_PHASE __device__ __noinline__
+// HBM pointers that cross a (non-inlined) function boundary must carry their address space, otherwise every
+// access through them is a flat_* instruction (both memory pipes, both wait counters) instead of global_*.
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+#define TSAT_GLOBAL __attribute__((address_space(1)))
+#else
+#define TSAT_GLOBAL   /* host pass of the same translation unit: only parses the device functions */
+#endif
 #define TSAT_LANE() ((int)threadIdx.x)
 // full fence: orders global AND LDS traffic between the lanes of the wave (s_waitcnt vmcnt(0) lgkmcnt(0))
 #define TSAT_SYNC() __syncthreads()
 // LDS-only ordering between the lanes of ONE wavefront. A wave's DS instructions execute in issue order, so a
 // ds_write followed in program order by another lane's ds_read of the same address needs no s_waitcnt; all that
 // is required is that the compiler keeps the order. Crucially this does NOT drain vmcnt, so global stores issued
-// inside a sequential sweep (K/d, candidates) stay in flight instead of stalling every knot on their write-ack.
+// inside a sequential sweep (candidates) stay in flight instead of stalling every knot on their write-ack.
 #define TSAT_SYNC_LDS()                                       \
   do {                                                        \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
     __builtin_amdgcn_wave_barrier();                          \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
   } while (0)
+// the wavefront's LDS block. Declared at namespace scope so that every phase function addresses it as LDS
+// (address space 3) instead of through a generic pointer argument, which would turn ds_* into flat_* accesses.
+extern __shared__ __align__(16) unsigned char tsat_smem[];
 #endif
 
 namespace tsat {
 
 constexpr int WAVE = 64;
 constexpr int CK = 32;    // knots per forward-sweep LDS chunk
-constexpr int CHB = 40;   // knots per backward-sweep LDS chunk (Jacobian lanes)
+constexpr int CHB = 40;   // knots per backward-sweep LDS chunk (Jacobian lanes); 4 waves x 40.8 KB fit one CU
 constexpr int PSTRIDE = 64;
 // per-trajectory parameter record (reals)
 enum { P_X0 = 0, P_XF = 7, P_QD = 14, P_QFD = 21, P_RD = 28, P_ULO = 31, P_UHI = 34, P_J = 37, P_JI = 46,
@@ -74,9 +89,23 @@ struct KArgs {
   int trace_rows;
 };
 
+// per-trajectory pointers handed (by value) to the phase functions
+template <typename real>
+struct TPtrs {
+  TSAT_GLOBAL real* XU;          // [N][10]
+  TSAT_GLOBAL real* KD;          // [N-1][24]
+  TSAT_GLOBAL real* LAM;         // [N-1][6]
+  TSAT_GLOBAL real* CAND;        // [max_ls][N][10]
+  const TSAT_GLOBAL real* bt;    // [n_tab][4]
+};
+
 // LDS carve-up (in reals)
 constexpr int L_RED = 0;                 // 64 reduction scratch
-constexpr int L_ST = L_RED + 64;         // S~ : 8 rows x 9
+constexpr int L_TR = L_RED + 64;         // trajectory constants: parameter record (64) + hJi(9) + hh + us (+pad) = 76
+constexpr int TR_HJI = PSTRIDE, TR_HH = PSTRIDE + 9, TR_US = PSTRIDE + 10;
+constexpr int L_NU = L_TR + 76;          // terminal multipliers nu(7) (+1)
+constexpr int L_PC = L_NU + 8;           // diagnostic phase clocks (4)
+constexpr int L_ST = L_PC + 4;           // S~ : 8 rows x 9
 constexpr int L_WT = L_ST + 72;          // W~ : 10 cols x 9
 constexpr int L_HXX = L_WT + 90;         // 7 x 7 (+1)
 constexpr int L_HUX = L_HXX + 50;        // 3 x 8  (col 7 = Qu)
@@ -84,7 +113,8 @@ constexpr int L_HUU = L_HUX + 24;        // 3 x 3 (+1)
 constexpr int L_KD = L_HUU + 10;         // 3 x 8  (col 7 = d)
 constexpr int L_ZERO = L_KD + 24;        // a constant 0 (branch-free "no initial value" source)
 constexpr int L_SINK = L_ZERO + 1;       // write target of lanes without a role in a step
-constexpr int L_UNION = L_SINK + 1;      // 336 (16-byte aligned)
+constexpr int L_UNION = L_SINK + 1;      // 424 (16-byte aligned)
+static_assert(L_UNION % 2 == 0, "phase buffers must stay 16-byte aligned");
 constexpr int L_REC = L_UNION;           // CHB x RECS
 constexpr int L_KDB = L_REC + CHB * RECS;  // CHB x 24: K,d of the chunk, flushed to HBM once per chunk
 constexpr int L_KDC = L_UNION;           // CK x 24
@@ -94,6 +124,15 @@ constexpr int L_BSC = L_LMC + CK * LMW;
 constexpr int L_FWD_END = L_BSC + CK * BSW;
 constexpr int L_BWD_END = L_KDB + CHB * KDW;
 constexpr int LDS_REALS = (L_FWD_END > L_BWD_END ? L_FWD_END : L_BWD_END);
+
+template <typename real>
+TSAT_DEV real* lds_base() {
+#ifdef TSAT_EMU
+  return reinterpret_cast<real*>(tsat_emu::lds());
+#else
+  return reinterpret_cast<real*>(tsat_smem);
+#endif
+}
 
 // --------------------------------------------------------------------------------------------------
 // small math helpers
@@ -138,9 +177,6 @@ TSAT_DEV unsigned long long tick_() { return __builtin_amdgcn_s_memtime(); }
 #else
 TSAT_DEV unsigned long long tick_() { return 0ull; }
 #endif
-struct PhaseClock {
-  unsigned long long fwd = 0, jac = 0, ric = 0, par = 0;
-};
 
 // a[i] for a register-resident array and a run-time i (select chain: keeps `a` out of scratch memory)
 template <typename real>
@@ -209,8 +245,36 @@ struct Traj {
   real h, hh, us;
   double tau0, dtau;
   int N, n_tab;
-  const real* bt;  // [n_tab][4]
+  const TSAT_GLOBAL real* bt;  // [n_tab][4]
 };
+
+// The constants live in the wave's LDS block (written once by stage_traj); every phase function re-reads the
+// ones it uses, so they sit in VGPRs local to that phase instead of in SGPRs spilled across the whole kernel.
+template <typename real>
+TSAT_DEV Traj<real> load_traj(int N, int n_tab, const TSAT_GLOBAL real* bt) {
+  const real* t = lds_base<real>() + L_TR;
+  Traj<real> tr;
+  for (int i = 0; i < 7; ++i) { tr.xf[i] = t[P_XF + i]; tr.Qd[i] = t[P_QD + i]; tr.Qfd[i] = t[P_QFD + i]; }
+  for (int i = 0; i < 3; ++i) { tr.Rd[i] = t[P_RD + i]; tr.ulo[i] = t[P_ULO + i]; tr.uhi[i] = t[P_UHI + i]; }
+  for (int i = 0; i < 9; ++i) { tr.J[i] = t[P_J + i]; tr.hJi[i] = t[TR_HJI + i]; }
+  tr.h = t[P_DT]; tr.hh = t[TR_HH]; tr.us = t[TR_US];
+  tr.tau0 = (double)t[P_TAU0]; tr.dtau = (double)t[P_DTAU];
+  tr.N = N; tr.n_tab = n_tab; tr.bt = bt;
+  return tr;
+}
+// copy the parameter record into LDS and append the derived constants (all lanes; wave-uniform values)
+template <typename real>
+TSAT_DEV void stage_traj(const TSAT_GLOBAL real* P, real u_scale) {
+  real* t = lds_base<real>() + L_TR;
+  const int lane = TSAT_LANE();
+  t[lane] = P[lane];                       // PSTRIDE == WAVE
+  const real h = P[P_DT];
+  if (lane < 9) t[TR_HJI + lane] = h * P[P_JI + lane];
+  if (lane == 9) t[TR_HH] = (real)0.5 * h;
+  if (lane == 10) t[TR_US] = u_scale;
+  if (lane < 8) lds_base<real>()[L_NU + lane] = 0;
+  if (lane < 4) lds_base<real>()[L_PC + lane] = 0;
+}
 
 template <typename real>
 TSAT_DEV int brow_index(const Traj<real>& tr, int k, double c) {
@@ -418,33 +482,36 @@ TSAT_DEV real term_cost(const Traj<real>& tr, const real x[7], const real nu[7],
 
 // cooperative copy of `n` reals (n even, 16-byte aligned both sides) global -> LDS
 template <typename real>
-TSAT_DEV void coop_load(real* dst, const real* src, int n) {
+TSAT_DEV void coop_load(real* dst, const TSAT_GLOBAL real* src, int n) {
   const int lane = TSAT_LANE();
   struct alignas(2 * sizeof(real)) R2 { real a, b; };
-  const R2* s2 = reinterpret_cast<const R2*>(src);
+  const TSAT_GLOBAL R2* s2 = reinterpret_cast<const TSAT_GLOBAL R2*>(src);
   R2* d2 = reinterpret_cast<R2*>(dst);
   for (int i = lane; i < (n >> 1); i += WAVE) d2[i] = s2[i];
 }
 
+template <typename real> struct FwdOut { real J; int ok; };
+template <typename real> struct BwdOut { real dV1, dV2; int pd_ok; };
+
 // --------------------------------------------------------------------------------------------------
-// forward sweep: all line-search candidates at once (lane j: alpha = 2^-j). Returns this lane's AL cost;
-// *ok = rollout stayed within max_state. Candidate knot records go to CAND[traj][lane].
+// forward sweep: all line-search candidates at once (lane j: alpha = 2^-j). Returns this lane's AL cost and
+// whether its rollout stayed within max_state. Candidate knot records go to CAND[lane].
 // --------------------------------------------------------------------------------------------------
 template <typename real, int INTEG>
-TSAT_DEV real forward_sweep(const KArgs<real>& a, const Traj<real>& tr, int traj, bool closed, int n_cand,
-                            const real nu[7], real mu, real* lds, bool* ok) {
+TSAT_PHASE FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_cand, real mu,
+                                      int term_mask, real max_state) {
+  real* lds = lds_base<real>();
+  const Traj<real> tr = load_traj<real>(N, n_tab, p.bt);
   const int lane = TSAT_LANE();
-  const int N = tr.N;
-  const real* P = a.P + (size_t)traj * PSTRIDE;
   real alpha = 1;
   for (int j = 0; j < lane && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (real)0.5;
   real x[7];
-  for (int i = 0; i < 7; ++i) x[i] = P[P_X0 + i];
+  for (int i = 0; i < 7; ++i) x[i] = lds[L_TR + P_X0 + i];
   real J = 0, amax = 0;
-  const real* XUg = a.XU + (size_t)traj * N * XUW;
-  const real* KDg = a.KD + (size_t)traj * (N - 1) * KDW;
-  const real* LMg = a.LAM + (size_t)traj * (N - 1) * LMW;
-  real* Cg = a.CAND + ((size_t)traj * a.max_ls + (lane < n_cand ? lane : 0)) * (size_t)N * XUW;
+  const TSAT_GLOBAL real* XUg = p.XU;
+  const TSAT_GLOBAL real* KDg = p.KD;
+  const TSAT_GLOBAL real* LMg = p.LAM;
+  TSAT_GLOBAL real* Cg = p.CAND + (size_t)(lane < n_cand ? lane : 0) * (size_t)N * XUW;
   real* KDc = lds + L_KDC;
   real* XUc = lds + L_XUC;
   real* LMc = lds + L_LMC;
@@ -457,7 +524,7 @@ TSAT_DEV real forward_sweep(const KArgs<real>& a, const Traj<real>& tr, int traj
     for (int e = lane; e < nk * 3; e += WAVE) {
       const int kk = e / 3, st = e - 3 * kk;
       const int row = brow_index(tr, k0 + kk, 0.5 * (double)st);
-      const real* br = tr.bt + (size_t)row * 4;
+      const TSAT_GLOBAL real* br = tr.bt + (size_t)row * 4;
       BSc[kk * BSW + st * 3 + 0] = br[0];
       BSc[kk * BSW + st * 3 + 1] = br[1];
       BSc[kk * BSW + st * 3 + 2] = br[2];
@@ -480,7 +547,7 @@ TSAT_DEV real forward_sweep(const KArgs<real>& a, const Traj<real>& tr, int traj
       for (int c = 0; c < 3; ++c) amax = fmax_(amax, fabs_(u[c]));
       J += stage_cost(tr, x, u, LMc + kk * LMW, mu, true);
       if (lane < n_cand) {
-        real* cr = Cg + (size_t)(k0 + kk) * XUW;
+        TSAT_GLOBAL real* cr = Cg + (size_t)(k0 + kk) * XUW;
         for (int i = 0; i < 7; ++i) cr[i] = x[i];
         for (int c = 0; c < 3; ++c) cr[7 + c] = u[c];
       }
@@ -492,18 +559,60 @@ TSAT_DEV real forward_sweep(const KArgs<real>& a, const Traj<real>& tr, int traj
     TSAT_SYNC_LDS();  // the next chunk's staging writes must not overtake this chunk's LDS reads
   }
   for (int i = 0; i < 7; ++i) amax = fmax_(amax, fabs_(x[i]));
-  J += term_cost(tr, x, nu, mu, a.opt.terminal_mask, true);
+  real nu[7];
+  for (int i = 0; i < 7; ++i) nu[i] = lds[L_NU + i];
+  J += term_cost(tr, x, nu, mu, term_mask, true);
   if (lane < n_cand) {
-    real* cr = Cg + (size_t)(N - 1) * XUW;
+    TSAT_GLOBAL real* cr = Cg + (size_t)(N - 1) * XUW;
     for (int i = 0; i < 7; ++i) cr[i] = x[i];
     for (int c = 0; c < 3; ++c) cr[7 + c] = 0;
   }
-  *ok = (amax <= (real)a.opt.max_state) && (J == J);
-  return J;
+  FwdOut<real> out;
+  out.J = J;
+  out.ok = ((amax <= max_state) && (J == J)) ? 1 : 0;
+  return out;
 }
 
 // --------------------------------------------------------------------------------------------------
-// backward sweep = Jacobian lanes + Riccati recursion. Returns false (wave-uniform) when some Quu_reg is not PD.
+// Jacobian lanes of one backward chunk: lane l linearises knot k0 + l and leaves [A|B], lx, lu, luu in LDS
+// --------------------------------------------------------------------------------------------------
+template <typename real, int INTEG>
+TSAT_PHASE void jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, real mu) {
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE();
+  if (lane < nk) {
+    const Traj<real> tr = load_traj<real>(N, n_tab, p.bt);
+    const int k = k0 + lane;
+    const TSAT_GLOBAL real* xu = p.XU + (size_t)k * XUW;
+    real x[7], u[3], lam[6], b0[3], b1[3], b2[3];
+    for (int i = 0; i < 7; ++i) x[i] = xu[i];
+    for (int c = 0; c < 3; ++c) u[c] = xu[7 + c];
+    for (int c = 0; c < 6; ++c) lam[c] = p.LAM[(size_t)k * LMW + c];
+    const TSAT_GLOBAL real* p0 = tr.bt + (size_t)brow_index(tr, k, 0.0) * 4;
+    const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
+    const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
+    for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
+    real* rc = lds + L_REC + lane * RECS;
+    rk_jacobian<real, INTEG>(tr, x, u, b0, b1, b2, rc + R_F);
+    for (int i = 0; i < 7; ++i) rc[R_LX + i] = tr.Qd[i] * (x[i] - tr.xf[i]);
+    for (int c = 0; c < 3; ++c) {
+      real lu = tr.Rd[c] * u[c], luu = tr.Rd[c];
+      real cc = u[c] - tr.uhi[c], lm = lam[c];
+      bool act = (cc > 0 || lm > 0);
+      lu += lm + (act ? mu * cc : (real)0);
+      luu += act ? mu : (real)0;
+      cc = tr.ulo[c] - u[c]; lm = lam[3 + c];
+      act = (cc > 0 || lm > 0);
+      lu -= lm + (act ? mu * cc : (real)0);
+      luu += act ? mu : (real)0;
+      rc[R_LU + c] = lu;
+      rc[R_LUU + c] = luu;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// backward sweep = Jacobian lanes + Riccati recursion. pd_ok = 0 (wave-uniform) when some Quu_reg is not PD.
 // --------------------------------------------------------------------------------------------------
 TSAT_DEV void pair28(int L, int& i, int& j) {  // L in [0,28) -> (i<=j) of a 7x7 upper triangle, row by row
   int r = 0, base = 0;
@@ -513,15 +622,10 @@ TSAT_DEV void pair28(int L, int& i, int& j) {  // L in [0,28) -> (i<=j) of a 7x7
 }
 
 template <typename real, int INTEG>
-TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int traj, const real nu[7], real mu,
-                             real rho, real* lds, real* dV1_out, real* dV2_out, PhaseClock& pc) {
+TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu, real rho, int term_mask) {
+  real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
-  const int N = tr.N;
-  const real* XUg = a.XU + (size_t)traj * N * XUW;
-  const real* LMg = a.LAM + (size_t)traj * (N - 1) * LMW;
-  real* KDg = a.KD + (size_t)traj * (N - 1) * KDW;
-  real* St = lds + L_ST;
-  real* rec = lds + L_REC;
+  TSAT_GLOBAL real* KDg = p.KD;
 
   // ---- lane roles. Every step is branch-free: each lane owns LDS offsets for its operands and outputs; lanes
   // without a role in a step compute on harmless operands and write to L_SINK. -----------------------------
@@ -537,7 +641,7 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
   if (lane < 28) {                                   // Qxx(i,j), i <= j  = Q + A'SA
     int i, j; pair28(lane, i, j);
     s2_fa = i * 8; s2_b = L_WT + j * 9; s2_o1 = L_HXX + i * 7 + j; s2_o2 = L_HXX + j * 7 + i;
-    if (i == j) s2_diag = sel7(tr.Qd, i);
+    if (i == j) s2_diag = lds[L_TR + P_QD + i];
   } else if (lane < 49) {                            // Qux(a,j) = B'SA
     const int aa = (lane - 28) / 7, j = (lane - 28) % 7;
     s2_fa = (7 + aa) * 8; s2_b = L_WT + j * 9; s2_o1 = s2_o2 = L_HUX + aa * 8 + j;
@@ -569,18 +673,18 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
 
   // terminal cost-to-go: Sxx = Qf + mu*mask, Sx = Qf e + mask (nu + mu e)   (Appendix A backward)
   {
-    const real* xN = XUg + (size_t)(N - 1) * XUW;
+    const TSAT_GLOBAL real* xN = p.XU + (size_t)(N - 1) * XUW;
     if (c1 < 7) {
       real v = 0;
-      const real qf = sel7(tr.Qfd, c1);
-      const real e = xN[c1] - sel7(tr.xf, c1);
-      const bool m = (a.opt.terminal_mask >> c1) & 1;
+      const real qf = lds[L_TR + P_QFD + c1];
+      const real e = xN[c1] - lds[L_TR + P_XF + c1];
+      const bool m = (term_mask >> c1) & 1;
       if (r1 < 7) {
         if (r1 == c1) v = qf + (m ? mu : (real)0);
       } else {
-        v = qf * e + (m ? (sel7(nu, c1) + mu * e) : (real)0);
+        v = qf * e + (m ? (lds[L_NU + c1] + mu * e) : (real)0);
       }
-      St[r1 * 9 + c1] = v;
+      lds[L_ST + r1 * 9 + c1] = v;
     }
     if (lane == 0) { lds[L_ZERO] = 0; lds[L_SINK] = 0; }
   }
@@ -592,39 +696,10 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
   for (int ch = nchunks - 1; ch >= 0 && pd_ok; --ch) {
     const int k0 = ch * CHB;
     const int nk = (N - 1 - k0 < CHB) ? (N - 1 - k0) : CHB;
-    // ---- Jacobian lanes: knot k0 + lane -------------------------------------------------------
     const unsigned long long t_j0 = tick_();
-    if (lane < nk) {
-      const int k = k0 + lane;
-      const real* xu = XUg + (size_t)k * XUW;
-      real x[7], u[3], lam[6], b0[3], b1[3], b2[3];
-      for (int i = 0; i < 7; ++i) x[i] = xu[i];
-      for (int c = 0; c < 3; ++c) u[c] = xu[7 + c];
-      for (int c = 0; c < 6; ++c) lam[c] = LMg[(size_t)k * LMW + c];
-      const real* p0 = tr.bt + (size_t)brow_index(tr, k, 0.0) * 4;
-      const real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
-      const real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
-      for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
-      real* rc = rec + lane * RECS;
-      rk_jacobian<real, INTEG>(tr, x, u, b0, b1, b2, rc + R_F);
-      for (int i = 0; i < 7; ++i) rc[R_LX + i] = tr.Qd[i] * (x[i] - tr.xf[i]);
-      for (int c = 0; c < 3; ++c) {
-        real lu = tr.Rd[c] * u[c], luu = tr.Rd[c];
-        real cc = u[c] - tr.uhi[c], lm = lam[c];
-        bool act = (cc > 0 || lm > 0);
-        lu += lm + (act ? mu * cc : (real)0);
-        luu += act ? mu : (real)0;
-        cc = tr.ulo[c] - u[c]; lm = lam[3 + c];
-        act = (cc > 0 || lm > 0);
-        lu -= lm + (act ? mu * cc : (real)0);
-        luu += act ? mu : (real)0;
-        rc[R_LU + c] = lu;
-        rc[R_LUU + c] = luu;
-      }
-    }
+    jacobian_chunk<real, INTEG>(p, N, n_tab, k0, nk, mu);
     TSAT_SYNC();
     const unsigned long long t_j1 = tick_();
-    pc.jac += t_j1 - t_j0;
     // ---- Riccati recursion over the chunk, last knot first -----------------------------------
     int l_done = nk;  // knots [l_done, nk) of the chunk have their K,d in the LDS buffer
     for (int l = nk - 1; l >= 0; --l) {
@@ -705,16 +780,25 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
     {
       struct alignas(2 * sizeof(real)) R2 { real a, b; };
       const R2* src = reinterpret_cast<const R2*>(lds + L_KDB + l_done * KDW);
-      R2* dst = reinterpret_cast<R2*>(KDg + (size_t)(k0 + l_done) * KDW);
+      TSAT_GLOBAL R2* dst = reinterpret_cast<TSAT_GLOBAL R2*>(KDg + (size_t)(k0 + l_done) * KDW);
       const int n2 = (nk - l_done) * (KDW / 2);
       for (int i = lane; i < n2; i += WAVE) dst[i] = src[i];
     }
     TSAT_SYNC();
-    pc.ric += tick_() - t_j1;
+#ifdef TSAT_PROFILE
+    if (lane == 0) {
+      lds[L_PC + 1] += (real)(t_j1 - t_j0);
+      lds[L_PC + 2] += (real)(tick_() - t_j1);
+    }
+#else
+    (void)t_j0; (void)t_j1;
+#endif
   }
-  *dV1_out = dV1;
-  *dV2_out = dV2;
-  return pd_ok;
+  BwdOut<real> out;
+  out.dV1 = dV1;
+  out.dV2 = dV2;
+  out.pd_ok = pd_ok ? 1 : 0;
+  return out;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -722,89 +806,76 @@ TSAT_DEV bool backward_sweep(const KArgs<real>& a, const Traj<real>& tr, int tra
 // --------------------------------------------------------------------------------------------------
 // AL (or plain LQR) cost of the nominal trajectory
 template <typename real>
-TSAT_DEV real nominal_cost(const KArgs<real>& a, const Traj<real>& tr, int traj, const real nu[7], real mu,
-                           bool with_al, real* lds) {
+TSAT_PHASE real nominal_cost(TPtrs<real> p, int N, real mu, int term_mask, int with_al) {
+  real* lds = lds_base<real>();
+  const Traj<real> tr = load_traj<real>(N, 1, p.bt);
   const int lane = TSAT_LANE();
-  const int N = tr.N;
-  const real* XUg = a.XU + (size_t)traj * N * XUW;
-  const real* LMg = a.LAM + (size_t)traj * (N - 1) * LMW;
+  real nu[7];
+  for (int i = 0; i < 7; ++i) nu[i] = lds[L_NU + i];
   real J = 0;
   for (int k = lane; k < N; k += WAVE) {
     real x[7], u[3], lam[6];
-    for (int i = 0; i < 7; ++i) x[i] = XUg[(size_t)k * XUW + i];
+    for (int i = 0; i < 7; ++i) x[i] = p.XU[(size_t)k * XUW + i];
     if (k < N - 1) {
-      for (int c = 0; c < 3; ++c) u[c] = XUg[(size_t)k * XUW + 7 + c];
-      for (int c = 0; c < 6; ++c) lam[c] = LMg[(size_t)k * LMW + c];
-      J += stage_cost(tr, x, u, lam, mu, with_al);
+      for (int c = 0; c < 3; ++c) u[c] = p.XU[(size_t)k * XUW + 7 + c];
+      for (int c = 0; c < 6; ++c) lam[c] = p.LAM[(size_t)k * LMW + c];
+      J += stage_cost(tr, x, u, lam, mu, with_al != 0);
     } else {
-      J += term_cost(tr, x, nu, mu, a.opt.terminal_mask, with_al);
+      J += term_cost(tr, x, nu, mu, term_mask, with_al != 0);
     }
   }
   return wave_sum(J, lds + L_RED);
 }
 
-// max constraint violation of the nominal trajectory
+// max constraint violation of the nominal trajectory; optionally applies the dual update of the control-box
+// multipliers in the same pass (Appendix A "solve_AL")
 template <typename real>
-TSAT_DEV real nominal_violation(const KArgs<real>& a, const Traj<real>& tr, int traj, real* lds) {
+TSAT_PHASE real violation_and_duals(TPtrs<real> p, int N, real mu, int term_mask, int update, real dmax) {
+  real* lds = lds_base<real>();
+  const Traj<real> tr = load_traj<real>(N, 1, p.bt);
   const int lane = TSAT_LANE();
-  const int N = tr.N;
-  const real* XUg = a.XU + (size_t)traj * N * XUW;
   real c = 0;
   for (int k = lane; k < N; k += WAVE) {
     if (k < N - 1) {
       for (int m = 0; m < 3; ++m) {
-        const real u = XUg[(size_t)k * XUW + 7 + m];
-        c = fmax_(c, u - tr.uhi[m]);
-        c = fmax_(c, tr.ulo[m] - u);
+        const real u = p.XU[(size_t)k * XUW + 7 + m];
+        const real chi = u - tr.uhi[m], clo = tr.ulo[m] - u;
+        c = fmax_(c, chi);
+        c = fmax_(c, clo);
+        if (update) {
+          real l = p.LAM[(size_t)k * LMW + m] + mu * chi;
+          l = l > 0 ? l : (real)0; l = l < dmax ? l : dmax;
+          p.LAM[(size_t)k * LMW + m] = l;
+          l = p.LAM[(size_t)k * LMW + 3 + m] + mu * clo;
+          l = l > 0 ? l : (real)0; l = l < dmax ? l : dmax;
+          p.LAM[(size_t)k * LMW + 3 + m] = l;
+        }
       }
     } else {
       for (int i = 0; i < 7; ++i)
-        if ((a.opt.terminal_mask >> i) & 1) c = fmax_(c, fabs_(XUg[(size_t)k * XUW + i] - tr.xf[i]));
+        if ((term_mask >> i) & 1) c = fmax_(c, fabs_(p.XU[(size_t)k * XUW + i] - tr.xf[i]));
     }
   }
   return wave_max(c, lds + L_RED);
 }
 
-// dual update of the control-box multipliers (Appendix A "solve_AL")
-template <typename real>
-TSAT_DEV void dual_update(const KArgs<real>& a, const Traj<real>& tr, int traj, real mu) {
-  const int lane = TSAT_LANE();
-  const int N = tr.N;
-  const real* XUg = a.XU + (size_t)traj * N * XUW;
-  real* LMg = a.LAM + (size_t)traj * (N - 1) * LMW;
-  const real dmax = (real)a.opt.dual_max;
-  for (int k = lane; k < N - 1; k += WAVE) {
-    for (int m = 0; m < 3; ++m) {
-      const real u = XUg[(size_t)k * XUW + 7 + m];
-      real l = LMg[(size_t)k * LMW + m] + mu * (u - tr.uhi[m]);
-      l = l > 0 ? l : (real)0; l = l < dmax ? l : dmax;
-      LMg[(size_t)k * LMW + m] = l;
-      l = LMg[(size_t)k * LMW + 3 + m] + mu * (tr.ulo[m] - u);
-      l = l > 0 ? l : (real)0; l = l < dmax ? l : dmax;
-      LMg[(size_t)k * LMW + 3 + m] = l;
-    }
-  }
-}
-
 // adopt candidate `jw` as the nominal trajectory (or keep it when jw < 0) and return the Todorov gradient
 // mean_k max_i |d_k,i| / (|u_k,i| + 1) evaluated with the (new) nominal controls.
 template <typename real>
-TSAT_DEV real adopt_and_gradient(const KArgs<real>& a, const Traj<real>& tr, int traj, int jw, real* lds) {
+TSAT_PHASE real adopt_and_gradient(TPtrs<real> p, int N, int jw) {
+  real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
-  const int N = tr.N;
-  real* XUg = a.XU + (size_t)traj * N * XUW;
-  const real* KDg = a.KD + (size_t)traj * (N - 1) * KDW;
-  const real* Cg = a.CAND + ((size_t)traj * a.max_ls + (jw >= 0 ? jw : 0)) * (size_t)N * XUW;
+  const TSAT_GLOBAL real* Cg = p.CAND + (size_t)(jw >= 0 ? jw : 0) * (size_t)N * XUW;
   real g = 0;
   for (int k = lane; k < N; k += WAVE) {
     real r[10];
-    const real* src = (jw >= 0) ? (Cg + (size_t)k * XUW) : (XUg + (size_t)k * XUW);
+    const TSAT_GLOBAL real* src = (jw >= 0) ? (Cg + (size_t)k * XUW) : (p.XU + (size_t)k * XUW);
     for (int i = 0; i < 10; ++i) r[i] = src[i];
     if (jw >= 0)
-      for (int i = 0; i < 10; ++i) XUg[(size_t)k * XUW + i] = r[i];
+      for (int i = 0; i < 10; ++i) p.XU[(size_t)k * XUW + i] = r[i];
     if (k < N - 1) {
       real m = 0;
-      for (int c = 0; c < 3; ++c) m = fmax_(m, fabs_(KDg[(size_t)k * KDW + 21 + c]) / (fabs_(r[7 + c]) + (real)1));
+      for (int c = 0; c < 3; ++c) m = fmax_(m, fabs_(p.KD[(size_t)k * KDW + 21 + c]) / (fabs_(r[7 + c]) + (real)1));
       g += m;
     }
   }
@@ -816,74 +887,69 @@ TSAT_DEV real adopt_and_gradient(const KArgs<real>& a, const Traj<real>& tr, int
 // the whole AL-iLQR solve of one trajectory by one wavefront
 // --------------------------------------------------------------------------------------------------
 template <typename real, int INTEG>
-TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, real* lds) {
+TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
+  real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
   const tsat_options& o = a.opt;
-  const int N = a.N;
-  const real* P = a.P + (size_t)traj * PSTRIDE;
-  Traj<real> tr;
-  for (int i = 0; i < 7; ++i) { tr.xf[i] = P[P_XF + i]; tr.Qd[i] = P[P_QD + i]; tr.Qfd[i] = P[P_QFD + i]; }
-  for (int i = 0; i < 3; ++i) { tr.Rd[i] = P[P_RD + i]; tr.ulo[i] = P[P_ULO + i]; tr.uhi[i] = P[P_UHI + i]; }
-  tr.h = P[P_DT];
-  tr.hh = (real)0.5 * tr.h;
-  for (int i = 0; i < 9; ++i) { tr.J[i] = P[P_J + i]; tr.hJi[i] = tr.h * P[P_JI + i]; }
-  tr.us = (real)o.u_scale;
-  tr.tau0 = (double)P[P_TAU0];
-  tr.dtau = (double)P[P_DTAU];
-  tr.N = N;
-  tr.n_tab = a.n_tab;
-  tr.bt = a.BT + (size_t)a.bidx[traj] * a.n_tab * 4;
+  const int N = a.N, n_tab = a.n_tab;
+  TPtrs<real> p;
+  p.XU = (TSAT_GLOBAL real*)(a.XU + (size_t)traj * N * XUW);
+  p.KD = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * (N - 1) * KDW);
+  p.LAM = (TSAT_GLOBAL real*)(a.LAM + (size_t)traj * (N - 1) * LMW);
+  p.CAND = (TSAT_GLOBAL real*)(a.CAND + (size_t)traj * a.max_ls * (size_t)N * XUW);
+  p.bt = (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[traj] * n_tab * 4);
+  stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)traj * PSTRIDE), (real)o.u_scale);
 
-  real* XUg = a.XU + (size_t)traj * N * XUW;
-  real* LMg = a.LAM + (size_t)traj * (N - 1) * LMW;
   const real* U0g = a.U0 + (size_t)traj * (N - 1) * 3;
   double* trace = a.trace ? a.trace + (size_t)traj * a.trace_rows * 8 : nullptr;
   int trow = 0;
 
   // initial_controls!(prob, U0) (src/TortoiseSat.jl:191) + zero multipliers
   for (int k = lane; k < N; k += WAVE) {
-    for (int i = 0; i < 7; ++i) XUg[(size_t)k * XUW + i] = 0;
-    for (int c = 0; c < 3; ++c) XUg[(size_t)k * XUW + 7 + c] = (k < N - 1) ? U0g[(size_t)k * 3 + c] : (real)0;
+    for (int i = 0; i < 7; ++i) p.XU[(size_t)k * XUW + i] = 0;
+    for (int c = 0; c < 3; ++c) p.XU[(size_t)k * XUW + 7 + c] = (k < N - 1) ? U0g[(size_t)k * 3 + c] : (real)0;
     if (k < N - 1)
-      for (int c = 0; c < 6; ++c) LMg[(size_t)k * LMW + c] = 0;
+      for (int c = 0; c < 6; ++c) p.LAM[(size_t)k * LMW + c] = 0;
   }
-  real nu[7];
-  for (int i = 0; i < 7; ++i) nu[i] = 0;
   real mu = (real)o.penalty_init;
+  const real max_state = (real)o.max_state;
+  const int tmask = o.terminal_mask;
   TSAT_SYNC();
 
   int status = TSAT_MAX_OUTER, outer_iters = 0, inner_iters = 0, ls_trials = 0, n_backward = 0, n_forward = 0,
       bp_restarts = 0, fp_fails = 0;
   real grad = 0;
+  unsigned long long pc_fwd = 0, pc_par = 0;
 
-  PhaseClock pc;
   // open-loop rollout of U0
-  bool ok;
-  real J0 = forward_sweep<real, INTEG>(a, tr, traj, false, 1, nu, mu, lds, &ok);
+  FwdOut<real> f0 = forward_sweep<real, INTEG>(p, N, n_tab, 0, 1, mu, tmask, max_state);
   n_forward++;
-  J0 = wave_bcast(J0, 0, lds + L_RED);
-  const int ok0 = wave_first<real>(!ok, lds + L_RED) > 0;  // lane 0 ok?
-  (void)adopt_and_gradient(a, tr, traj, 0, lds);
+  const real J0 = wave_bcast(f0.J, 0, lds + L_RED);
+  const int ok0 = wave_first<real>(!f0.ok, lds + L_RED) > 0;  // lane 0 ok?
+  TSAT_SYNC();
+  (void)adopt_and_gradient<real>(p, N, 0);
   TSAT_SYNC();
   if (!ok0 || !(J0 - J0 == 0)) {
     status = TSAT_DIVERGED;
   } else {
     for (int outer = 1; outer <= o.max_outer; ++outer) {
-      real Jprev = nominal_cost(a, tr, traj, nu, mu, true, lds);
+      real Jprev = nominal_cost<real>(p, N, mu, tmask, 1);
       real rho = (real)o.reg_init, drho = 0;
       int djz = 0;
       bool regfail = false;
       for (int it = 1; it <= o.max_inner; ++it) {
-        real dV1 = 0, dV2 = 0;
+        BwdOut<real> bw;
         for (;;) {
           n_backward++;
-          if (backward_sweep<real, INTEG>(a, tr, traj, nu, mu, rho, lds, &dV1, &dV2, pc)) break;
+          bw = backward_sweep<real, INTEG>(p, N, n_tab, mu, rho, tmask);
+          if (bw.pd_ok) break;
           bp_restarts++;
           drho = (drho * (real)o.reg_scale > (real)o.reg_scale) ? drho * (real)o.reg_scale : (real)o.reg_scale;
           rho = (rho * drho > (real)o.reg_min) ? rho * drho : (real)o.reg_min;
           if (rho > (real)o.reg_max) { regfail = true; break; }
         }
         if (regfail) break;
+        const real dV1 = bw.dV1, dV2 = bw.dV2;
         const real rho_used = rho;
         {  // regularisation decrease
           const real inv = (real)1 / (real)o.reg_scale;
@@ -894,22 +960,24 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, real* lds) {
         TSAT_SYNC();
         // all backtracking trials in one sweep
         const unsigned long long t_f0 = tick_();
-        const real Jc = forward_sweep<real, INTEG>(a, tr, traj, true, o.max_linesearch, nu, mu, lds, &ok);
+        const FwdOut<real> fw = forward_sweep<real, INTEG>(p, N, n_tab, 1, o.max_linesearch, mu, tmask, max_state);
         const unsigned long long t_f1 = tick_();
-        pc.fwd += t_f1 - t_f0;
+        pc_fwd += t_f1 - t_f0;
         n_forward++;
+        const real Jc = fw.J;
         real alpha = 1;
         for (int j = 0; j < lane && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (real)0.5;
         const real expected = -alpha * (dV1 + alpha * dV2);
         const real z = (expected > 0) ? (Jprev - Jc) / expected : (real)-1;
-        const bool acc = (lane < o.max_linesearch) && ok &&
+        const bool acc = (lane < o.max_linesearch) && fw.ok &&
                          ((z > (real)o.ls_lower && z <= (real)o.ls_upper) || Jc < Jprev);
         const int jw = wave_first<real>(acc, lds + L_RED);
         real J;
+        TSAT_SYNC();
         if (jw < WAVE) {
           J = wave_bcast(Jc, jw, lds + L_RED);
           ls_trials += jw + 1;
-          grad = adopt_and_gradient(a, tr, traj, jw, lds);
+          grad = adopt_and_gradient<real>(p, N, jw);
         } else {
           J = Jprev;
           ls_trials += o.max_linesearch;
@@ -917,10 +985,10 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, real* lds) {
           drho = (drho * (real)o.reg_scale > (real)o.reg_scale) ? drho * (real)o.reg_scale : (real)o.reg_scale;
           rho = (rho * drho > (real)o.reg_min) ? rho * drho : (real)o.reg_min;
           rho += (real)o.reg_fp;
-          grad = adopt_and_gradient(a, tr, traj, -1, lds);
+          grad = adopt_and_gradient<real>(p, N, -1);
         }
         TSAT_SYNC();
-        pc.par += tick_() - t_f1;
+        pc_par += tick_() - t_f1;
         real dJ = J - Jprev;
         dJ = dJ < 0 ? -dJ : dJ;
         if (trace && lane == 0 && trow < a.trace_rows) {
@@ -937,29 +1005,25 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, real* lds) {
         if (djz > o.dj_counter_limit) break;
       }
       outer_iters = outer;
-      const real cmax = nominal_violation(a, tr, traj, lds);
+      const real cmax = violation_and_duals<real>(p, N, mu, tmask, 0, (real)o.dual_max);
       if (regfail) { status = TSAT_REG_FAIL; break; }
       if (cmax < (real)o.constraint_tol) { status = TSAT_CONVERGED; break; }
       if (outer == o.max_outer) break;
-      dual_update(a, tr, traj, mu);
-      {
-        const real* xN = XUg + (size_t)(N - 1) * XUW;
+      (void)violation_and_duals<real>(p, N, mu, tmask, 1, (real)o.dual_max);   // dual update of the control box
+      if (lane < 7 && ((tmask >> lane) & 1)) {
         const real dmax = (real)o.dual_max;
-        for (int i = 0; i < 7; ++i)
-          if ((o.terminal_mask >> i) & 1) {
-            real v = nu[i] + mu * (xN[i] - tr.xf[i]);
-            v = v > -dmax ? v : -dmax; v = v < dmax ? v : dmax;
-            nu[i] = v;
-          }
+        real v = lds[L_NU + lane] + mu * (p.XU[(size_t)(N - 1) * XUW + lane] - lds[L_TR + P_XF + lane]);
+        v = v > -dmax ? v : -dmax; v = v < dmax ? v : dmax;
+        lds[L_NU + lane] = v;
       }
       mu = (mu * (real)o.penalty_scale < (real)o.penalty_max) ? mu * (real)o.penalty_scale : (real)o.penalty_max;
       TSAT_SYNC();
     }
   }
   TSAT_SYNC();
-  const real cmax = nominal_violation(a, tr, traj, lds);
-  const real cost = nominal_cost(a, tr, traj, nu, mu, false, lds);
-  const real cost_al = nominal_cost(a, tr, traj, nu, mu, true, lds);
+  const real cmax = violation_and_duals<real>(p, N, mu, tmask, 0, (real)o.dual_max);
+  const real cost = nominal_cost<real>(p, N, mu, tmask, 0);
+  const real cost_al = nominal_cost<real>(p, N, mu, tmask, 1);
   if (lane == 0) {
     tsat_stats& st = a.stats[traj];
     st.status = status; st.outer_iters = outer_iters; st.inner_iters = inner_iters; st.ls_trials = ls_trials;
@@ -967,9 +1031,11 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, real* lds) {
     st.cost = (double)cost; st.cost_al = (double)cost_al; st.c_max = (double)cmax; st.grad = (double)grad;
 #ifdef TSAT_PROFILE
     if (trace && a.trace_rows > 0) {  // diagnostic build only: row 0 carries the phase clocks instead of iteration 1
-      trace[0] = (double)pc.fwd; trace[1] = (double)pc.jac; trace[2] = (double)pc.ric; trace[3] = (double)pc.par;
-      trace[4] = (double)inner_iters; trace[5] = (double)n_backward;
+      trace[0] = (double)pc_fwd; trace[1] = (double)lds[L_PC + 1]; trace[2] = (double)lds[L_PC + 2];
+      trace[3] = (double)pc_par; trace[4] = (double)inner_iters; trace[5] = (double)n_backward;
     }
+#else
+    (void)pc_fwd; (void)pc_par;
 #endif
   }
 }

@@ -17,10 +17,9 @@ using namespace tsat;
 // ------------------------------------------------------------------------------------------------
 template <typename real, int INTEG>
 __global__ __launch_bounds__(64) void tsat_solve_kernel(KArgs<real> a) {
-  extern __shared__ __align__(16) unsigned char tsat_smem[];
   const int traj = blockIdx.x;
   if (traj >= a.T) return;
-  solve_trajectory<real, INTEG>(a, traj, reinterpret_cast<real*>(tsat_smem));
+  solve_trajectory<real, INTEG>(a, traj);
 }
 
 template <typename real>
