@@ -24,6 +24,7 @@
 namespace tsat_emu { int lane(); void sync(); void* lds(); }
 #define TSAT_DEV inline
 #define TSAT_PHASE inline
+#define TSAT_FWD inline
 #define TSAT_GLOBAL
 #define TSAT_LANE() (tsat_emu::lane())
 #define TSAT_SYNC() (tsat_emu::sync())
@@ -33,6 +34,9 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 // Each sweep is its own (non-inlined) function: the register allocator then works on one hot loop at a time
 // instead of on the whole solve, which otherwise spills loop invariants of every phase into every other phase.
 #define TSAT_PHASE __device__ __noinline__
+// the forward sweep is inlined into the kernel body: there the register allocator can park values in AGPRs
+// (one-instruction reload), while a called function has to spill to scratch memory
+#define TSAT_FWD __device__ __forceinline__
 // HBM pointers that cross a (non-inlined) function boundary must carry their address space, otherwise every
 // access through them is a flat_* instruction (both memory pipes, both wait counters) instead of global_*.
 #if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
@@ -62,13 +66,14 @@ namespace tsat {
 
 constexpr int WAVE = 64;
 constexpr int CK = 32;    // knots per forward-sweep LDS chunk
-constexpr int CHB = 40;   // knots per backward-sweep LDS chunk (Jacobian lanes); 4 waves x 40.8 KB fit one CU
+constexpr int CHB = 56;   // knots per backward-sweep LDS chunk (Jacobian lanes); 4 waves x 40.6 KB fit one CU
 constexpr int PSTRIDE = 64;
 // per-trajectory parameter record (reals)
 enum { P_X0 = 0, P_XF = 7, P_QD = 14, P_QFD = 21, P_RD = 28, P_ULO = 31, P_UHI = 34, P_J = 37, P_JI = 46,
        P_TAU0 = 55, P_DTAU = 56, P_DT = 57 };
-// Jacobian record left in LDS per knot (reals): F=[A|B] column-major with column stride 8, then gradients
-constexpr int R_F = 0, R_LX = 80, R_LU = 87, R_LUU = 90, RECS = 93;
+// Jacobian record left in LDS per knot (reals): F=[A|B] column-major (column stride FS = 7), then gradients
+constexpr int FS = 7;
+constexpr int R_F = 0, R_LX = 70, R_LU = 77, R_LUU = 80, RECS = 83;
 // forward-sweep chunk arrays
 constexpr int KDW = 24, XUW = 10, LMW = 6, BSW = 9;
 
@@ -116,13 +121,13 @@ constexpr int L_SINK = L_ZERO + 1;       // write target of lanes without a role
 constexpr int L_UNION = L_SINK + 1;      // 424 (16-byte aligned)
 static_assert(L_UNION % 2 == 0, "phase buffers must stay 16-byte aligned");
 constexpr int L_REC = L_UNION;           // CHB x RECS
-constexpr int L_KDB = L_REC + CHB * RECS;  // CHB x 24: K,d of the chunk, flushed to HBM once per chunk
 constexpr int L_KDC = L_UNION;           // CK x 24
 constexpr int L_XUC = L_KDC + CK * KDW;
 constexpr int L_LMC = L_XUC + CK * XUW;
 constexpr int L_BSC = L_LMC + CK * LMW;
-constexpr int L_FWD_END = L_BSC + CK * BSW;
-constexpr int L_BWD_END = L_KDB + CHB * KDW;
+constexpr int L_GTC = L_BSC + CK * BSW;   // CK x 6 activity gates of the control-box rows (see forward_sweep)
+constexpr int L_FWD_END = L_GTC + CK * LMW;
+constexpr int L_BWD_END = L_REC + CHB * RECS;
 constexpr int LDS_REALS = (L_FWD_END > L_BWD_END ? L_FWD_END : L_BWD_END);
 
 template <typename real>
@@ -158,7 +163,7 @@ template <> TSAT_DEV double rsqrt_<double>(double s) {
 }
 template <> TSAT_DEV float rsqrt_<float>(float s) { return __builtin_amdgcn_rsqf(s); }
 TSAT_DEV double fabs_(double a) { return __builtin_fabs(a); }
-TSAT_DEV double fmax_(double a, double b) { return a > b ? a : b; }
+TSAT_DEV double fmax_(double a, double b) { return __builtin_fmax(a, b); }   // v_max_f64; a NaN operand is ignored
 TSAT_DEV double floor_(double a) { return __builtin_floor(a); }
 TSAT_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 // v_rcp_f64 seed + two Newton steps
@@ -185,6 +190,8 @@ TSAT_DEV real sel7(const real a[7], int i) {
   for (int m = 1; m < 7; ++m) v = (i == m) ? a[m] : v;
   return v;
 }
+
+template <typename real> TSAT_DEV real inf_() { return (real)__builtin_huge_val(); }
 
 // wave collectives through LDS scratch; identical butterfly order in the GPU and emulated builds
 template <typename real>
@@ -291,7 +298,7 @@ struct StageBase {
   real w[3], qh[4], rn, c[3], BB[3], Jw[3];
 };
 
-template <typename real>
+template <typename real, int DIAGJ>
 TSAT_DEV void dyn_h(const Traj<real>& tr, const real x[7], const real us[3], const real b[3], real k[7],
                     StageBase<real>& sb) {
   const real w0 = x[0], w1 = x[1], w2 = x[2];
@@ -315,15 +322,16 @@ TSAT_DEV void dyn_h(const Traj<real>& tr, const real x[7], const real us[3], con
   const real t1 = us[2] * B0 - us[0] * B2;
   const real t2 = us[0] * B1 - us[1] * B0;
   // wdot = inv(J) (tau_c - w x Jw)  (:41)
-  const real Jw0 = tr.J[0] * w0 + tr.J[1] * w1 + tr.J[2] * w2;
-  const real Jw1 = tr.J[3] * w0 + tr.J[4] * w1 + tr.J[5] * w2;
-  const real Jw2 = tr.J[6] * w0 + tr.J[7] * w1 + tr.J[8] * w2;
+  // every inertia preset of the reference is diagonal (src/input_parameters.jl:29-51): DIAGJ drops the zero terms
+  const real Jw0 = DIAGJ ? tr.J[0] * w0 : tr.J[0] * w0 + tr.J[1] * w1 + tr.J[2] * w2;
+  const real Jw1 = DIAGJ ? tr.J[4] * w1 : tr.J[3] * w0 + tr.J[4] * w1 + tr.J[5] * w2;
+  const real Jw2 = DIAGJ ? tr.J[8] * w2 : tr.J[6] * w0 + tr.J[7] * w1 + tr.J[8] * w2;
   const real r0 = t0 - (w1 * Jw2 - w2 * Jw1);
   const real r1 = t1 - (w2 * Jw0 - w0 * Jw2);
   const real r2 = t2 - (w0 * Jw1 - w1 * Jw0);
-  k[0] = tr.hJi[0] * r0 + tr.hJi[1] * r1 + tr.hJi[2] * r2;
-  k[1] = tr.hJi[3] * r0 + tr.hJi[4] * r1 + tr.hJi[5] * r2;
-  k[2] = tr.hJi[6] * r0 + tr.hJi[7] * r1 + tr.hJi[8] * r2;
+  k[0] = DIAGJ ? tr.hJi[0] * r0 : tr.hJi[0] * r0 + tr.hJi[1] * r1 + tr.hJi[2] * r2;
+  k[1] = DIAGJ ? tr.hJi[4] * r1 : tr.hJi[3] * r0 + tr.hJi[4] * r1 + tr.hJi[5] * r2;
+  k[2] = DIAGJ ? tr.hJi[8] * r2 : tr.hJi[6] * r0 + tr.hJi[7] * r1 + tr.hJi[8] * r2;
   sb.w[0] = w0; sb.w[1] = w1; sb.w[2] = w2;
   sb.qh[0] = q0; sb.qh[1] = q1; sb.qh[2] = q2; sb.qh[3] = q3;
   sb.rn = rn;
@@ -334,7 +342,7 @@ TSAT_DEV void dyn_h(const Traj<real>& tr, const real x[7], const real us[3], con
 
 // directional derivative of h*f at a stage (applied to a tangent instead of forming F):
 // dx = [dw; dq] tangent of the stage state, dus = u_scale * du.
-template <typename real>
+template <typename real, int DIAGJ>
 TSAT_DEV void dyn_h_jvp(const Traj<real>& tr, const StageBase<real>& sb, const real us[3], const real b[3],
                         const real dx[7], const real dus[3], real dk[7]) {
   const real dw0 = dx[0], dw1 = dx[1], dw2 = dx[2];
@@ -362,61 +370,61 @@ TSAT_DEV void dyn_h_jvp(const Traj<real>& tr, const StageBase<real>& sb, const r
   const real t1 = (dus[2] * sb.BB[0] - dus[0] * sb.BB[2]) + (us[2] * dB0 - us[0] * dB2);
   const real t2 = (dus[0] * sb.BB[1] - dus[1] * sb.BB[0]) + (us[0] * dB1 - us[1] * dB0);
   // d(w x Jw) = dw x Jw + w x J dw
-  const real dJ0 = tr.J[0] * dw0 + tr.J[1] * dw1 + tr.J[2] * dw2;
-  const real dJ1 = tr.J[3] * dw0 + tr.J[4] * dw1 + tr.J[5] * dw2;
-  const real dJ2 = tr.J[6] * dw0 + tr.J[7] * dw1 + tr.J[8] * dw2;
+  const real dJ0 = DIAGJ ? tr.J[0] * dw0 : tr.J[0] * dw0 + tr.J[1] * dw1 + tr.J[2] * dw2;
+  const real dJ1 = DIAGJ ? tr.J[4] * dw1 : tr.J[3] * dw0 + tr.J[4] * dw1 + tr.J[5] * dw2;
+  const real dJ2 = DIAGJ ? tr.J[8] * dw2 : tr.J[6] * dw0 + tr.J[7] * dw1 + tr.J[8] * dw2;
   const real r0 = t0 - ((dw1 * sb.Jw[2] - dw2 * sb.Jw[1]) + (w1 * dJ2 - w2 * dJ1));
   const real r1 = t1 - ((dw2 * sb.Jw[0] - dw0 * sb.Jw[2]) + (w2 * dJ0 - w0 * dJ2));
   const real r2 = t2 - ((dw0 * sb.Jw[1] - dw1 * sb.Jw[0]) + (w0 * dJ1 - w1 * dJ0));
-  dk[0] = tr.hJi[0] * r0 + tr.hJi[1] * r1 + tr.hJi[2] * r2;
-  dk[1] = tr.hJi[3] * r0 + tr.hJi[4] * r1 + tr.hJi[5] * r2;
-  dk[2] = tr.hJi[6] * r0 + tr.hJi[7] * r1 + tr.hJi[8] * r2;
+  dk[0] = DIAGJ ? tr.hJi[0] * r0 : tr.hJi[0] * r0 + tr.hJi[1] * r1 + tr.hJi[2] * r2;
+  dk[1] = DIAGJ ? tr.hJi[4] * r1 : tr.hJi[3] * r0 + tr.hJi[4] * r1 + tr.hJi[5] * r2;
+  dk[2] = DIAGJ ? tr.hJi[8] * r2 : tr.hJi[6] * r0 + tr.hJi[7] * r1 + tr.hJi[8] * r2;
 }
 
 // one RK step (rk3: src/attitude_controller.jl:178-187; rk4: :122-132); b0/b1/b2 = rows at tau, tau+dtau/2, tau+dtau
-template <typename real, int INTEG>
+template <typename real, int INTEG, int DIAGJ>
 TSAT_DEV void rk_step(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3], const real b1[3],
                       const real b2[3], real xn[7]) {
   const real us[3] = {u[0] * tr.us, u[1] * tr.us, u[2] * tr.us};
   real k1[7], k2[7], k3[7], t[7];
   StageBase<real> sb;
-  dyn_h(tr, x, us, b0, k1, sb);
+  dyn_h<real, DIAGJ>(tr, x, us, b0, k1, sb);
   for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k1[i];
-  dyn_h(tr, t, us, b1, k2, sb);
+  dyn_h<real, DIAGJ>(tr, t, us, b1, k2, sb);
   if (INTEG == 3) {
     for (int i = 0; i < 7; ++i) t[i] = x[i] - k1[i] + 2 * k2[i];
-    dyn_h(tr, t, us, b2, k3, sb);
+    dyn_h<real, DIAGJ>(tr, t, us, b2, k3, sb);
     for (int i = 0; i < 7; ++i) xn[i] = x[i] + (k1[i] + 4 * k2[i] + k3[i]) * (real)(1.0 / 6.0);
   } else {
     real k4[7];
     for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k2[i];
-    dyn_h(tr, t, us, b1, k3, sb);
+    dyn_h<real, DIAGJ>(tr, t, us, b1, k3, sb);
     for (int i = 0; i < 7; ++i) t[i] = x[i] + k3[i];
-    dyn_h(tr, t, us, b2, k4, sb);
+    dyn_h<real, DIAGJ>(tr, t, us, b2, k4, sb);
     for (int i = 0; i < 7; ++i) xn[i] = x[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) * (real)(1.0 / 6.0);
   }
 }
 
 // discrete Jacobians of one RK step, column by column, written to LDS record `F` (column stride 8).
 // Equivalent of ForwardDiff.jacobian! over the discretised dynamics (src/attitude_controller.jl:95-119).
-template <typename real, int INTEG>
+template <typename real, int INTEG, int DIAGJ>
 TSAT_DEV void rk_jacobian(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3],
                           const real b1[3], const real b2[3], real* F) {
   const real us[3] = {u[0] * tr.us, u[1] * tr.us, u[2] * tr.us};
   real k1[7], k2[7], k3[7], t[7];
   StageBase<real> s1, s2, s3, s4;
-  dyn_h(tr, x, us, b0, k1, s1);
+  dyn_h<real, DIAGJ>(tr, x, us, b0, k1, s1);
   for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k1[i];
-  dyn_h(tr, t, us, b1, k2, s2);
+  dyn_h<real, DIAGJ>(tr, t, us, b1, k2, s2);
   if (INTEG == 3) {
     for (int i = 0; i < 7; ++i) t[i] = x[i] - k1[i] + 2 * k2[i];
-    dyn_h(tr, t, us, b2, k3, s3);
+    dyn_h<real, DIAGJ>(tr, t, us, b2, k3, s3);
   } else {
     for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k2[i];
-    dyn_h(tr, t, us, b1, k3, s3);
+    dyn_h<real, DIAGJ>(tr, t, us, b1, k3, s3);
     for (int i = 0; i < 7; ++i) t[i] = x[i] + k3[i];
     real k4[7];
-    dyn_h(tr, t, us, b2, k4, s4);
+    dyn_h<real, DIAGJ>(tr, t, us, b2, k4, s4);
   }
 #ifndef TSAT_EMU
 #pragma unroll 1
@@ -426,20 +434,20 @@ TSAT_DEV void rk_jacobian(const Traj<real>& tr, const real x[7], const real u[3]
     for (int i = 0; i < 7; ++i) ex[i] = (i == c) ? (real)1 : (real)0;
     for (int a = 0; a < 3; ++a) du[a] = (c == 7 + a) ? tr.us : (real)0;
     real v1[7], v2[7], v3[7], arg[7];
-    dyn_h_jvp(tr, s1, us, b0, ex, du, v1);
+    dyn_h_jvp<real, DIAGJ>(tr, s1, us, b0, ex, du, v1);
     for (int i = 0; i < 7; ++i) arg[i] = ex[i] + (real)0.5 * v1[i];
-    dyn_h_jvp(tr, s2, us, b1, arg, du, v2);
+    dyn_h_jvp<real, DIAGJ>(tr, s2, us, b1, arg, du, v2);
     if (INTEG == 3) {
       for (int i = 0; i < 7; ++i) arg[i] = ex[i] - v1[i] + 2 * v2[i];
-      dyn_h_jvp(tr, s3, us, b2, arg, du, v3);
-      for (int i = 0; i < 7; ++i) F[c * 8 + i] = ex[i] + (v1[i] + 4 * v2[i] + v3[i]) * (real)(1.0 / 6.0);
+      dyn_h_jvp<real, DIAGJ>(tr, s3, us, b2, arg, du, v3);
+      for (int i = 0; i < 7; ++i) F[c * FS + i] = ex[i] + (v1[i] + 4 * v2[i] + v3[i]) * (real)(1.0 / 6.0);
     } else {
       real v4[7];
       for (int i = 0; i < 7; ++i) arg[i] = ex[i] + (real)0.5 * v2[i];
-      dyn_h_jvp(tr, s3, us, b1, arg, du, v3);
+      dyn_h_jvp<real, DIAGJ>(tr, s3, us, b1, arg, du, v3);
       for (int i = 0; i < 7; ++i) arg[i] = ex[i] + v3[i];
-      dyn_h_jvp(tr, s4, us, b2, arg, du, v4);
-      for (int i = 0; i < 7; ++i) F[c * 8 + i] = ex[i] + (v1[i] + 2 * v2[i] + 2 * v3[i] + v4[i]) * (real)(1.0 / 6.0);
+      dyn_h_jvp<real, DIAGJ>(tr, s4, us, b2, arg, du, v4);
+      for (int i = 0; i < 7; ++i) F[c * FS + i] = ex[i] + (v1[i] + 2 * v2[i] + 2 * v3[i] + v4[i]) * (real)(1.0 / 6.0);
     }
   }
 }
@@ -480,6 +488,32 @@ TSAT_DEV real term_cost(const Traj<real>& tr, const real x[7], const real nu[7],
   return l;
 }
 
+// The same AL stage cost with the per-knot work of the sequential sweep trimmed: half-weights are precomputed and
+// the activity test `c > 0 || lambda > 0` becomes one max against a per-row gate staged with the multipliers:
+// gate = -inf when lambda > 0 (row always active: t = c) and 0 otherwise (t = max(c, 0)), so I_mu c^2 = mu t^2.
+template <typename real>
+struct HalfWeights { real hQd[7], hRd[3], hmu; };
+template <typename real>
+TSAT_DEV real stage_cost_gated(const Traj<real>& tr, const HalfWeights<real>& hw, const real x[7], const real u[3],
+                               const real* lam, const real* gate) {
+  real l = 0;
+  for (int i = 0; i < 7; ++i) { const real e = x[i] - tr.xf[i]; l += hw.hQd[i] * (e * e); }
+  for (int a = 0; a < 3; ++a) l += hw.hRd[a] * (u[a] * u[a]);
+  for (int a = 0; a < 3; ++a) {
+    const real c = u[a] - tr.uhi[a];
+    const real t = fmax_(c, gate[a]);
+    l += lam[a] * c;
+    l += hw.hmu * (t * t);
+  }
+  for (int a = 0; a < 3; ++a) {
+    const real c = tr.ulo[a] - u[a];
+    const real t = fmax_(c, gate[3 + a]);
+    l += lam[3 + a] * c;
+    l += hw.hmu * (t * t);
+  }
+  return l;
+}
+
 // cooperative copy of `n` reals (n even, 16-byte aligned both sides) global -> LDS
 template <typename real>
 TSAT_DEV void coop_load(real* dst, const TSAT_GLOBAL real* src, int n) {
@@ -497,8 +531,8 @@ template <typename real> struct BwdOut { real dV1, dV2; int pd_ok; };
 // forward sweep: all line-search candidates at once (lane j: alpha = 2^-j). Returns this lane's AL cost and
 // whether its rollout stayed within max_state. Candidate knot records go to CAND[lane].
 // --------------------------------------------------------------------------------------------------
-template <typename real, int INTEG>
-TSAT_PHASE FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_cand, real mu,
+template <typename real, int INTEG, int DIAGJ>
+TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_cand, real mu,
                                       int term_mask, real max_state) {
   real* lds = lds_base<real>();
   const Traj<real> tr = load_traj<real>(N, n_tab, p.bt);
@@ -516,11 +550,20 @@ TSAT_PHASE FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int close
   real* XUc = lds + L_XUC;
   real* LMc = lds + L_LMC;
   real* BSc = lds + L_BSC;
+  real* GTc = lds + L_GTC;
+  HalfWeights<real> hw;
+  for (int i = 0; i < 7; ++i) hw.hQd[i] = (real)0.5 * tr.Qd[i];
+  for (int i = 0; i < 3; ++i) hw.hRd[i] = (real)0.5 * tr.Rd[i];
+  hw.hmu = (real)0.5 * mu;
   for (int k0 = 0; k0 < N - 1; k0 += CK) {
     const int nk = (N - 1 - k0 < CK) ? (N - 1 - k0) : CK;
     if (closed) coop_load(KDc, KDg + (size_t)k0 * KDW, nk * KDW);
     coop_load(XUc, XUg + (size_t)k0 * XUW, nk * XUW);
-    coop_load(LMc, LMg + (size_t)k0 * LMW, nk * LMW);
+    for (int e = lane; e < nk * LMW; e += WAVE) {
+      const real l = LMg[(size_t)k0 * LMW + e];
+      LMc[e] = l;
+      GTc[e] = (l > 0) ? -inf_<real>() : (real)0;
+    }
     for (int e = lane; e < nk * 3; e += WAVE) {
       const int kk = e / 3, st = e - 3 * kk;
       const int row = brow_index(tr, k0 + kk, 0.5 * (double)st);
@@ -545,7 +588,7 @@ TSAT_PHASE FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int close
       }
       for (int i = 0; i < 7; ++i) amax = fmax_(amax, fabs_(x[i]));
       for (int c = 0; c < 3; ++c) amax = fmax_(amax, fabs_(u[c]));
-      J += stage_cost(tr, x, u, LMc + kk * LMW, mu, true);
+      J += stage_cost_gated(tr, hw, x, u, LMc + kk * LMW, GTc + kk * LMW);
       if (lane < n_cand) {
         TSAT_GLOBAL real* cr = Cg + (size_t)(k0 + kk) * XUW;
         for (int i = 0; i < 7; ++i) cr[i] = x[i];
@@ -553,7 +596,7 @@ TSAT_PHASE FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int close
       }
       real xn[7];
       const real* bs = BSc + kk * BSW;
-      rk_step<real, INTEG>(tr, x, u, bs, bs + 3, bs + 6, xn);
+      rk_step<real, INTEG, DIAGJ>(tr, x, u, bs, bs + 3, bs + 6, xn);
       for (int i = 0; i < 7; ++i) x[i] = xn[i];
     }
     TSAT_SYNC_LDS();  // the next chunk's staging writes must not overtake this chunk's LDS reads
@@ -576,7 +619,7 @@ TSAT_PHASE FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int close
 // --------------------------------------------------------------------------------------------------
 // Jacobian lanes of one backward chunk: lane l linearises knot k0 + l and leaves [A|B], lx, lu, luu in LDS
 // --------------------------------------------------------------------------------------------------
-template <typename real, int INTEG>
+template <typename real, int INTEG, int DIAGJ>
 TSAT_PHASE void jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, real mu) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
@@ -593,7 +636,7 @@ TSAT_PHASE void jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, 
     const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
     for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
     real* rc = lds + L_REC + lane * RECS;
-    rk_jacobian<real, INTEG>(tr, x, u, b0, b1, b2, rc + R_F);
+    rk_jacobian<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, rc + R_F);
     for (int i = 0; i < 7; ++i) rc[R_LX + i] = tr.Qd[i] * (x[i] - tr.xf[i]);
     for (int c = 0; c < 3; ++c) {
       real lu = tr.Rd[c] * u[c], luu = tr.Rd[c];
@@ -621,7 +664,7 @@ TSAT_DEV void pair28(int L, int& i, int& j) {  // L in [0,28) -> (i<=j) of a 7x7
   j = r + (L - base);
 }
 
-template <typename real, int INTEG>
+template <typename real, int INTEG, int DIAGJ>
 TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu, real rho, int term_mask) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
@@ -632,7 +675,7 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
   // step 1: W~[r1][c1] = sum_m S~[r1][m] F[m][c1], plus columns 8,9 on the lanes with c1 < 2
   const int r1 = lane & 7, c1 = lane >> 3;
   const int s1_st = L_ST + r1 * 9;
-  const int s1_fa = c1 * 8, s1_fb = (8 + (c1 & 1)) * 8;           // relative to the knot record
+  const int s1_fa = c1 * FS, s1_fb = (8 + (c1 & 1)) * FS;         // relative to the knot record
   const int s1_oa = L_WT + c1 * 9 + r1;
   const int s1_ob = (c1 < 2) ? (L_WT + (8 + c1) * 9 + r1) : L_SINK;
   // step 2: acc = diag + init + dot(F[:,colA], opB[0..6]) -> lds[o1], lds[o2]
@@ -640,20 +683,20 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
   real s2_diag = 0;
   if (lane < 28) {                                   // Qxx(i,j), i <= j  = Q + A'SA
     int i, j; pair28(lane, i, j);
-    s2_fa = i * 8; s2_b = L_WT + j * 9; s2_o1 = L_HXX + i * 7 + j; s2_o2 = L_HXX + j * 7 + i;
+    s2_fa = i * FS; s2_b = L_WT + j * 9; s2_o1 = L_HXX + i * 7 + j; s2_o2 = L_HXX + j * 7 + i;
     if (i == j) s2_diag = lds[L_TR + P_QD + i];
   } else if (lane < 49) {                            // Qux(a,j) = B'SA
     const int aa = (lane - 28) / 7, j = (lane - 28) % 7;
-    s2_fa = (7 + aa) * 8; s2_b = L_WT + j * 9; s2_o1 = s2_o2 = L_HUX + aa * 8 + j;
+    s2_fa = (7 + aa) * FS; s2_b = L_WT + j * 9; s2_o1 = s2_o2 = L_HUX + aa * 8 + j;
   } else if (lane < 55) {                            // Quu(a,b), a <= b = luu + B'SB
     const int L = lane - 49;                         // (0,0)(0,1)(0,2)(1,1)(1,2)(2,2)
     const int aa = (L < 3) ? 0 : (L < 5 ? 1 : 2);
     const int bb = (L < 3) ? L : (L < 5 ? L - 2 : 2);
-    s2_fa = (7 + aa) * 8; s2_b = L_WT + (7 + bb) * 9; s2_o1 = L_HUU + aa * 3 + bb; s2_o2 = L_HUU + bb * 3 + aa;
+    s2_fa = (7 + aa) * FS; s2_b = L_WT + (7 + bb) * 9; s2_o1 = L_HUU + aa * 3 + bb; s2_o2 = L_HUU + bb * 3 + aa;
     if (aa == bb) s2_init = R_LUU + aa;
   } else if (lane < 58) {                            // Qu(a) = lu + B's'  -> Hux[a][7]
     const int aa = lane - 55;
-    s2_fa = (7 + aa) * 8; s2_b = L_ST + 7 * 9; s2_init = R_LU + aa; s2_o1 = s2_o2 = L_HUX + aa * 8 + 7;
+    s2_fa = (7 + aa) * FS; s2_b = L_ST + 7 * 9; s2_init = R_LU + aa; s2_o1 = s2_o2 = L_HUX + aa * 8 + 7;
   }
   // step 3: K[a3][j3] (j3 == 7: d[a3]) on the lanes with a3 < 3
   const int a3 = lane >> 3, j3 = lane & 7;
@@ -697,11 +740,10 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
     const int k0 = ch * CHB;
     const int nk = (N - 1 - k0 < CHB) ? (N - 1 - k0) : CHB;
     const unsigned long long t_j0 = tick_();
-    jacobian_chunk<real, INTEG>(p, N, n_tab, k0, nk, mu);
+    jacobian_chunk<real, INTEG, DIAGJ>(p, N, n_tab, k0, nk, mu);
     TSAT_SYNC();
     const unsigned long long t_j1 = tick_();
     // ---- Riccati recursion over the chunk, last knot first -----------------------------------
-    int l_done = nk;  // knots [l_done, nk) of the chunk have their K,d in the LDS buffer
     for (int l = nk - 1; l >= 0; --l) {
       const int rcb = L_REC + l * RECS;
       // step 1: W~ = [S; s'] [A|B]   (8 x 10)
@@ -746,10 +788,9 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
         const real Qi2 = ((a3c == 0) ? c02 : (a3c == 1 ? c12 : c22)) * nid;
         const real v = Qi0 * h0 + Qi1 * h1 + Qi2 * h2;
         lds[s3_o] = v;
-        lds[(s3_slot >= 0) ? (L_KDB + l * KDW + s3_slot) : L_SINK] = v;
+        if (s3_slot >= 0) KDg[(size_t)(k0 + l) * KDW + s3_slot] = v;   // stays in flight: no vmcnt wait in this loop
       }
       if (!pd_ok) break;  // wave-uniform: every lane read the same Huu
-      l_done = l;
       TSAT_SYNC_LDS();
       // step 4: cost-to-go. With K = -Quu_reg^-1 Qux: Quu K + Qux = -rho K, so
       //   Sxx = Qxx + sym(Qux'K) - rho K'K ;  Sx = Qx + sym(Qux'd, Qu'K) - rho K'd   (Appendix A, compacted;
@@ -775,14 +816,6 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
         lds[s4_o2] = acc;
       }
       TSAT_SYNC_LDS();
-    }
-    // flush the chunk's K,d records (contiguous in HBM) with coalesced 16-byte stores
-    {
-      struct alignas(2 * sizeof(real)) R2 { real a, b; };
-      const R2* src = reinterpret_cast<const R2*>(lds + L_KDB + l_done * KDW);
-      TSAT_GLOBAL R2* dst = reinterpret_cast<TSAT_GLOBAL R2*>(KDg + (size_t)(k0 + l_done) * KDW);
-      const int n2 = (nk - l_done) * (KDW / 2);
-      for (int i = lane; i < n2; i += WAVE) dst[i] = src[i];
     }
     TSAT_SYNC();
 #ifdef TSAT_PROFILE
@@ -886,7 +919,7 @@ TSAT_PHASE real adopt_and_gradient(TPtrs<real> p, int N, int jw) {
 // --------------------------------------------------------------------------------------------------
 // the whole AL-iLQR solve of one trajectory by one wavefront
 // --------------------------------------------------------------------------------------------------
-template <typename real, int INTEG>
+template <typename real, int INTEG, int DIAGJ>
 TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
@@ -922,7 +955,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   unsigned long long pc_fwd = 0, pc_par = 0;
 
   // open-loop rollout of U0
-  FwdOut<real> f0 = forward_sweep<real, INTEG>(p, N, n_tab, 0, 1, mu, tmask, max_state);
+  FwdOut<real> f0 = forward_sweep<real, INTEG, DIAGJ>(p, N, n_tab, 0, 1, mu, tmask, max_state);
   n_forward++;
   const real J0 = wave_bcast(f0.J, 0, lds + L_RED);
   const int ok0 = wave_first<real>(!f0.ok, lds + L_RED) > 0;  // lane 0 ok?
@@ -941,7 +974,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
         BwdOut<real> bw;
         for (;;) {
           n_backward++;
-          bw = backward_sweep<real, INTEG>(p, N, n_tab, mu, rho, tmask);
+          bw = backward_sweep<real, INTEG, DIAGJ>(p, N, n_tab, mu, rho, tmask);
           if (bw.pd_ok) break;
           bp_restarts++;
           drho = (drho * (real)o.reg_scale > (real)o.reg_scale) ? drho * (real)o.reg_scale : (real)o.reg_scale;
@@ -960,7 +993,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
         TSAT_SYNC();
         // all backtracking trials in one sweep
         const unsigned long long t_f0 = tick_();
-        const FwdOut<real> fw = forward_sweep<real, INTEG>(p, N, n_tab, 1, o.max_linesearch, mu, tmask, max_state);
+        const FwdOut<real> fw = forward_sweep<real, INTEG, DIAGJ>(p, N, n_tab, 1, o.max_linesearch, mu, tmask, max_state);
         const unsigned long long t_f1 = tick_();
         pc_fwd += t_f1 - t_f0;
         n_forward++;

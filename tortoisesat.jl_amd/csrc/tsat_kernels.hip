@@ -15,11 +15,11 @@ using namespace tsat;
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-template <typename real, int INTEG>
+template <typename real, int INTEG, int DIAGJ>
 __global__ __launch_bounds__(64) void tsat_solve_kernel(KArgs<real> a) {
   const int traj = blockIdx.x;
   if (traj >= a.T) return;
-  solve_trajectory<real, INTEG>(a, traj);
+  solve_trajectory<real, INTEG, DIAGJ>(a, traj);
 }
 
 template <typename real>
@@ -41,6 +41,7 @@ struct tsat_handle {
   int64_t T = 0, n_btab = 0;
   int N = 0, n_tab = 0, max_ls = 0, trace_rows = 0;
   bool uploaded = false, solved = false;
+  bool diag_inertia = false;  // every uploaded inertia tensor is diagonal -> DIAGJ kernel variant
   double *P = nullptr, *BT = nullptr, *U0 = nullptr, *XU = nullptr, *KD = nullptr, *LAM = nullptr, *CAND = nullptr;
   int* bidx = nullptr;
   tsat_stats* stats = nullptr;
@@ -191,6 +192,11 @@ int tsat_batch_upload(tsat_handle* h, const double* x0, const double* xf, const 
   }
   for (int64_t t = 0; t < T; ++t)
     if (!(dt[t] > 0.0)) return fail(h, -1, "dt must be positive");
+  bool diag = true;
+  for (int64_t t = 0; t < T && diag; ++t)
+    for (int i = 0; i < 9; ++i)
+      if (i % 4 != 0 && Jmat[9 * t + i] != 0.0) { diag = false; break; }
+  h->diag_inertia = diag;
   std::vector<double> P((size_t)T * PSTRIDE), BT((size_t)h->n_btab * h->n_tab * 4);
   pack_params<double>(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, P.data());
   pack_btab<double>(h->n_btab, h->n_tab, Btab, BT.data());
@@ -215,7 +221,9 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
   a.XU = h->XU; a.KD = h->KD; a.LAM = h->LAM; a.CAND = h->CAND;
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
   const size_t lds = (size_t)LDS_REALS * sizeof(double);
-  auto kern = (o->integrator == 3) ? tsat_solve_kernel<double, 3> : tsat_solve_kernel<double, 4>;
+  auto kern = (o->integrator == 3)
+                  ? (h->diag_inertia ? tsat_solve_kernel<double, 3, 1> : tsat_solve_kernel<double, 3, 0>)
+                  : (h->diag_inertia ? tsat_solve_kernel<double, 4, 1> : tsat_solve_kernel<double, 4, 0>);
   TSAT_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (h->trace) TSAT_HIP(h, hipMemsetAsync(h->trace, 0, (size_t)h->T * h->trace_rows * 8 * sizeof(double), h->stream));
   TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
