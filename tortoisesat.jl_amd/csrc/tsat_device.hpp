@@ -29,6 +29,7 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 #define TSAT_LANE() (tsat_emu::lane())
 #define TSAT_SYNC() (tsat_emu::sync())
 #define TSAT_SYNC_LDS() (tsat_emu::sync())
+#define TSAT_SCHED_FENCE() ((void)0)
 #else
 #define TSAT_DEV __device__ __forceinline__
 // Each sweep is its own (non-inlined) function: the register allocator then works on one hot loop at a time
@@ -57,9 +58,7 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
     __builtin_amdgcn_wave_barrier();                          \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
   } while (0)
-// the wavefront's LDS block. Declared at namespace scope so that every phase function addresses it as LDS
-// (address space 3) instead of through a generic pointer argument, which would turn ds_* into flat_* accesses.
-extern __shared__ __align__(16) unsigned char tsat_smem[];
+#define TSAT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 namespace tsat {
@@ -130,6 +129,14 @@ constexpr int L_FWD_END = L_GTC + CK * LMW;
 constexpr int L_BWD_END = L_REC + CHB * RECS;
 constexpr int LDS_REALS = (L_FWD_END > L_BWD_END ? L_FWD_END : L_BWD_END);
 
+// The wavefront's LDS block: a STATIC module-level __shared__ array. Declared at namespace scope so that every phase
+// function addresses it as LDS (address space 3) at a link-time constant address — a generic pointer argument would
+// turn ds_* into flat_* accesses, and a dynamic (extern) array makes every non-kernel function fetch its base address
+// with an s_load inside the hot loops.
+constexpr int LDS_BYTES = LDS_REALS * 8;
+#ifndef TSAT_EMU
+__shared__ __align__(16) unsigned char tsat_smem[LDS_BYTES];
+#endif
 template <typename real>
 TSAT_DEV real* lds_base() {
 #ifdef TSAT_EMU
@@ -664,12 +671,12 @@ TSAT_DEV void pair28(int L, int& i, int& j) {  // L in [0,28) -> (i<=j) of a 7x7
   j = r + (L - base);
 }
 
-template <typename real, int INTEG, int DIAGJ>
-TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu, real rho, int term_mask) {
+// Riccati recursion over one chunk whose Jacobian records are in LDS (last knot first). Its own function, so that
+// the lane-role tables live in registers for exactly this loop (nothing survives the call to jacobian_chunk).
+template <typename real>
+TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, real rho, real dV1, real dV2) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
-  TSAT_GLOBAL real* KDg = p.KD;
-
   // ---- lane roles. Every step is branch-free: each lane owns LDS offsets for its operands and outputs; lanes
   // without a role in a step compute on harmless operands and write to L_SINK. -----------------------------
   // step 1: W~[r1][c1] = sum_m S~[r1][m] F[m][c1], plus columns 8,9 on the lanes with c1 < 2
@@ -714,8 +721,104 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
   }
   const int s4_hi = L_HUX + i4, s4_hj = L_HUX + j4, s4_ki = L_KD + i4, s4_kj = L_KD + j4;
 
+  bool pd_ok = true;
+  for (int l = nk - 1; l >= 0; --l) {
+    const int rcb = L_REC + l * RECS;
+    // step 1: W~ = [S; s'] [A|B]   (8 x 10)
+    {
+      real sv[7], fa[7], fb[7];
+      for (int m = 0; m < 7; ++m) { sv[m] = lds[s1_st + m]; fa[m] = lds[rcb + s1_fa + m]; fb[m] = lds[rcb + s1_fb + m]; }
+      TSAT_SCHED_FENCE();   // all 21 reads in flight before the first FMA: one LDS latency per step, not seven
+      real acc = 0, acc2 = 0;
+      for (int m = 0; m < 7; ++m) { acc += sv[m] * fa[m]; acc2 += sv[m] * fb[m]; }
+      lds[s1_oa] = acc;
+      lds[s1_ob] = acc2;
+    }
+    TSAT_SYNC_LDS();
+    // step 2: Qxx = Q + A'SA, Qux = B'SA, Quu = luu + B'SB, Qu = lu + B's
+    {
+      real fa[7], wb[7];
+      const real ini = lds[(s2_init >= 0) ? (rcb + s2_init) : L_ZERO];
+      for (int m = 0; m < 7; ++m) { fa[m] = lds[rcb + s2_fa + m]; wb[m] = lds[s2_b + m]; }
+      TSAT_SCHED_FENCE();
+      real acc = s2_diag + ini;
+      for (int m = 0; m < 7; ++m) acc += fa[m] * wb[m];
+      lds[s2_o1] = acc;
+      lds[s2_o2] = acc;
+    }
+    TSAT_SYNC_LDS();
+    // step 3: regularise, PD test (Sylvester), adjugate inverse, K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu
+    {
+      const real* Huu = lds + L_HUU;
+      const real* Hux = lds + L_HUX;
+      const real q00 = Huu[0] + rho, q11 = Huu[4] + rho, q22 = Huu[8] + rho;
+      const real q10 = Huu[1], q20 = Huu[2], q21 = Huu[5];
+      const real h0 = Hux[0 * 8 + j3], h1 = Hux[1 * 8 + j3], h2 = Hux[2 * 8 + j3];
+      TSAT_SCHED_FENCE();
+      const real c00 = q11 * q22 - q21 * q21;
+      const real c01 = q20 * q21 - q10 * q22;
+      const real c02 = q10 * q21 - q20 * q11;
+      const real c11 = q00 * q22 - q20 * q20;
+      const real c12 = q10 * q20 - q00 * q21;
+      const real c22 = q00 * q11 - q10 * q10;
+      const real det = q00 * c00 + q10 * c01 + q20 * c02;
+      if (!(q00 > 0 && c22 > 0 && det > 0)) pd_ok = false;
+      const real nid = -rcp_(det);
+      // row a3 of the inverse (negated)
+      const real Qi0 = ((a3c == 0) ? c00 : (a3c == 1 ? c01 : c02)) * nid;
+      const real Qi1 = ((a3c == 0) ? c01 : (a3c == 1 ? c11 : c12)) * nid;
+      const real Qi2 = ((a3c == 0) ? c02 : (a3c == 1 ? c12 : c22)) * nid;
+      const real v = Qi0 * h0 + Qi1 * h1 + Qi2 * h2;
+      lds[s3_o] = v;
+      if (s3_slot >= 0) KDg[(size_t)(k0 + l) * KDW + s3_slot] = v;   // stays in flight: no vmcnt wait in this loop
+    }
+    if (!pd_ok) break;  // wave-uniform: every lane read the same Huu
+    TSAT_SYNC_LDS();
+    // step 4: cost-to-go. With K = -Quu_reg^-1 Qux: Quu K + Qux = -rho K, so
+    //   Sxx = Qxx + sym(Qux'K) - rho K'K ;  Sx = Qx + sym(Qux'd, Qu'K) - rho K'd   (Appendix A, compacted;
+    //   Qux'd = Qu'K in exact arithmetic, so the s-lanes run the very same formula with j = "column 7")
+    {
+      const real* Huu = lds + L_HUU;
+      const real d0 = lds[L_KD + 7], d1 = lds[L_KD + 15], d2 = lds[L_KD + 23];
+      const real qu0 = lds[L_HUX + 7], qu1 = lds[L_HUX + 15], qu2 = lds[L_HUX + 23];
+      real hu[9], hi[3], hj[3], ki[3], kj[3];
+      for (int c = 0; c < 9; ++c) hu[c] = Huu[c];
+      const real b1 = lds[(s4_b1rel >= 0) ? (rcb + s4_b1rel) : s4_b1], b2 = lds[s4_b2];
+      for (int c = 0; c < 3; ++c) {
+        hi[c] = lds[s4_hi + c * 8]; hj[c] = lds[s4_hj + c * 8]; ki[c] = lds[s4_ki + c * 8]; kj[c] = lds[s4_kj + c * 8];
+      }
+      TSAT_SCHED_FENCE();
+      dV1 += d0 * qu0 + d1 * qu1 + d2 * qu2;
+      const real t0 = hu[0] * d0 + hu[1] * d1 + hu[2] * d2;
+      const real t1 = hu[3] * d0 + hu[4] * d1 + hu[5] * d2;
+      const real t2 = hu[6] * d0 + hu[7] * d1 + hu[8] * d2;
+      dV2 += (real)0.5 * (d0 * t0 + d1 * t1 + d2 * t2);
+      real acc = b1 + b2;
+      real sy = 0, kk = 0;
+      for (int c = 0; c < 3; ++c) {
+        sy += hi[c] * kj[c] + hj[c] * ki[c];
+        kk += ki[c] * kj[c];
+      }
+      acc += (real)0.5 * sy - rho * kk;
+      lds[s4_o1] = acc;
+      lds[s4_o2] = acc;
+    }
+    TSAT_SYNC_LDS();
+  }
+  BwdOut<real> out;
+  out.dV1 = dV1;
+  out.dV2 = dV2;
+  out.pd_ok = pd_ok ? 1 : 0;
+  return out;
+}
+
+template <typename real, int INTEG, int DIAGJ>
+TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu, real rho, int term_mask) {
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE();
   // terminal cost-to-go: Sxx = Qf + mu*mask, Sx = Qf e + mask (nu + mu e)   (Appendix A backward)
   {
+    const int r1 = lane & 7, c1 = lane >> 3;
     const TSAT_GLOBAL real* xN = p.XU + (size_t)(N - 1) * XUW;
     if (c1 < 7) {
       real v = 0;
@@ -731,92 +834,18 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
     }
     if (lane == 0) { lds[L_ZERO] = 0; lds[L_SINK] = 0; }
   }
-  real dV1 = 0, dV2 = 0;
-  bool pd_ok = true;
+  BwdOut<real> acc;
+  acc.dV1 = 0; acc.dV2 = 0; acc.pd_ok = 1;
   TSAT_SYNC();
-
   const int nchunks = (N - 1 + CHB - 1) / CHB;
-  for (int ch = nchunks - 1; ch >= 0 && pd_ok; --ch) {
+  for (int ch = nchunks - 1; ch >= 0 && acc.pd_ok; --ch) {
     const int k0 = ch * CHB;
     const int nk = (N - 1 - k0 < CHB) ? (N - 1 - k0) : CHB;
     const unsigned long long t_j0 = tick_();
     jacobian_chunk<real, INTEG, DIAGJ>(p, N, n_tab, k0, nk, mu);
     TSAT_SYNC();
     const unsigned long long t_j1 = tick_();
-    // ---- Riccati recursion over the chunk, last knot first -----------------------------------
-    for (int l = nk - 1; l >= 0; --l) {
-      const int rcb = L_REC + l * RECS;
-      // step 1: W~ = [S; s'] [A|B]   (8 x 10)
-      {
-        real acc = 0, acc2 = 0;
-        for (int m = 0; m < 7; ++m) {
-          const real sv = lds[s1_st + m];
-          acc += sv * lds[rcb + s1_fa + m];
-          acc2 += sv * lds[rcb + s1_fb + m];
-        }
-        lds[s1_oa] = acc;
-        lds[s1_ob] = acc2;
-      }
-      TSAT_SYNC_LDS();
-      // step 2: Qxx = Q + A'SA, Qux = B'SA, Quu = luu + B'SB, Qu = lu + B's
-      {
-        real acc = s2_diag + lds[(s2_init >= 0) ? (rcb + s2_init) : L_ZERO];
-        for (int m = 0; m < 7; ++m) acc += lds[rcb + s2_fa + m] * lds[s2_b + m];
-        lds[s2_o1] = acc;
-        lds[s2_o2] = acc;
-      }
-      TSAT_SYNC_LDS();
-      // step 3: regularise, PD test (Sylvester), adjugate inverse, K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu
-      {
-        const real* Huu = lds + L_HUU;
-        const real* Hux = lds + L_HUX;
-        const real q00 = Huu[0] + rho, q11 = Huu[4] + rho, q22 = Huu[8] + rho;
-        const real q10 = Huu[1], q20 = Huu[2], q21 = Huu[5];
-        const real h0 = Hux[0 * 8 + j3], h1 = Hux[1 * 8 + j3], h2 = Hux[2 * 8 + j3];
-        const real c00 = q11 * q22 - q21 * q21;
-        const real c01 = q20 * q21 - q10 * q22;
-        const real c02 = q10 * q21 - q20 * q11;
-        const real c11 = q00 * q22 - q20 * q20;
-        const real c12 = q10 * q20 - q00 * q21;
-        const real c22 = q00 * q11 - q10 * q10;
-        const real det = q00 * c00 + q10 * c01 + q20 * c02;
-        if (!(q00 > 0 && c22 > 0 && det > 0)) pd_ok = false;
-        const real nid = -rcp_(det);
-        // row a3 of the inverse (negated)
-        const real Qi0 = ((a3c == 0) ? c00 : (a3c == 1 ? c01 : c02)) * nid;
-        const real Qi1 = ((a3c == 0) ? c01 : (a3c == 1 ? c11 : c12)) * nid;
-        const real Qi2 = ((a3c == 0) ? c02 : (a3c == 1 ? c12 : c22)) * nid;
-        const real v = Qi0 * h0 + Qi1 * h1 + Qi2 * h2;
-        lds[s3_o] = v;
-        if (s3_slot >= 0) KDg[(size_t)(k0 + l) * KDW + s3_slot] = v;   // stays in flight: no vmcnt wait in this loop
-      }
-      if (!pd_ok) break;  // wave-uniform: every lane read the same Huu
-      TSAT_SYNC_LDS();
-      // step 4: cost-to-go. With K = -Quu_reg^-1 Qux: Quu K + Qux = -rho K, so
-      //   Sxx = Qxx + sym(Qux'K) - rho K'K ;  Sx = Qx + sym(Qux'd, Qu'K) - rho K'd   (Appendix A, compacted;
-      //   Qux'd = Qu'K in exact arithmetic, so the s-lanes run the very same formula with j = "column 7")
-      {
-        const real* Huu = lds + L_HUU;
-        const real d0 = lds[L_KD + 7], d1 = lds[L_KD + 15], d2 = lds[L_KD + 23];
-        const real qu0 = lds[L_HUX + 7], qu1 = lds[L_HUX + 15], qu2 = lds[L_HUX + 23];
-        dV1 += d0 * qu0 + d1 * qu1 + d2 * qu2;
-        const real t0 = Huu[0] * d0 + Huu[1] * d1 + Huu[2] * d2;
-        const real t1 = Huu[3] * d0 + Huu[4] * d1 + Huu[5] * d2;
-        const real t2 = Huu[6] * d0 + Huu[7] * d1 + Huu[8] * d2;
-        dV2 += (real)0.5 * (d0 * t0 + d1 * t1 + d2 * t2);
-        real acc = lds[(s4_b1rel >= 0) ? (rcb + s4_b1rel) : s4_b1] + lds[s4_b2];
-        real sy = 0, kk = 0;
-        for (int c = 0; c < 3; ++c) {
-          const real hi = lds[s4_hi + c * 8], hj = lds[s4_hj + c * 8], ki = lds[s4_ki + c * 8], kj = lds[s4_kj + c * 8];
-          sy += hi * kj + hj * ki;
-          kk += ki * kj;
-        }
-        acc += (real)0.5 * sy - rho * kk;
-        lds[s4_o1] = acc;
-        lds[s4_o2] = acc;
-      }
-      TSAT_SYNC_LDS();
-    }
+    acc = riccati_chunk<real>(p.KD, k0, nk, rho, acc.dV1, acc.dV2);
     TSAT_SYNC();
 #ifdef TSAT_PROFILE
     if (lane == 0) {
@@ -827,11 +856,7 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
     (void)t_j0; (void)t_j1;
 #endif
   }
-  BwdOut<real> out;
-  out.dV1 = dV1;
-  out.dV2 = dV2;
-  out.pd_ok = pd_ok ? 1 : 0;
-  return out;
+  return acc;
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -220,14 +220,13 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
   a.P = h->P; a.BT = h->BT; a.bidx = h->bidx; a.U0 = h->U0;
   a.XU = h->XU; a.KD = h->KD; a.LAM = h->LAM; a.CAND = h->CAND;
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
-  const size_t lds = (size_t)LDS_REALS * sizeof(double);
+  // LDS is a static module-level array (tsat_device.hpp): nothing dynamic to request at launch
   auto kern = (o->integrator == 3)
                   ? (h->diag_inertia ? tsat_solve_kernel<double, 3, 1> : tsat_solve_kernel<double, 3, 0>)
                   : (h->diag_inertia ? tsat_solve_kernel<double, 4, 1> : tsat_solve_kernel<double, 4, 0>);
-  TSAT_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (h->trace) TSAT_HIP(h, hipMemsetAsync(h->trace, 0, (size_t)h->T * h->trace_rows * 8 * sizeof(double), h->stream));
   TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(kern, dim3((unsigned)h->T), dim3(64), lds, h->stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)h->T), dim3(64), 0, h->stream, a);
   TSAT_HIP(h, hipGetLastError());
   TSAT_HIP(h, hipEventRecord(h->ev1, h->stream));
   TSAT_HIP(h, hipStreamSynchronize(h->stream));
