@@ -45,8 +45,9 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
                                const double* dt, const double* Jmat, const double* Qd, const double* Qfd,
                                const double* Rd, const double* ulo, const double* uhi, const double* U0, double* X,
                                double* U, double* K, tsat_stats* stats, double* trace, int trace_rows) {
-  const int N = o->n_knots, n_tab = o->n_tab, max_ls = o->max_linesearch;
-  if (!check_options(*o, N, n_tab, max_ls).empty()) return -1;
+  const int N = o->n_knots, n_tab = o->n_tab;
+  if (!check_options(*o, N, n_tab, o->max_linesearch).empty()) return -1;
+  const int max_ls = o->max_linesearch < NSTORE ? o->max_linesearch : NSTORE;   // stored candidate slots
   std::vector<double> P((size_t)T * PSTRIDE), BT((size_t)n_btab * n_tab * 4);
   std::vector<int> bidx(T);
   pack_params<double>(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, P.data());

@@ -67,6 +67,10 @@ constexpr int WAVE = 64;
 constexpr int CK = 32;    // knots per forward-sweep LDS chunk
 constexpr int CHB = 56;   // knots per backward-sweep LDS chunk (Jacobian lanes); 4 waves x 40.6 KB fit one CU
 constexpr int PSTRIDE = 64;
+// line-search candidates whose rollouts are kept in HBM. On the reference Monte-Carlo workload the accepted step is
+// alpha = 2^-j with j <= 5 in 99.9 % of the iterations; a deeper winner is re-rolled on its own (rare second sweep)
+// instead of every sweep streaming all max_linesearch candidate trajectories to memory.
+constexpr int NSTORE = 6;
 // per-trajectory parameter record (reals)
 enum { P_X0 = 0, P_XF = 7, P_QD = 14, P_QFD = 21, P_RD = 28, P_ULO = 31, P_UHI = 34, P_J = 37, P_JI = 46,
        P_TAU0 = 55, P_DTAU = 56, P_DT = 57 };
@@ -78,7 +82,7 @@ constexpr int KDW = 24, XUW = 10, LMW = 6, BSW = 9;
 
 template <typename real>
 struct KArgs {
-  int T, N, n_tab, max_ls;
+  int T, N, n_tab, max_ls;   // max_ls: candidate slots reserved per trajectory (<= NSTORE)
   tsat_options opt;
   const real* P;      // [T][PSTRIDE]
   const real* BT;     // [n_btab][n_tab][4]
@@ -87,7 +91,7 @@ struct KArgs {
   real* XU;           // [T][N][10]      nominal knot records x(7),u(3)
   real* KD;           // [T][N-1][24]    K (3x7 row-major), d(3)
   real* LAM;          // [T][N-1][6]     control-box multipliers [upper(3), lower(3)]
-  real* CAND;         // [T][max_ls][N][10] line-search candidates
+  real* CAND;         // [T][max_ls][N][10] stored line-search candidates
   tsat_stats* stats;  // [T]
   double* trace;      // [T][trace_rows][8] or null
   int trace_rows;
@@ -539,13 +543,13 @@ template <typename real> struct BwdOut { real dV1, dV2; int pd_ok; };
 // whether its rollout stayed within max_state. Candidate knot records go to CAND[lane].
 // --------------------------------------------------------------------------------------------------
 template <typename real, int INTEG, int DIAGJ>
-TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_cand, real mu,
-                                      int term_mask, real max_state) {
+TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_cand, int alpha_shift,
+                                      real mu, int term_mask, real max_state) {
   real* lds = lds_base<real>();
   const Traj<real> tr = load_traj<real>(N, n_tab, p.bt);
   const int lane = TSAT_LANE();
-  real alpha = 1;
-  for (int j = 0; j < lane && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (real)0.5;
+  real alpha = 1;   // lane j rolls out alpha = 2^-(j + alpha_shift); the first n_cand lanes keep their rollout in HBM
+  for (int j = 0; j < lane + alpha_shift && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (real)0.5;
   real x[7];
   for (int i = 0; i < 7; ++i) x[i] = lds[L_TR + P_X0 + i];
   real J = 0, amax = 0;
@@ -980,7 +984,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   unsigned long long pc_fwd = 0, pc_par = 0;
 
   // open-loop rollout of U0
-  FwdOut<real> f0 = forward_sweep<real, INTEG, DIAGJ>(p, N, n_tab, 0, 1, mu, tmask, max_state);
+  FwdOut<real> f0 = forward_sweep<real, INTEG, DIAGJ>(p, N, n_tab, 0, 1, 0, mu, tmask, max_state);
   n_forward++;
   const real J0 = wave_bcast(f0.J, 0, lds + L_RED);
   const int ok0 = wave_first<real>(!f0.ok, lds + L_RED) > 0;  // lane 0 ok?
@@ -1018,7 +1022,8 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
         TSAT_SYNC();
         // all backtracking trials in one sweep
         const unsigned long long t_f0 = tick_();
-        const FwdOut<real> fw = forward_sweep<real, INTEG, DIAGJ>(p, N, n_tab, 1, o.max_linesearch, mu, tmask, max_state);
+        const int n_store = (o.max_linesearch < a.max_ls) ? o.max_linesearch : a.max_ls;
+        const FwdOut<real> fw = forward_sweep<real, INTEG, DIAGJ>(p, N, n_tab, 1, n_store, 0, mu, tmask, max_state);
         const unsigned long long t_f1 = tick_();
         pc_fwd += t_f1 - t_f0;
         n_forward++;
@@ -1035,7 +1040,14 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
         if (jw < WAVE) {
           J = wave_bcast(Jc, jw, lds + L_RED);
           ls_trials += jw + 1;
-          grad = adopt_and_gradient<real>(p, N, jw);
+          int slot = jw;
+          if (jw >= n_store) {   // the winner's rollout was not kept: roll out that one alpha again, into slot 0
+            (void)forward_sweep<real, INTEG, DIAGJ>(p, N, n_tab, 1, 1, jw, mu, tmask, max_state);
+            n_forward++;
+            slot = 0;
+            TSAT_SYNC();
+          }
+          grad = adopt_and_gradient<real>(p, N, slot);
         } else {
           J = Jprev;
           ls_trials += o.max_linesearch;

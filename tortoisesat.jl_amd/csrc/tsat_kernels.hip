@@ -153,7 +153,8 @@ int tsat_batch_reserve(tsat_handle* h, int64_t T, int32_t n_knots, int32_t n_tab
   rc |= dev_alloc(h, &h->XU, Tn * N * XUW);
   rc |= dev_alloc(h, &h->KD, Tn * (N - 1) * KDW);
   rc |= dev_alloc(h, &h->LAM, Tn * (N - 1) * LMW);
-  rc |= dev_alloc(h, &h->CAND, Tn * (size_t)max_linesearch * N * XUW);
+  const int slots = max_linesearch < NSTORE ? max_linesearch : NSTORE;   // stored candidates (tsat_device.hpp)
+  rc |= dev_alloc(h, &h->CAND, Tn * (size_t)slots * N * XUW);
   rc |= dev_alloc(h, &h->stats, Tn);
   if (trows > 0) rc |= dev_alloc(h, &h->trace, Tn * (size_t)trows * 8);
   if (rc) { release(h); return -10; }
@@ -216,7 +217,7 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
   if (!why.empty()) return fail(h, -1, why);
   TSAT_HIP(h, hipSetDevice(h->dev));
   KArgs<double> a;
-  a.T = (int)h->T; a.N = h->N; a.n_tab = h->n_tab; a.max_ls = h->max_ls; a.opt = *o;
+  a.T = (int)h->T; a.N = h->N; a.n_tab = h->n_tab; a.max_ls = h->max_ls < NSTORE ? h->max_ls : NSTORE; a.opt = *o;
   a.P = h->P; a.BT = h->BT; a.bidx = h->bidx; a.U0 = h->U0;
   a.XU = h->XU; a.KD = h->KD; a.LAM = h->LAM; a.CAND = h->CAND;
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
