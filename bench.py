@@ -50,7 +50,7 @@ def cpu_baseline(batch, abi_opts, res, sample, threads):
     oo = ol.default_options()
     for f in ("integrator", "max_outer", "max_inner", "max_linesearch", "dj_counter_limit", "cost_tol", "grad_tol",
               "constraint_tol", "penalty_init", "penalty_scale", "penalty_max", "dual_max", "reg_init", "reg_scale",
-              "reg_min", "reg_max", "reg_fp", "ls_lower", "ls_upper", "max_state", "u_scale", "terminal_mask"):
+              "reg_min", "reg_max", "reg_fp", "ls_lower", "ls_upper", "max_state", "u_scale", "terminal_mask", "error_state"):
         setattr(oo, f, getattr(abi_opts, f))
     t0 = time.perf_counter()
     ref = ol.solve_batch(sub, oo, nthreads=threads, want_K=False)

@@ -70,7 +70,12 @@ typedef struct tsat_options {
   int32_t terminal_mask;    /* bit i set: state component i has a terminal equality x_N[i]=xf[i]
                                (goal_constraint, src/TortoiseSat.jl:182,188)                         */
   int32_t error_state;      /* 0: plain 7-state differences (Model(DerivFunction,8,3), src/TortoiseSat.jl:145)
-                               1: reserved for the quaternion hooks of src/quaternion_toolbox.jl:15-75 */
+                               1: the quaternion hooks Model(f!,n,m,quaternion_error,quaternion_expansion)
+                                  (src/monte_carlo.jl:158): state difference [dw; MRP(q^-1 (x) q_new)]
+                                  (src/quaternion_toolbox.jl:58-75), dynamics blocks E(q_{k+1})'AE(q_k), E(q_{k+1})'B
+                                  (src/attitude_controller.jl:59-81), cost expansion projected through E(q)
+                                  (src/quaternion_toolbox.jl:15-50); gains K act on the 6 error coordinates and
+                                  are returned with a zero 7th column */
 } tsat_options;
 
 /* per-trajectory result record */

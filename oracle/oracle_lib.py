@@ -79,6 +79,7 @@ def qrot(q, r): return _call_vec("orc_qrot", 3, q, r)
 def qinv(q): return _call_vec("orc_qinv", 4, q)
 def hat(x): return _call_vec("orc_hat", 9, x).reshape(3, 3).T          # column-major -> [r,c]
 def gmat(q): return _call_vec("orc_gmat", 12, q).reshape(3, 4).T       # 4x3
+def emat(q): return _call_vec("orc_emat", 42, q).reshape(7, 6)
 def inv3(M): return _call_vec("orc_inv3", 9, np.asarray(M).T.reshape(9)).reshape(3, 3).T
 
 

@@ -250,18 +250,33 @@ double max_violation(const Traj& t, const tsat_options& o, const double* X, cons
   return c;
 }
 
-// forward rollout with the iLQR policy u = ubar + K (x - xbar) + alpha d   (Appendix A "forward")
+// state difference fed to the gains: plain x - xbar, or with error_state = 1 the reference's hook
+// quaternion_error(X1, X2) = [dw; MRP(q2^-1 (x) q1)] (src/quaternion_toolbox.jl:58-75), a 6-vector
+void state_diff(int es, const double* xnew, const double* xnom, double* dx) {
+  if (!es) { for (int j = 0; j < 7; ++j) dx[j] = xnew[j] - xnom[j]; return; }
+  for (int j = 0; j < 3; ++j) dx[j] = xnew[j] - xnom[j];
+  double qi[4] = {xnom[3], -xnom[4], -xnom[5], -xnom[6]}, qe[4];
+  qmult<double>(qi, xnew + 3, qe);
+  for (int j = 0; j < 3; ++j) dx[3 + j] = qe[1 + j] / (1.0 + qe[0]);
+  dx[6] = 0.0;
+}
+
+// forward rollout with the iLQR policy u = ubar + K dx + alpha d   (Appendix A "forward"). K rows are stored with
+// stride 7 in both modes (column 6 is zero in error-state mode).
 bool rollout(const Traj& t, const tsat_options& o, const double* X, const double* U, const double* K,
              const double* d, double alpha, bool closed, double* Xc, double* Uc) {
   for (int i = 0; i < 7; ++i) Xc[i] = t.x0[i];
   bool ok = true;
+  const int nh = o.error_state ? 6 : 7;
   for (int k = 0; k < t.N - 1; ++k) {
     double* xc = Xc + 7 * k;
     double* uc = Uc + 3 * k;
+    double dx[7];
+    if (closed) state_diff(o.error_state, xc, X + 7 * k, dx);
     for (int a = 0; a < 3; ++a) {
       double v = U[3 * k + a];
       if (closed) {
-        for (int j = 0; j < 7; ++j) v += K[(k * 3 + a) * 7 + j] * (xc[j] - X[7 * k + j]);
+        for (int j = 0; j < nh; ++j) v += K[(k * 3 + a) * 7 + j] * dx[j];
         v += alpha * d[3 * k + a];
       }
       uc[a] = v;
@@ -274,27 +289,72 @@ bool rollout(const Traj& t, const tsat_options& o, const double* X, const double
   return ok;
 }
 
+// E(q) = blkdiag(I3, G(q)) (7x6 row-major) with the raw state quaternion (src/attitude_controller.jl:61-78)
+void emat(const double* q, double* E) {
+  for (int i = 0; i < 42; ++i) E[i] = 0.0;
+  for (int i = 0; i < 3; ++i) E[i * 6 + i] = 1.0;
+  const double s = q[0], v0 = q[1], v1 = q[2], v2 = q[3];
+  const double G[12] = {-v0, -v1, -v2, s, -v2, v1, v2, s, -v0, -v1, v0, s};  // rows: [-v'; s I + hat(v)]
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 3; ++c) E[(3 + r) * 6 + 3 + c] = G[r * 3 + c];
+}
+
 // backward Riccati sweep of iLQR on the AL cost (Appendix A "backward"); false if some Quu_reg is not PD.
+// error_state = 0: 7-state differences. error_state = 1: the reference's quaternion hooks — dynamics blocks reduced to
+// E(q_{k+1})' A E(q_k), E(q_{k+1})' B (src/attitude_controller.jl:59-81), cost expansion projected through E(q_k)
+// (src/quaternion_toolbox.jl:15-50); everything runs on nh = 6 error coordinates. K is written with row stride 7.
 bool backward(const Traj& t, const tsat_options& o, const double* X, const double* U, const AL& al, double rho,
               double* K, double* d, double dV[2]) {
   const int N = t.N;
+  const int es = o.error_state, nh = es ? 6 : 7;
   double S[49], s[7];
   for (int i = 0; i < 49; ++i) S[i] = 0.0;
   const double* xN = X + 7 * (N - 1);
-  for (int i = 0; i < 7; ++i) {
-    double e = xN[i] - t.xf[i];
-    S[i * 7 + i] = t.Qfd[i];
-    s[i] = t.Qfd[i] * e;
-    if (o.terminal_mask >> i & 1) { S[i * 7 + i] += al.mu; s[i] += al.nu[i] + al.mu * e; }
+  {
+    double Sd[7], sf[7];
+    for (int i = 0; i < 7; ++i) {
+      double e = xN[i] - t.xf[i];
+      Sd[i] = t.Qfd[i];
+      sf[i] = t.Qfd[i] * e;
+      if (o.terminal_mask >> i & 1) { Sd[i] += al.mu; sf[i] += al.nu[i] + al.mu * e; }
+    }
+    if (!es) {
+      for (int i = 0; i < 7; ++i) { S[i * 7 + i] = Sd[i]; s[i] = sf[i]; }
+    } else {
+      double E[42];
+      emat(xN + 3, E);
+      for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 6; ++j) { double a = 0; for (int m = 0; m < 7; ++m) a += E[m * 6 + i] * Sd[m] * E[m * 6 + j]; S[i * 7 + j] = a; }
+        double a = 0; for (int m = 0; m < 7; ++m) a += E[m * 6 + i] * sf[m]; s[i] = a;
+      }
+    }
   }
   dV[0] = dV[1] = 0.0;
-  double A[49], B[21];
+  double A7[49], B7[21], A[49], B[21];
   for (int k = N - 2; k >= 0; --k) {
     const double* x = X + 7 * k;
     const double* u = U + 3 * k;
-    discrete_jacobian(t.integ, x, u, brow(t, k, 0.0), brow(t, k, 0.5), brow(t, k, 1.0), t.dt, t.ph, A, B);
-    double lx[7], lu[3], luu[3];
-    for (int i = 0; i < 7; ++i) lx[i] = t.Qd[i] * (x[i] - t.xf[i]);
+    discrete_jacobian(t.integ, x, u, brow(t, k, 0.0), brow(t, k, 0.5), brow(t, k, 1.0), t.dt, t.ph, A7, B7);
+    double lx7[7], lx[7], lu[3], luu[3], Q0[49];
+    for (int i = 0; i < 49; ++i) Q0[i] = 0.0;
+    for (int i = 0; i < 7; ++i) lx7[i] = t.Qd[i] * (x[i] - t.xf[i]);
+    if (!es) {
+      for (int i = 0; i < 49; ++i) A[i] = A7[i];
+      for (int i = 0; i < 21; ++i) B[i] = B7[i];
+      for (int i = 0; i < 7; ++i) { lx[i] = lx7[i]; Q0[i * 7 + i] = t.Qd[i]; }
+    } else {
+      double Ek[42], En[42], T[42];
+      emat(x + 3, Ek);
+      emat(x + 7 + 3, En);
+      for (int i = 0; i < 7; ++i)
+        for (int j = 0; j < 6; ++j) { double a = 0; for (int m = 0; m < 7; ++m) a += A7[i * 7 + m] * Ek[m * 6 + j]; T[i * 6 + j] = a; }
+      for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 6; ++j) { double a = 0; for (int m = 0; m < 7; ++m) a += En[m * 6 + i] * T[m * 6 + j]; A[i * 7 + j] = a; }
+        for (int c = 0; c < 3; ++c) { double a = 0; for (int m = 0; m < 7; ++m) a += En[m * 6 + i] * B7[m * 3 + c]; B[i * 3 + c] = a; }
+        double a = 0; for (int m = 0; m < 7; ++m) a += Ek[m * 6 + i] * lx7[m]; lx[i] = a;
+        for (int j = 0; j < 6; ++j) { double b = 0; for (int m = 0; m < 7; ++m) b += Ek[m * 6 + i] * t.Qd[m] * Ek[m * 6 + j]; Q0[i * 7 + j] = b; }
+      }
+    }
     const double* lam = al.lam.data() + 6 * k;
     for (int a = 0; a < 3; ++a) {
       lu[a] = t.Rd[a] * u[a];
@@ -308,21 +368,21 @@ bool backward(const Traj& t, const tsat_options& o, const double* X, const doubl
       lu[a] -= lm + (act ? al.mu * c : 0.0);
       if (act) luu[a] += al.mu;
     }
-    // SA = S A (7x7), SB = S B (7x3)
+    // SA = S A (nh x nh), SB = S B (nh x 3); all blocks use row stride 7 / 3
     double SA[49], SB[21];
-    for (int i = 0; i < 7; ++i) {
-      for (int j = 0; j < 7; ++j) { double a = 0; for (int m = 0; m < 7; ++m) a += S[i * 7 + m] * A[m * 7 + j]; SA[i * 7 + j] = a; }
-      for (int c = 0; c < 3; ++c) { double a = 0; for (int m = 0; m < 7; ++m) a += S[i * 7 + m] * B[m * 3 + c]; SB[i * 3 + c] = a; }
+    for (int i = 0; i < nh; ++i) {
+      for (int j = 0; j < nh; ++j) { double a = 0; for (int m = 0; m < nh; ++m) a += S[i * 7 + m] * A[m * 7 + j]; SA[i * 7 + j] = a; }
+      for (int c = 0; c < 3; ++c) { double a = 0; for (int m = 0; m < nh; ++m) a += S[i * 7 + m] * B[m * 3 + c]; SB[i * 3 + c] = a; }
     }
     double Qx[7], Qu[3], Qxx[49], Quu[9], Qux[21];
-    for (int j = 0; j < 7; ++j) { double a = lx[j]; for (int m = 0; m < 7; ++m) a += A[m * 7 + j] * s[m]; Qx[j] = a; }
-    for (int c = 0; c < 3; ++c) { double a = lu[c]; for (int m = 0; m < 7; ++m) a += B[m * 3 + c] * s[m]; Qu[c] = a; }
-    for (int i = 0; i < 7; ++i)
-      for (int j = 0; j < 7; ++j) { double a = (i == j) ? t.Qd[i] : 0.0; for (int m = 0; m < 7; ++m) a += A[m * 7 + i] * SA[m * 7 + j]; Qxx[i * 7 + j] = a; }
+    for (int j = 0; j < nh; ++j) { double a = lx[j]; for (int m = 0; m < nh; ++m) a += A[m * 7 + j] * s[m]; Qx[j] = a; }
+    for (int c = 0; c < 3; ++c) { double a = lu[c]; for (int m = 0; m < nh; ++m) a += B[m * 3 + c] * s[m]; Qu[c] = a; }
+    for (int i = 0; i < nh; ++i)
+      for (int j = 0; j < nh; ++j) { double a = Q0[i * 7 + j]; for (int m = 0; m < nh; ++m) a += A[m * 7 + i] * SA[m * 7 + j]; Qxx[i * 7 + j] = a; }
     for (int c = 0; c < 3; ++c)
-      for (int e = 0; e < 3; ++e) { double a = (c == e) ? luu[c] : 0.0; for (int m = 0; m < 7; ++m) a += B[m * 3 + c] * SB[m * 3 + e]; Quu[c * 3 + e] = a; }
+      for (int e = 0; e < 3; ++e) { double a = (c == e) ? luu[c] : 0.0; for (int m = 0; m < nh; ++m) a += B[m * 3 + c] * SB[m * 3 + e]; Quu[c * 3 + e] = a; }
     for (int c = 0; c < 3; ++c)
-      for (int j = 0; j < 7; ++j) { double a = 0; for (int m = 0; m < 7; ++m) a += B[m * 3 + c] * SA[m * 7 + j]; Qux[c * 7 + j] = a; }
+      for (int j = 0; j < nh; ++j) { double a = 0; for (int m = 0; m < nh; ++m) a += B[m * 3 + c] * SA[m * 7 + j]; Qux[c * 7 + j] = a; }
     // control regularisation + Sylvester PD test + adjugate inverse of the symmetric 3x3
     double q00 = Quu[0] + rho, q11 = Quu[4] + rho, q22 = Quu[8] + rho;
     double q10 = 0.5 * (Quu[3] + Quu[1]), q20 = 0.5 * (Quu[6] + Quu[2]), q21 = 0.5 * (Quu[7] + Quu[5]);
@@ -339,29 +399,30 @@ bool backward(const Traj& t, const tsat_options& o, const double* X, const doubl
     double* Kk = K + (size_t)k * 21;
     double* dk = d + (size_t)k * 3;
     for (int c = 0; c < 3; ++c) {
-      for (int j = 0; j < 7; ++j) Kk[c * 7 + j] = -(Qi[c * 3 + 0] * Qux[0 * 7 + j] + Qi[c * 3 + 1] * Qux[1 * 7 + j] + Qi[c * 3 + 2] * Qux[2 * 7 + j]);
+      for (int j = 0; j < 7; ++j) Kk[c * 7 + j] = 0.0;
+      for (int j = 0; j < nh; ++j) Kk[c * 7 + j] = -(Qi[c * 3 + 0] * Qux[0 * 7 + j] + Qi[c * 3 + 1] * Qux[1 * 7 + j] + Qi[c * 3 + 2] * Qux[2 * 7 + j]);
       dk[c] = -(Qi[c * 3 + 0] * Qu[0] + Qi[c * 3 + 1] * Qu[1] + Qi[c * 3 + 2] * Qu[2]);
     }
     // cost-to-go update (literal Appendix A form, un-regularised Quu)
     double QuuK[21], Quud[3];
     for (int c = 0; c < 3; ++c) {
-      for (int j = 0; j < 7; ++j) QuuK[c * 7 + j] = Quu[c * 3 + 0] * Kk[0 * 7 + j] + Quu[c * 3 + 1] * Kk[1 * 7 + j] + Quu[c * 3 + 2] * Kk[2 * 7 + j];
+      for (int j = 0; j < nh; ++j) QuuK[c * 7 + j] = Quu[c * 3 + 0] * Kk[0 * 7 + j] + Quu[c * 3 + 1] * Kk[1 * 7 + j] + Quu[c * 3 + 2] * Kk[2 * 7 + j];
       Quud[c] = Quu[c * 3 + 0] * dk[0] + Quu[c * 3 + 1] * dk[1] + Quu[c * 3 + 2] * dk[2];
     }
     double Sn[49], sn[7];
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < nh; ++i) {
       double a = Qx[i];
       for (int c = 0; c < 3; ++c) a += Kk[c * 7 + i] * Quud[c] + Kk[c * 7 + i] * Qu[c] + Qux[c * 7 + i] * dk[c];
       sn[i] = a;
-      for (int j = 0; j < 7; ++j) {
+      for (int j = 0; j < nh; ++j) {
         double b = Qxx[i * 7 + j];
         for (int c = 0; c < 3; ++c) b += Kk[c * 7 + i] * QuuK[c * 7 + j] + Kk[c * 7 + i] * Qux[c * 7 + j] + Qux[c * 7 + i] * Kk[c * 7 + j];
         Sn[i * 7 + j] = b;
       }
     }
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < nh; ++i) {
       s[i] = sn[i];
-      for (int j = 0; j < 7; ++j) S[i * 7 + j] = 0.5 * (Sn[i * 7 + j] + Sn[j * 7 + i]);
+      for (int j = 0; j < nh; ++j) S[i * 7 + j] = 0.5 * (Sn[i * 7 + j] + Sn[j * 7 + i]);
     }
     dV[0] += dk[0] * Qu[0] + dk[1] * Qu[1] + dk[2] * Qu[2];
     dV[1] += 0.5 * (dk[0] * Quud[0] + dk[1] * Quud[1] + dk[2] * Quud[2]);
@@ -540,6 +601,8 @@ void orc_gmat(const double* q, double* G) {
   }
 }
 void orc_inv3(const double* M, double* Mi) { inv3(M, Mi); }
+// E(q) = blkdiag(I3, G(q)) used by the error-state solve (7x6 row-major)
+void orc_emat(const double* q, double* E) { emat(q, E); }
 
 // A2 literal: DerivFunction(dx,x,u) with the globals passed explicitly.
 // Btab is [rows][3]; Nglob = the script-global N (src/DerivFunction.jl:28), tspan = tf - t0 (:44).
@@ -720,7 +783,7 @@ int orc_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab, const doub
                     tsat_stats* stats, int nthreads, double* trace, int trace_rows) {
   if (!o || o->n_knots < 2 || o->n_tab < 1 || (o->integrator != 3 && o->integrator != 4)) return -1;
   if (o->max_linesearch < 1 || o->max_linesearch > TSAT_MAX_LINESEARCH) return -1;
-  if (o->error_state != 0) return -2;
+  if (o->error_state != 0 && o->error_state != 1) return -2;
   if (!btab_idx && n_btab != T) return -1;
   const int N = o->n_knots;
   (void)nthreads;

@@ -23,7 +23,7 @@ void* lds() { return g_lds; }
 
 using namespace tsat;
 
-template <int INTEG, int DIAGJ>
+template <int INTEG, int DIAGJ, int ES>
 static void run_block(const KArgs<double>& a, int traj) {
   std::vector<double> lds(LDS_REALS, 0.0);
   std::barrier<> bar(WAVE);
@@ -33,7 +33,7 @@ static void run_block(const KArgs<double>& a, int traj) {
   for (int l = 0; l < WAVE; ++l)
     th.emplace_back([&, l]() {
       tsat_emu::g_lane = l;
-      solve_trajectory<double, INTEG, DIAGJ>(a, traj);
+      solve_trajectory<double, INTEG, DIAGJ, ES>(a, traj);
     });
   for (auto& t : th) t.join();
 }
@@ -64,10 +64,11 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
   for (int64_t t = 0; t < T && diag; ++t)
     for (int i = 0; i < 9; ++i)
       if (i % 4 != 0 && Jmat[9 * t + i] != 0.0) { diag = false; break; }
-  for (int t = 0; t < (int)T; ++t) {
-    if (o->integrator == 3) { if (diag) run_block<3, 1>(a, t); else run_block<3, 0>(a, t); }
-    else { if (diag) run_block<4, 1>(a, t); else run_block<4, 0>(a, t); }
-  }
+  using blk_t = void (*)(const KArgs<double>&, int);
+  static const blk_t variants[2][2][2] = {{{run_block<3, 0, 0>, run_block<3, 0, 1>}, {run_block<3, 1, 0>, run_block<3, 1, 1>}},
+                                          {{run_block<4, 0, 0>, run_block<4, 0, 1>}, {run_block<4, 1, 0>, run_block<4, 1, 1>}}};
+  const blk_t blk = variants[o->integrator == 4 ? 1 : 0][diag ? 1 : 0][o->error_state ? 1 : 0];
+  for (int t = 0; t < (int)T; ++t) blk(a, t);
   for (int64_t e = 0; e < T * (int64_t)N; ++e) export_record<double>(e, N, XU.data(), KD.data(), X, U, K);
   return 0;
 }

@@ -46,6 +46,9 @@ CASES = {
                                 opts(max_outer=3, max_inner=5, dj_counter_limit=1, max_linesearch=12)),
     # single-slew flavour (src/TortoiseSat.jl:117-199): 1P inertia, |u| <= 1 active bounds, U0 = 0
     "single_n150_rk3.npz": (lambda: ss.workload_single_slew(N=150), opts(max_outer=4, max_inner=12)),
+    # quaternion hooks of the old-API Monte-Carlo (src/monte_carlo.jl:158): error_state = 1
+    "mc_es_n120_t3_rk3.npz": (lambda: ss.workload_monte_carlo(T=3, N=120, seed=13), opts(max_outer=4, max_inner=8, dj_counter_limit=1, error_state=1)),
+    "mc_es_n70_t2_rk4.npz": (lambda: ss.workload_monte_carlo(T=2, N=70, seed=17, random_orbit=True), opts(max_outer=2, max_inner=5, integrator=4, error_state=1)),
     # negative control weight: Quu is indefinite, so the backward sweep has to restart with growing regularisation
     "negR_n70_t2_rk3.npz": (lambda: neg_r(ss.workload_monte_carlo(T=2, N=70, seed=5)), opts(max_outer=2, max_inner=4)),
 }

@@ -109,3 +109,36 @@ def test_oracle_openmp_matches_serial(pkg, ol):
     o = oracle_options(ol, max_outer=2, max_inner=3)
     a, c = ol.solve_batch(b, o, nthreads=1), ol.solve_batch(b, o, nthreads=4)
     assert np.array_equal(a["X"], c["X"]) and np.array_equal(a["U"], c["U"])
+
+
+@pytest.mark.parametrize("N", [2, 53, 54])
+def test_emulated_kernel_error_state_mode(pkg, ol, emu, N):
+    """error_state = 1 (quaternion hooks, src/monte_carlo.jl:158): ragged sizes around the 52-knot backward chunk"""
+    b = pkg.slew_setup.workload_monte_carlo(T=1, N=N, seed=300 + N)
+    b.Rd[~np.isfinite(b.Rd)] = 0.03
+    o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1, error_state=1)
+    assert_same_solution(ol.solve_batch(b, o), emu.solve(b, o))
+
+
+def test_emulated_kernel_error_state_masks_and_full_inertia(pkg, ol, emu):
+    ss = pkg.slew_setup
+    b = ss.workload_monte_carlo(T=1, N=45, seed=31)
+    J = np.array([[2.0e-3, 1.0e-4, -2.0e-4], [1.0e-4, 1.5e-3, 3.0e-4], [-2.0e-4, 3.0e-4, 2.5e-3]])
+    b.Jmat[:] = ss.jmat_cm(J)
+    for mask in (0, 0b1111000, 0x7F):
+        o = oracle_options(ol, max_outer=2, max_inner=3, terminal_mask=mask, error_state=1)
+        r, g = ol.solve_batch(b, o), emu.solve(b, o)
+        assert_same_solution(r, g)
+        assert np.all(g["K"][:, :, 6, :] == 0)      # gains act on 6 error coordinates; 7th column is zero
+
+
+def test_error_state_is_a_different_iteration_on_the_same_problem(pkg, ol):
+    b = pkg.slew_setup.workload_monte_carlo(T=2, N=150, seed=3)
+    r0 = ol.solve_batch(b, oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1))
+    r1 = ol.solve_batch(b, oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, error_state=1), trace_rows=60)
+    assert np.max(np.abs(r0["X"] - r1["X"])) > 1e-6            # the hooks change the iterates ...
+    for t in range(2):                                          # ... and every accepted step still lowers the AL cost
+        tr = r1["trace"][t]
+        tr = tr[tr[:, 0] > 0]
+        assert np.all(tr[:, 3] <= tr[:, 2])
+    assert np.all(np.isfinite(r1["X"])) and np.all(r1["K"][:, :, 6, :] == 0)

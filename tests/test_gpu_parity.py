@@ -69,6 +69,26 @@ def test_gpu_monte_carlo_1000_knots(pkg, ol, solver, integ):
     np.testing.assert_allclose(got["trace"][:, :, 3], ref["trace"][:, :, 3], rtol=1e-9)
 
 
+def test_gpu_error_state_mode_1000_knots(pkg, ol, solver):
+    """the quaternion hooks of the old-API Monte-Carlo (src/monte_carlo.jl:158), full horizon"""
+    b = pkg.slew_setup.workload_monte_carlo(T=16, N=1000)
+    o = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, error_state=1)
+    ref = ol.solve_batch(b, o, nthreads=min(16, ol.num_procs()))
+    got = gpu_solve(pkg, solver, b, o)
+    assert_same_solution(ref, got, tol=1e-9)
+    k_close(ref, got)
+    assert np.all(got["K"][:, :, 6, :] == 0)
+
+
+@pytest.mark.parametrize("N", [2, 53, 54, 105])
+def test_gpu_error_state_ragged(pkg, ol, solver, N):
+    b = pkg.slew_setup.workload_monte_carlo(T=3, N=N, seed=300 + N)
+    b.Rd[~np.isfinite(b.Rd)] = 0.03
+    for integ in (3, 4):
+        o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1, error_state=1, integrator=integ)
+        assert_same_solution(ol.solve_batch(b, o), gpu_solve(pkg, solver, b, o))
+
+
 def test_gpu_single_slew_config0(pkg, ol, solver):
     """configs[0]: the reference's own case (src/TortoiseSat.jl:117-199) — 500 knots, |u| <= 1, 20 x 50 budget"""
     b = pkg.slew_setup.workload_single_slew(N=500)
@@ -133,7 +153,7 @@ def test_gpu_api_errors_are_codes_not_crashes(pkg, ol, solver):
     b = pkg.slew_setup.workload_monte_carlo(T=2, N=30)
     o = helpers.abi_options_like(oracle_options(ol, max_outer=1, max_inner=1), pkg, b.N, b.n_tab)
     solver.upload(b, o.max_linesearch)
-    for field, bad in (("integrator", 5), ("precision", 32), ("error_state", 1), ("max_linesearch", 33), ("n_knots", 31)):
+    for field, bad in (("integrator", 5), ("precision", 32), ("error_state", 2), ("max_linesearch", 33), ("n_knots", 31)):
         o2 = o.copy()
         setattr(o2, field, bad)
         rc = lib.tsat_batch_run(solver._h, C.byref(o2), None)

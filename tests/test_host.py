@@ -112,3 +112,18 @@ def test_shard_range_partitions_exactly(pkg):
             assert all(blocks[i][1] == blocks[i + 1][0] for i in range(W - 1))
             sizes = [b - a for a, b in blocks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_model_hooks_select_error_state_mode(pkg):
+    """Model(f!, n, m, quaternion_error, quaternion_expansion) as at src/monte_carlo.jl:158"""
+    to = pkg.trajopt
+    f = to.DerivFunction(np.eye(3) * 1e-3, np.zeros((10, 3)))
+    assert to.Model(f, 8, 3).error_state == 0
+    m = to.rk3(to.Model(f, 8, 3, to.quaternion_error, to.quaternion_expansion))
+    assert m.error_state == 1 and m.integrator == 3
+    with pytest.raises(ValueError):
+        to.Model(f, 8, 3, to.quaternion_error, None).error_state
+    with pytest.raises(ValueError):
+        to.Model(f, 8, 3, lambda a, b: a - b, lambda *a: None).error_state
+    o = to.AugmentedLagrangianSolverOptions().to_abi(10, 10, 3, error_state=1)
+    assert o.error_state == 1

@@ -192,3 +192,22 @@ def test_tvlqr_riccati_converges_to_dare_on_lti(ol):
     S = scipy.linalg.solve_discrete_are(A1, B1, Q, R)
     Kinf = np.linalg.solve(R + B1.T @ S @ B1, B1.T @ S @ A1)
     np.testing.assert_allclose(K[0], Kinf, rtol=1e-8, atol=1e-10)
+
+
+def test_error_state_solver_blocks_use_the_reference_projection(ol):
+    """the E(q) the error-state solve projects with is blkdiag(I3, G(q)) of src/attitude_controller.jl:69-78, and
+    projecting with it reproduces the reference's reduction and cost expansion"""
+    for _ in range(5):
+        qk, qn = rq(False), rq(False)
+        Ek, En = ol.emat(qk), ol.emat(qn)
+        ref = np.zeros((7, 6)); ref[:3, :3] = np.eye(3); ref[3:, 3:] = rm.gmat(qk)
+        np.testing.assert_array_equal(Ek, ref)
+        A, B = RNG.standard_normal((7, 7)), RNG.standard_normal((7, 3))
+        Ar, Br = rm.reduce_error_state(A, B, qk, qn)
+        np.testing.assert_allclose(En.T @ A @ Ek, Ar, atol=1e-13)
+        np.testing.assert_allclose(En.T @ B, Br, atol=1e-13)
+        Q = np.diag(RNG.random(7) + 0.1)
+        x = np.r_[RNG.standard_normal(3), qk]
+        Rxx, Rx = rm.quaternion_expansion(Q, -Q @ np.ones(7), x)
+        np.testing.assert_allclose(Ek.T @ Q @ Ek, Rxx, atol=1e-13)
+        np.testing.assert_allclose(Ek.T @ (Q @ (x - np.ones(7))), Rx, atol=1e-13)

@@ -65,7 +65,6 @@ namespace tsat {
 
 constexpr int WAVE = 64;
 constexpr int CK = 32;    // knots per forward-sweep LDS chunk
-constexpr int CHB = 56;   // knots per backward-sweep LDS chunk (Jacobian lanes); 4 waves x 40.6 KB fit one CU
 constexpr int PSTRIDE = 64;
 // line-search candidates whose rollouts are kept in HBM. On the reference Monte-Carlo workload the accepted step is
 // alpha = 2^-j with j <= 5 in 99.9 % of the iterations; a deeper winner is re-rolled on its own (rare second sweep)
@@ -74,9 +73,15 @@ constexpr int NSTORE = 6;
 // per-trajectory parameter record (reals)
 enum { P_X0 = 0, P_XF = 7, P_QD = 14, P_QFD = 21, P_RD = 28, P_ULO = 31, P_UHI = 34, P_J = 37, P_JI = 46,
        P_TAU0 = 55, P_DTAU = 56, P_DT = 57 };
-// Jacobian record left in LDS per knot (reals): F=[A|B] column-major (column stride FS = 7), then gradients
+// Jacobian record left in LDS per knot (reals): F=[A|B] column-major (column stride FS = 7), then gradients.
+// error_state = 1 appends the projected attitude block of the stage Hessian (6 unique entries of G'QG).
 constexpr int FS = 7;
-constexpr int R_F = 0, R_LX = 70, R_LU = 77, R_LUU = 80, RECS = 83;
+constexpr int R_F = 0, R_LX = 70, R_LU = 77, R_LUU = 80, R_QQ = 83;
+template <int ES> struct BwdCfg {
+  static constexpr int NH = ES ? 6 : 7;        // dimension of the state difference the gains act on
+  static constexpr int RECS = ES ? 89 : 83;    // reals per knot record
+  static constexpr int CHB = ES ? 52 : 56;     // knots per backward chunk: 4 waves x <= 40.6 KB fit one CU
+};
 // forward-sweep chunk arrays
 constexpr int KDW = 24, XUW = 10, LMW = 6, BSW = 9;
 
@@ -123,14 +128,15 @@ constexpr int L_ZERO = L_KD + 24;        // a constant 0 (branch-free "no initia
 constexpr int L_SINK = L_ZERO + 1;       // write target of lanes without a role in a step
 constexpr int L_UNION = L_SINK + 1;      // 424 (16-byte aligned)
 static_assert(L_UNION % 2 == 0, "phase buffers must stay 16-byte aligned");
-constexpr int L_REC = L_UNION;           // CHB x RECS
+constexpr int L_REC = L_UNION;           // BwdCfg::CHB x BwdCfg::RECS
 constexpr int L_KDC = L_UNION;           // CK x 24
 constexpr int L_XUC = L_KDC + CK * KDW;
 constexpr int L_LMC = L_XUC + CK * XUW;
 constexpr int L_BSC = L_LMC + CK * LMW;
 constexpr int L_GTC = L_BSC + CK * BSW;   // CK x 6 activity gates of the control-box rows (see forward_sweep)
 constexpr int L_FWD_END = L_GTC + CK * LMW;
-constexpr int L_BWD_END = L_REC + CHB * RECS;
+constexpr int L_BWD_END = L_REC + (BwdCfg<0>::CHB * BwdCfg<0>::RECS > BwdCfg<1>::CHB * BwdCfg<1>::RECS
+                                    ? BwdCfg<0>::CHB * BwdCfg<0>::RECS : BwdCfg<1>::CHB * BwdCfg<1>::RECS);
 constexpr int LDS_REALS = (L_FWD_END > L_BWD_END ? L_FWD_END : L_BWD_END);
 
 // The wavefront's LDS block: a STATIC module-level __shared__ array. Declared at namespace scope so that every phase
@@ -393,7 +399,7 @@ TSAT_DEV void dyn_h_jvp(const Traj<real>& tr, const StageBase<real>& sb, const r
 }
 
 // one RK step (rk3: src/attitude_controller.jl:178-187; rk4: :122-132); b0/b1/b2 = rows at tau, tau+dtau/2, tau+dtau
-template <typename real, int INTEG, int DIAGJ>
+template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_DEV void rk_step(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3], const real b1[3],
                       const real b2[3], real xn[7]) {
   const real us[3] = {u[0] * tr.us, u[1] * tr.us, u[2] * tr.us};
@@ -418,7 +424,7 @@ TSAT_DEV void rk_step(const Traj<real>& tr, const real x[7], const real u[3], co
 
 // discrete Jacobians of one RK step, column by column, written to LDS record `F` (column stride 8).
 // Equivalent of ForwardDiff.jacobian! over the discretised dynamics (src/attitude_controller.jl:95-119).
-template <typename real, int INTEG, int DIAGJ>
+template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_DEV void rk_jacobian(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3],
                           const real b1[3], const real b2[3], real* F) {
   const real us[3] = {u[0] * tr.us, u[1] * tr.us, u[2] * tr.us};
@@ -542,7 +548,7 @@ template <typename real> struct BwdOut { real dV1, dV2; int pd_ok; };
 // forward sweep: all line-search candidates at once (lane j: alpha = 2^-j). Returns this lane's AL cost and
 // whether its rollout stayed within max_state. Candidate knot records go to CAND[lane].
 // --------------------------------------------------------------------------------------------------
-template <typename real, int INTEG, int DIAGJ>
+template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_cand, int alpha_shift,
                                       real mu, int term_mask, real max_state) {
   real* lds = lds_base<real>();
@@ -590,10 +596,23 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
       if (closed) {
         const real* kd = KDc + kk * KDW;
         real dx[7];
-        for (int i = 0; i < 7; ++i) dx[i] = x[i] - xu[i];
+        if (ES) {
+          // quaternion_error(new, nominal) = [dw; MRP(q_nom^-1 (x) q_new)]  (src/quaternion_toolbox.jl:58-75)
+          for (int i = 0; i < 3; ++i) dx[i] = x[i] - xu[i];
+          const real s1 = xu[3], a1 = -xu[4], a2 = -xu[5], a3 = -xu[6];   // conjugate of the nominal quaternion
+          const real s2 = x[3], b1 = x[4], b2 = x[5], b3 = x[6];
+          const real e0 = s1 * s2 - (a1 * b1 + a2 * b2 + a3 * b3);
+          const real e1 = s1 * b1 + s2 * a1 + (a2 * b3 - a3 * b2);
+          const real e2 = s1 * b2 + s2 * a2 + (a3 * b1 - a1 * b3);
+          const real e3 = s1 * b3 + s2 * a3 + (a1 * b2 - a2 * b1);
+          const real ir = rcp_((real)1 + e0);
+          dx[3] = e1 * ir; dx[4] = e2 * ir; dx[5] = e3 * ir; dx[6] = 0;
+        } else {
+          for (int i = 0; i < 7; ++i) dx[i] = x[i] - xu[i];
+        }
         for (int c = 0; c < 3; ++c) {
           real v = u[c];
-          for (int j = 0; j < 7; ++j) v += kd[c * 7 + j] * dx[j];
+          for (int j = 0; j < BwdCfg<ES>::NH; ++j) v += kd[c * 7 + j] * dx[j];
           u[c] = v + alpha * kd[21 + c];
         }
       }
@@ -607,7 +626,7 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
       }
       real xn[7];
       const real* bs = BSc + kk * BSW;
-      rk_step<real, INTEG, DIAGJ>(tr, x, u, bs, bs + 3, bs + 6, xn);
+      rk_step<real, INTEG, DIAGJ, ES>(tr, x, u, bs, bs + 3, bs + 6, xn);
       for (int i = 0; i < 7; ++i) x[i] = xn[i];
     }
     TSAT_SYNC_LDS();  // the next chunk's staging writes must not overtake this chunk's LDS reads
@@ -627,10 +646,19 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
   return out;
 }
 
+// o = G(q)' r for a 4-vector r, G(q) = [-v'; s I + hat(v)] with the raw state quaternion (src/attitude_controller.jl:69)
+template <typename real>
+TSAT_DEV void gt_apply(const real q[4], real r0, real r1, real r2, real r3, real o[3]) {
+  const real s = q[0], v0 = q[1], v1 = q[2], v2 = q[3];
+  o[0] = (-v0 * r0 + s * r1) + (v2 * r2 - v1 * r3);
+  o[1] = (-v1 * r0 - v2 * r1) + (s * r2 + v0 * r3);
+  o[2] = (-v2 * r0 + v1 * r1) + (-v0 * r2 + s * r3);
+}
+
 // --------------------------------------------------------------------------------------------------
 // Jacobian lanes of one backward chunk: lane l linearises knot k0 + l and leaves [A|B], lx, lu, luu in LDS
 // --------------------------------------------------------------------------------------------------
-template <typename real, int INTEG, int DIAGJ>
+template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_PHASE void jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, real mu) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
@@ -646,9 +674,44 @@ TSAT_PHASE void jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, 
     const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
     const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
     for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
-    real* rc = lds + L_REC + lane * RECS;
-    rk_jacobian<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, rc + R_F);
+    real* rc = lds + L_REC + lane * BwdCfg<ES>::RECS;
+    rk_jacobian<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, rc + R_F);
     for (int i = 0; i < 7; ++i) rc[R_LX + i] = tr.Qd[i] * (x[i] - tr.xf[i]);
+    if (ES) {
+      // reduce to error coordinates in place: A^ = E(q_{k+1})' A E(q_k), B^ = E(q_{k+1})' B
+      // (src/attitude_controller.jl:59-81), lx^ = E(q_k)' lx, Qxx^ = E(q_k)' Q E(q_k) (src/quaternion_toolbox.jl:15-36)
+      real qk[4], qn[4];
+      for (int i = 0; i < 4; ++i) { qk[i] = x[3 + i]; qn[i] = xu[XUW + 3 + i]; }
+      real* F = rc + R_F;
+      for (int i = 0; i < 7; ++i) {   // columns 3..6 of A -> 3 error columns
+        real o[3];
+        gt_apply(qk, F[3 * FS + i], F[4 * FS + i], F[5 * FS + i], F[6 * FS + i], o);
+        F[3 * FS + i] = o[0]; F[4 * FS + i] = o[1]; F[5 * FS + i] = o[2];
+      }
+      for (int a = 0; a < 3; ++a)     // B columns move from 7..9 to 6..8
+        for (int i = 0; i < 7; ++i) F[(6 + a) * FS + i] = F[(7 + a) * FS + i];
+      for (int c = 0; c < 9; ++c) {   // rows 3..6 -> 3 error rows
+        real o[3];
+        gt_apply(qn, F[c * FS + 3], F[c * FS + 4], F[c * FS + 5], F[c * FS + 6], o);
+        F[c * FS + 3] = o[0]; F[c * FS + 4] = o[1]; F[c * FS + 5] = o[2];
+      }
+      {
+        real o[3];
+        gt_apply(qk, rc[R_LX + 3], rc[R_LX + 4], rc[R_LX + 5], rc[R_LX + 6], o);
+        rc[R_LX + 3] = o[0]; rc[R_LX + 4] = o[1]; rc[R_LX + 5] = o[2];
+      }
+      {  // G' diag(Qd[3:7]) G, upper triangle (0,0)(0,1)(0,2)(1,1)(1,2)(2,2); G rows: [-v'; s I + hat(v)]
+        const real sq = qk[0], v0 = qk[1], v1 = qk[2], v2 = qk[3];
+        const real G[4][3] = {{-v0, -v1, -v2}, {sq, -v2, v1}, {v2, sq, -v0}, {-v1, v0, sq}};
+        int idx = 0;
+        for (int j = 0; j < 3; ++j)
+          for (int l = j; l < 3; ++l) {
+            real acc = 0;
+            for (int r = 0; r < 4; ++r) acc += G[r][j] * tr.Qd[3 + r] * G[r][l];
+            rc[R_QQ + idx++] = acc;
+          }
+      }
+    }
     for (int c = 0; c < 3; ++c) {
       real lu = tr.Rd[c] * u[c], luu = tr.Rd[c];
       real cc = u[c] - tr.uhi[c], lm = lam[c];
@@ -668,85 +731,97 @@ TSAT_PHASE void jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, 
 // --------------------------------------------------------------------------------------------------
 // backward sweep = Jacobian lanes + Riccati recursion. pd_ok = 0 (wave-uniform) when some Quu_reg is not PD.
 // --------------------------------------------------------------------------------------------------
-TSAT_DEV void pair28(int L, int& i, int& j) {  // L in [0,28) -> (i<=j) of a 7x7 upper triangle, row by row
+TSAT_DEV void pair_ut(int L, int n, int& i, int& j) {  // L in [0, n(n+1)/2) -> (i<=j) of an n x n upper triangle, row by row
   int r = 0, base = 0;
-  while (L >= base + (7 - r)) { base += 7 - r; ++r; }
+  while (L >= base + (n - r)) { base += n - r; ++r; }
   i = r;
   j = r + (L - base);
 }
 
 // Riccati recursion over one chunk whose Jacobian records are in LDS (last knot first). Its own function, so that
 // the lane-role tables live in registers for exactly this loop (nothing survives the call to jacobian_chunk).
-template <typename real>
+// NH = 7: plain state differences; NH = 6: error coordinates (records reduced by jacobian_chunk).
+template <typename real, int NH>
 TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, real rho, real dV1, real dV2) {
+  constexpr int ES = (NH == 6) ? 1 : 0;
+  constexpr int RECS = BwdCfg<ES>::RECS;
+  constexpr int NC = NH + 3;               // columns of [A|B]
+  constexpr int NP = NH * (NH + 1) / 2;    // unique entries of a symmetric NH x NH block
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
   // ---- lane roles. Every step is branch-free: each lane owns LDS offsets for its operands and outputs; lanes
   // without a role in a step compute on harmless operands and write to L_SINK. -----------------------------
-  // step 1: W~[r1][c1] = sum_m S~[r1][m] F[m][c1], plus columns 8,9 on the lanes with c1 < 2
+  // step 1: W~[r1][c1] = sum_m S~[r1][m] F[m][c1] (row NH of S~ is s'), plus columns >= 8 on the lanes with small c1
   const int r1 = lane & 7, c1 = lane >> 3;
-  const int s1_st = L_ST + r1 * 9;
-  const int s1_fa = c1 * FS, s1_fb = (8 + (c1 & 1)) * FS;         // relative to the knot record
-  const int s1_oa = L_WT + c1 * 9 + r1;
-  const int s1_ob = (c1 < 2) ? (L_WT + (8 + c1) * 9 + r1) : L_SINK;
-  // step 2: acc = diag + init + dot(F[:,colA], opB[0..6]) -> lds[o1], lds[o2]
+  const int r1c = (r1 <= NH) ? r1 : NH;
+  const int s1_st = L_ST + r1c * 9;
+  const int s1_fa = c1 * FS, s1_fb = ((8 + (c1 & 1) < NC) ? (8 + (c1 & 1)) : 0) * FS;   // relative to the knot record
+  const int s1_oa = (r1 <= NH) ? (L_WT + c1 * 9 + r1) : L_SINK;
+  const int s1_ob = (r1 <= NH && 8 + c1 < NC) ? (L_WT + (8 + c1) * 9 + r1) : L_SINK;
+  // step 2: acc = diag + init + dot(F[:,colA], opB[0..NH-1]) -> lds[o1], lds[o2]
   int s2_fa = 0, s2_b = L_WT, s2_init = -1, s2_o1 = L_SINK, s2_o2 = L_SINK;
   real s2_diag = 0;
-  if (lane < 28) {                                   // Qxx(i,j), i <= j  = Q + A'SA
-    int i, j; pair28(lane, i, j);
+  if (lane < NP) {                                   // Qxx(i,j), i <= j  = lxx + A'SA
+    int i, j; pair_ut(lane, NH, i, j);
     s2_fa = i * FS; s2_b = L_WT + j * 9; s2_o1 = L_HXX + i * 7 + j; s2_o2 = L_HXX + j * 7 + i;
-    if (i == j) s2_diag = lds[L_TR + P_QD + i];
-  } else if (lane < 49) {                            // Qux(a,j) = B'SA
-    const int aa = (lane - 28) / 7, j = (lane - 28) % 7;
-    s2_fa = (7 + aa) * FS; s2_b = L_WT + j * 9; s2_o1 = s2_o2 = L_HUX + aa * 8 + j;
-  } else if (lane < 55) {                            // Quu(a,b), a <= b = luu + B'SB
-    const int L = lane - 49;                         // (0,0)(0,1)(0,2)(1,1)(1,2)(2,2)
+    if (ES) {   // projected Hessian: diag(Qd[0:3]) on the rate block, G'QG (per-knot record) on the attitude block
+      if (i == j && i < 3) s2_diag = lds[L_TR + P_QD + i];
+      if (i >= 3) { const int a = i - 3, b = j - 3; s2_init = R_QQ + (a == 0 ? b : (a == 1 ? 2 + b : 5)); }
+    } else if (i == j) {
+      s2_diag = lds[L_TR + P_QD + i];
+    }
+  } else if (lane < NP + 3 * NH) {                   // Qux(a,j) = B'SA
+    const int aa = (lane - NP) / NH, j = (lane - NP) % NH;
+    s2_fa = (NH + aa) * FS; s2_b = L_WT + j * 9; s2_o1 = s2_o2 = L_HUX + aa * 8 + j;
+  } else if (lane < NP + 3 * NH + 6) {               // Quu(a,b), a <= b = luu + B'SB
+    const int L = lane - (NP + 3 * NH);              // (0,0)(0,1)(0,2)(1,1)(1,2)(2,2)
     const int aa = (L < 3) ? 0 : (L < 5 ? 1 : 2);
     const int bb = (L < 3) ? L : (L < 5 ? L - 2 : 2);
-    s2_fa = (7 + aa) * FS; s2_b = L_WT + (7 + bb) * 9; s2_o1 = L_HUU + aa * 3 + bb; s2_o2 = L_HUU + bb * 3 + aa;
+    s2_fa = (NH + aa) * FS; s2_b = L_WT + (NH + bb) * 9; s2_o1 = L_HUU + aa * 3 + bb; s2_o2 = L_HUU + bb * 3 + aa;
     if (aa == bb) s2_init = R_LUU + aa;
-  } else if (lane < 58) {                            // Qu(a) = lu + B's'  -> Hux[a][7]
-    const int aa = lane - 55;
-    s2_fa = (7 + aa) * FS; s2_b = L_ST + 7 * 9; s2_init = R_LU + aa; s2_o1 = s2_o2 = L_HUX + aa * 8 + 7;
+  } else if (lane < NP + 3 * NH + 9) {               // Qu(a) = lu + B's'  -> Hux[a][7]
+    const int aa = lane - (NP + 3 * NH + 6);
+    s2_fa = (NH + aa) * FS; s2_b = L_ST + NH * 9; s2_init = R_LU + aa; s2_o1 = s2_o2 = L_HUX + aa * 8 + 7;
   }
-  // step 3: K[a3][j3] (j3 == 7: d[a3]) on the lanes with a3 < 3
+  // step 3: K[a3][j3] (j3 == 7: d[a3]) on the lanes with a3 < 3; with NH = 6 the unused gain column 6 is written as 0
   const int a3 = lane >> 3, j3 = lane & 7;
   const int a3c = (a3 < 3) ? a3 : 2;
+  const bool s3_live = (j3 < NH) || (j3 == 7);
   const int s3_o = (a3 < 3) ? (L_KD + a3 * 8 + j3) : L_SINK;
   const int s3_slot = (a3 < 3) ? ((j3 < 7) ? (a3 * 7 + j3) : (21 + a3)) : -1;   // position inside the K,d record
-  // step 4: S(i,j), i <= j on lanes 0..27; s(i) on lanes 28..34 written as the "column 7" of the same formula
+  // step 4: S(i,j), i <= j on lanes 0..NP-1; s(i) on the next NH lanes written as the "column 7" of the same formula
   int i4 = 0, j4 = 0, s4_b1 = L_ZERO, s4_b1rel = -1, s4_b2 = L_ZERO, s4_o1 = L_SINK, s4_o2 = L_SINK;
-  if (lane < 28) {
-    pair28(lane, i4, j4);
+  if (lane < NP) {
+    pair_ut(lane, NH, i4, j4);
     s4_b1 = L_HXX + i4 * 7 + j4; s4_o1 = L_ST + i4 * 9 + j4; s4_o2 = L_ST + j4 * 9 + i4;
-  } else if (lane < 35) {
-    i4 = lane - 28; j4 = 7;
-    s4_b1rel = R_LX + i4; s4_b2 = L_WT + i4 * 9 + 7; s4_o1 = s4_o2 = L_ST + 7 * 9 + i4;
+  } else if (lane < NP + NH) {
+    i4 = lane - NP; j4 = 7;
+    s4_b1rel = R_LX + i4; s4_b2 = L_WT + i4 * 9 + NH; s4_o1 = s4_o2 = L_ST + NH * 9 + i4;
   }
   const int s4_hi = L_HUX + i4, s4_hj = L_HUX + j4, s4_ki = L_KD + i4, s4_kj = L_KD + j4;
 
   bool pd_ok = true;
   for (int l = nk - 1; l >= 0; --l) {
     const int rcb = L_REC + l * RECS;
-    // step 1: W~ = [S; s'] [A|B]   (8 x 10)
+    // step 1: W~ = [S; s'] [A|B]   ((NH+1) x (NH+3))
     {
-      real sv[7], fa[7], fb[7];
-      for (int m = 0; m < 7; ++m) { sv[m] = lds[s1_st + m]; fa[m] = lds[rcb + s1_fa + m]; fb[m] = lds[rcb + s1_fb + m]; }
-      TSAT_SCHED_FENCE();   // all 21 reads in flight before the first FMA: one LDS latency per step, not seven
+      real sv[NH], fa[NH], fb[NH];
+      for (int m = 0; m < NH; ++m) { sv[m] = lds[s1_st + m]; fa[m] = lds[rcb + s1_fa + m]; fb[m] = lds[rcb + s1_fb + m]; }
+      TSAT_SCHED_FENCE();   // all reads in flight before the first FMA: one LDS latency per step, not seven
       real acc = 0, acc2 = 0;
-      for (int m = 0; m < 7; ++m) { acc += sv[m] * fa[m]; acc2 += sv[m] * fb[m]; }
+      for (int m = 0; m < NH; ++m) { acc += sv[m] * fa[m]; acc2 += sv[m] * fb[m]; }
       lds[s1_oa] = acc;
       lds[s1_ob] = acc2;
     }
     TSAT_SYNC_LDS();
     // step 2: Qxx = Q + A'SA, Qux = B'SA, Quu = luu + B'SB, Qu = lu + B's
     {
-      real fa[7], wb[7];
+      real fa[NH], wb[NH];
       const real ini = lds[(s2_init >= 0) ? (rcb + s2_init) : L_ZERO];
-      for (int m = 0; m < 7; ++m) { fa[m] = lds[rcb + s2_fa + m]; wb[m] = lds[s2_b + m]; }
+      for (int m = 0; m < NH; ++m) { fa[m] = lds[rcb + s2_fa + m]; wb[m] = lds[s2_b + m]; }
       TSAT_SCHED_FENCE();
       real acc = s2_diag + ini;
-      for (int m = 0; m < 7; ++m) acc += fa[m] * wb[m];
+      for (int m = 0; m < NH; ++m) acc += fa[m] * wb[m];
       lds[s2_o1] = acc;
       lds[s2_o2] = acc;
     }
@@ -772,7 +847,8 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
       const real Qi0 = ((a3c == 0) ? c00 : (a3c == 1 ? c01 : c02)) * nid;
       const real Qi1 = ((a3c == 0) ? c01 : (a3c == 1 ? c11 : c12)) * nid;
       const real Qi2 = ((a3c == 0) ? c02 : (a3c == 1 ? c12 : c22)) * nid;
-      const real v = Qi0 * h0 + Qi1 * h1 + Qi2 * h2;
+      const real vv = Qi0 * h0 + Qi1 * h1 + Qi2 * h2;
+      const real v = s3_live ? vv : (real)0;
       lds[s3_o] = v;
       if (s3_slot >= 0) KDg[(size_t)(k0 + l) * KDW + s3_slot] = v;   // stays in flight: no vmcnt wait in this loop
     }
@@ -816,40 +892,68 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
   return out;
 }
 
-template <typename real, int INTEG, int DIAGJ>
+template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu, real rho, int term_mask) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
-  // terminal cost-to-go: Sxx = Qf + mu*mask, Sx = Qf e + mask (nu + mu e)   (Appendix A backward)
+  // terminal cost-to-go: Sxx = Qf + mu*mask, Sx = Qf e + mask (nu + mu e)   (Appendix A backward); in error
+  // coordinates both are projected through E(q_N): E'SxxE, E'Sx (src/quaternion_toolbox.jl:38-50)
   {
+    constexpr int NH = BwdCfg<ES>::NH;
     const int r1 = lane & 7, c1 = lane >> 3;
     const TSAT_GLOBAL real* xN = p.XU + (size_t)(N - 1) * XUW;
-    if (c1 < 7) {
-      real v = 0;
-      const real qf = lds[L_TR + P_QFD + c1];
-      const real e = xN[c1] - lds[L_TR + P_XF + c1];
-      const bool m = (term_mask >> c1) & 1;
-      if (r1 < 7) {
-        if (r1 == c1) v = qf + (m ? mu : (real)0);
-      } else {
-        v = qf * e + (m ? (lds[L_NU + c1] + mu * e) : (real)0);
+    if (!ES) {
+      if (c1 < 7) {
+        real v = 0;
+        const real qf = lds[L_TR + P_QFD + c1];
+        const real e = xN[c1] - lds[L_TR + P_XF + c1];
+        const bool m = (term_mask >> c1) & 1;
+        if (r1 < 7) {
+          if (r1 == c1) v = qf + (m ? mu : (real)0);
+        } else {
+          v = qf * e + (m ? (lds[L_NU + c1] + mu * e) : (real)0);
+        }
+        lds[L_ST + r1 * 9 + c1] = v;
       }
-      lds[L_ST + r1 * 9 + c1] = v;
+    } else if (c1 < NH && r1 <= NH) {
+      // E(q_N) column c: identity on the rate block, G(q_N) on the attitude block
+      const real sq = xN[3], v0 = xN[4], v1 = xN[5], v2 = xN[6];
+      const real G[4][3] = {{-v0, -v1, -v2}, {sq, -v2, v1}, {v2, sq, -v0}, {-v1, v0, sq}};
+      real acc = 0;
+      for (int m = 0; m < 7; ++m) {
+        const real qf = lds[L_TR + P_QFD + m];
+        const real e = xN[m] - lds[L_TR + P_XF + m];
+        const bool msk = (term_mask >> m) & 1;
+        const real sd = qf + (msk ? mu : (real)0);
+        const real sf = qf * e + (msk ? (lds[L_NU + m] + mu * e) : (real)0);
+        real ec = 0, er = 0;   // E[m][c1], E[m][r1]
+        for (int t = 0; t < 3; ++t) {
+          const real em = (m < 3) ? ((m == t) ? (real)1 : (real)0) : (real)0;
+          const real gm = (m >= 3) ? G[m >= 3 ? m - 3 : 0][t] : (real)0;
+          if (c1 == t) ec = em;
+          if (c1 == 3 + t) ec = gm;
+          if (r1 == t) er = em;
+          if (r1 == 3 + t) er = gm;
+        }
+        acc += (r1 < NH) ? (er * sd * ec) : (sf * ec);
+      }
+      lds[L_ST + r1 * 9 + c1] = acc;
     }
     if (lane == 0) { lds[L_ZERO] = 0; lds[L_SINK] = 0; }
   }
   BwdOut<real> acc;
   acc.dV1 = 0; acc.dV2 = 0; acc.pd_ok = 1;
   TSAT_SYNC();
+  constexpr int CHB = BwdCfg<ES>::CHB;
   const int nchunks = (N - 1 + CHB - 1) / CHB;
   for (int ch = nchunks - 1; ch >= 0 && acc.pd_ok; --ch) {
     const int k0 = ch * CHB;
     const int nk = (N - 1 - k0 < CHB) ? (N - 1 - k0) : CHB;
     const unsigned long long t_j0 = tick_();
-    jacobian_chunk<real, INTEG, DIAGJ>(p, N, n_tab, k0, nk, mu);
+    jacobian_chunk<real, INTEG, DIAGJ, ES>(p, N, n_tab, k0, nk, mu);
     TSAT_SYNC();
     const unsigned long long t_j1 = tick_();
-    acc = riccati_chunk<real>(p.KD, k0, nk, rho, acc.dV1, acc.dV2);
+    acc = riccati_chunk<real, BwdCfg<ES>::NH>(p.KD, k0, nk, rho, acc.dV1, acc.dV2);
     TSAT_SYNC();
 #ifdef TSAT_PROFILE
     if (lane == 0) {
@@ -948,7 +1052,7 @@ TSAT_PHASE real adopt_and_gradient(TPtrs<real> p, int N, int jw) {
 // --------------------------------------------------------------------------------------------------
 // the whole AL-iLQR solve of one trajectory by one wavefront
 // --------------------------------------------------------------------------------------------------
-template <typename real, int INTEG, int DIAGJ>
+template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
@@ -984,7 +1088,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   unsigned long long pc_fwd = 0, pc_par = 0;
 
   // open-loop rollout of U0
-  FwdOut<real> f0 = forward_sweep<real, INTEG, DIAGJ>(p, N, n_tab, 0, 1, 0, mu, tmask, max_state);
+  FwdOut<real> f0 = forward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, 0, 1, 0, mu, tmask, max_state);
   n_forward++;
   const real J0 = wave_bcast(f0.J, 0, lds + L_RED);
   const int ok0 = wave_first<real>(!f0.ok, lds + L_RED) > 0;  // lane 0 ok?
@@ -1003,7 +1107,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
         BwdOut<real> bw;
         for (;;) {
           n_backward++;
-          bw = backward_sweep<real, INTEG, DIAGJ>(p, N, n_tab, mu, rho, tmask);
+          bw = backward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, mu, rho, tmask);
           if (bw.pd_ok) break;
           bp_restarts++;
           drho = (drho * (real)o.reg_scale > (real)o.reg_scale) ? drho * (real)o.reg_scale : (real)o.reg_scale;
@@ -1023,7 +1127,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
         // all backtracking trials in one sweep
         const unsigned long long t_f0 = tick_();
         const int n_store = (o.max_linesearch < a.max_ls) ? o.max_linesearch : a.max_ls;
-        const FwdOut<real> fw = forward_sweep<real, INTEG, DIAGJ>(p, N, n_tab, 1, n_store, 0, mu, tmask, max_state);
+        const FwdOut<real> fw = forward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, 1, n_store, 0, mu, tmask, max_state);
         const unsigned long long t_f1 = tick_();
         pc_fwd += t_f1 - t_f0;
         n_forward++;
@@ -1042,7 +1146,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
           ls_trials += jw + 1;
           int slot = jw;
           if (jw >= n_store) {   // the winner's rollout was not kept: roll out that one alpha again, into slot 0
-            (void)forward_sweep<real, INTEG, DIAGJ>(p, N, n_tab, 1, 1, jw, mu, tmask, max_state);
+            (void)forward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, 1, 1, jw, mu, tmask, max_state);
             n_forward++;
             slot = 0;
             TSAT_SYNC();

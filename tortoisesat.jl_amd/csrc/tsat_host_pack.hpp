@@ -42,7 +42,7 @@ inline std::string check_options(const tsat_options& o, int N, int n_tab, int ma
   if (n_tab < 1) return "n_tab must be >= 1";
   if (o.integrator != 3 && o.integrator != 4) return "integrator must be 3 (rk3) or 4 (rk4)";
   if (o.precision != 64) return "only precision = 64 is implemented";
-  if (o.error_state != 0) return "error_state = 1 is reserved (not implemented)";
+  if (o.error_state != 0 && o.error_state != 1) return "error_state must be 0 or 1";
   if (o.max_linesearch < 1 || o.max_linesearch > TSAT_MAX_LINESEARCH) return "max_linesearch must be in [1,32]";
   if (o.max_linesearch > max_ls_reserved) return "max_linesearch exceeds the reserved candidate slots";
   if (o.max_outer < 1 || o.max_inner < 1) return "iteration budgets must be >= 1";

@@ -15,11 +15,11 @@ using namespace tsat;
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-template <typename real, int INTEG, int DIAGJ>
+template <typename real, int INTEG, int DIAGJ, int ES>
 __global__ __launch_bounds__(64) void tsat_solve_kernel(KArgs<real> a) {
   const int traj = blockIdx.x;
   if (traj >= a.T) return;
-  solve_trajectory<real, INTEG, DIAGJ>(a, traj);
+  solve_trajectory<real, INTEG, DIAGJ, ES>(a, traj);
 }
 
 template <typename real>
@@ -222,9 +222,14 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
   a.XU = h->XU; a.KD = h->KD; a.LAM = h->LAM; a.CAND = h->CAND;
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
   // LDS is a static module-level array (tsat_device.hpp): nothing dynamic to request at launch
-  auto kern = (o->integrator == 3)
-                  ? (h->diag_inertia ? tsat_solve_kernel<double, 3, 1> : tsat_solve_kernel<double, 3, 0>)
-                  : (h->diag_inertia ? tsat_solve_kernel<double, 4, 1> : tsat_solve_kernel<double, 4, 0>);
+  // kernel variant: integrator x diagonal-inertia fast path x error-state mode
+  using kern_t = void (*)(KArgs<double>);
+  static const kern_t variants[2][2][2] = {
+      {{tsat_solve_kernel<double, 3, 0, 0>, tsat_solve_kernel<double, 3, 0, 1>},
+       {tsat_solve_kernel<double, 3, 1, 0>, tsat_solve_kernel<double, 3, 1, 1>}},
+      {{tsat_solve_kernel<double, 4, 0, 0>, tsat_solve_kernel<double, 4, 0, 1>},
+       {tsat_solve_kernel<double, 4, 1, 0>, tsat_solve_kernel<double, 4, 1, 1>}}};
+  const kern_t kern = variants[o->integrator == 4 ? 1 : 0][h->diag_inertia ? 1 : 0][o->error_state ? 1 : 0];
   if (h->trace) TSAT_HIP(h, hipMemsetAsync(h->trace, 0, (size_t)h->T * h->trace_rows * 8 * sizeof(double), h->stream));
   TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(kern, dim3((unsigned)h->T), dim3(64), 0, h->stream, a);

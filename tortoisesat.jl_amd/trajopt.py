@@ -42,12 +42,36 @@ class DerivFunction:
     rows_per_knot: float = None   # d(row)/d(knot); None -> n_tab / N (physically consistent playback)
 
 
+def quaternion_error(X1, X2):
+    """Marker for the reference's state-difference hook (src/quaternion_toolbox.jl:58-75); evaluated on the GPU."""
+    raise NotImplementedError("hook marker: pass it to Model(...); the HIP kernel evaluates it")
+
+
+def quaternion_expansion(cost, x, u=None):
+    """Marker for the reference's cost-expansion hook (src/quaternion_toolbox.jl:15-50); evaluated on the GPU."""
+    raise NotImplementedError("hook marker: pass it to Model(...); the HIP kernel evaluates it")
+
+
 @dataclass
 class Model:
+    """Model(f!, n, m) (src/TortoiseSat.jl:145) or Model(f!, n, m, quaternion_error, quaternion_expansion)
+    (src/monte_carlo.jl:158): passing both hooks selects the kernel's error-state mode."""
+
     f: DerivFunction
     n: int = 8
     m: int = 3
+    state_diff: object = None
+    cost_expansion: object = None
     integrator: int = 0           # 0 = continuous; 3 / 4 after rk3 / rk4
+
+    @property
+    def error_state(self):
+        hooks = (self.state_diff is quaternion_error, self.cost_expansion is quaternion_expansion)
+        if any(hooks) and not all(hooks):
+            raise ValueError("pass both quaternion_error and quaternion_expansion, or neither (src/monte_carlo.jl:158)")
+        if (self.state_diff is not None or self.cost_expansion is not None) and not all(hooks):
+            raise ValueError("only the reference's quaternion hooks are implemented on the GPU")
+        return 1 if all(hooks) else 0
 
     def __post_init__(self):
         if self.n not in (7, 8) or self.m != 3:
@@ -56,11 +80,11 @@ class Model:
 
 def rk3(model):
     """TrajectoryOptimization.rk3(model) (src/TortoiseSat.jl:146)."""
-    return Model(model.f, model.n, model.m, 3)
+    return Model(model.f, model.n, model.m, model.state_diff, model.cost_expansion, 3)
 
 
 def rk4(model):
-    return Model(model.f, model.n, model.m, 4)
+    return Model(model.f, model.n, model.m, model.state_diff, model.cost_expansion, 4)
 
 
 @dataclass
@@ -186,7 +210,7 @@ class AugmentedLagrangianSolverOptions:
     dual_max: float = 1e8
     opts_uncon: _UnconOptions = field(default_factory=_UnconOptions)
 
-    def to_abi(self, N, n_tab, integrator, terminal_mask=0x7F, u_scale=1e-2):
+    def to_abi(self, N, n_tab, integrator, terminal_mask=0x7F, u_scale=1e-2, error_state=0):
         o = _abi.Options()
         _abi.load().tsat_default_options(C.byref(o))
         u = self.opts_uncon
@@ -199,7 +223,7 @@ class AugmentedLagrangianSolverOptions:
         o.reg_init, o.reg_scale, o.reg_min, o.reg_max, o.reg_fp = (
             u.bp_reg_initial, u.bp_reg_increase_factor, u.bp_reg_min, u.bp_reg_max, u.bp_reg_fp)
         o.ls_lower, o.ls_upper, o.max_state = u.line_search_lower_bound, u.line_search_upper_bound, u.max_state_value
-        o.u_scale, o.terminal_mask, o.error_state = u_scale, terminal_mask, 0
+        o.u_scale, o.terminal_mask, o.error_state = u_scale, terminal_mask, error_state
         return o
 
 
@@ -321,6 +345,7 @@ class BatchProblem:
             raise ValueError("discretise the model with rk3(model) or rk4(model) first (src/TortoiseSat.jl:146)")
         self.problems = problems
         self.integrator = integ
+        self.error_state = p0.model.error_state
         self.terminal_mask = _terminal_mask(p0)
         T = len(problems)
         tabs, idx, seen = [], np.zeros(T, np.int32), {}
@@ -329,7 +354,8 @@ class BatchProblem:
         ulo = np.zeros((T, 3)); uhi = np.zeros((T, 3)); U0 = np.zeros((T, N - 1, 3))
         tau0 = np.zeros(T); dtau = np.zeros(T); dt = np.zeros(T)
         for t, p in enumerate(problems):
-            if p.N != N or p.model.integrator != integ or _terminal_mask(p) != self.terminal_mask:
+            if (p.N != N or p.model.integrator != integ or _terminal_mask(p) != self.terminal_mask
+                    or p.model.error_state != self.error_state):
                 raise ValueError("all problems of a batch must share N, integrator and constraint structure")
             f = p.model.f
             key = id(f.B_ECI)
@@ -358,10 +384,11 @@ class BatchProblem:
                                 Qd, Qfd, Rd, ulo, uhi, U0)
 
     @classmethod
-    def from_arrays(cls, batch: SlewBatch, integrator=3, terminal_mask=0x7F):
+    def from_arrays(cls, batch: SlewBatch, integrator=3, terminal_mask=0x7F, error_state=0):
         self = cls.__new__(cls)
         self.problems = None
         self.integrator = integrator
+        self.error_state = error_state
         self.terminal_mask = terminal_mask
         self.arrays = batch
         return self
@@ -374,7 +401,7 @@ def solve_(prob, solver, want_K=True):
     dict (X (T,N,7), U (T,N-1,3), K (T,N-1,7,3), stats)."""
     batch = prob if isinstance(prob, BatchProblem) else BatchProblem([prob])
     b = batch.arrays
-    o = solver.opts.to_abi(b.N, b.n_tab, batch.integrator, batch.terminal_mask)
+    o = solver.opts.to_abi(b.N, b.n_tab, batch.integrator, batch.terminal_mask, error_state=batch.error_state)
     solver.upload(b, o.max_linesearch)
     solver.run(o)
     res = solver.download(want_K=want_K)
