@@ -90,8 +90,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the solve path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # TSAT_BENCH_FORCE_DIST=1 rehearses the RCCL path (init, all-gather, barrier, all-reduce) with a single rank
+    use_dist = world > 1 or os.environ.get("TSAT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from tsat_loader import load_package
@@ -107,7 +111,7 @@ def main():
     solver = to.AugmentedLagrangianSolver(None, opts, device=local_rank)
     abi = opts.to_abi(N, batch.n_tab, 3)
     solver.upload(batch, abi.max_linesearch)          # inputs resident in HBM before the timed region
-    gat = sweep.ResultGather(solver, T, N, world, dev, mode=args.gather)
+    gat = sweep.ResultGather(solver, T, N, world, dev, mode=args.gather, force_collective=use_dist)
 
     def step():
         ms = solver.run(abi)                          # blocks until the solve kernel has finished
@@ -116,7 +120,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -124,11 +128,11 @@ def main():
     for _ in range(args.steps):
         kms.append(step())
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -174,7 +178,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(batch, abi, res, sample, threads)
         print(json.dumps(out), flush=True)
     solver.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

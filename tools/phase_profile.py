@@ -26,5 +26,6 @@ print(f"kernel {ms:.2f} ms (stamped build); mean inner its {it.mean():.1f}")
 for i, name in enumerate(("forward sweep", "jacobian lanes", "riccati", "parallel passes")):
     print(f"  {name:16s}: {tr[:, i].mean()/1e6:8.2f} Mcycles/wave  ({100*tr[:, i].sum()/tot.sum():5.1f} %)  "
           f"per iteration {np.mean(tr[:, i]/np.maximum(it,1))/1e3:8.1f} kcycles; per knot-iteration {np.mean(tr[:, i]/np.maximum(it,1))/N:7.1f} cycles")
+print(f"  slowest wave: {tot.max()/1e6:.1f} Mcycles, {int(it[np.argmax(tot)])} iterations (the launch ends with it); mean wave {tot.mean()/1e6:.1f}")
 print(f"  sum of stamped phases {tot.mean()/1e6:.1f} Mcycles/wave = {tot.mean()/ (ms*1e-3)/1e9:.2f} GHz-equivalent of the kernel time")
 solver.close()

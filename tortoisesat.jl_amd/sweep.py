@@ -77,17 +77,18 @@ class ResultGather:
     """Per-step exchange used by bench.py: unpack the resident batch straight into torch device tensors
     (tsat_batch_export_device) and all-gather them across ranks without touching the host."""
 
-    def __init__(self, solver, T, N, world, device, mode="full", group=None):
+    def __init__(self, solver, T, N, world, device, mode="full", group=None, force_collective=False):
         import torch
 
         self.solver, self.world, self.mode, self.group = solver, world, mode, group
+        self.collective = world > 1 or force_collective
         self.stats = torch.empty((T, _abi.STATS_DTYPE.itemsize), dtype=torch.uint8, device=device)
         self.X = self.U = None
         if mode == "full":
             self.X = torch.empty((T, N, 7), dtype=torch.float64, device=device)
             self.U = torch.empty((T, N - 1, 3), dtype=torch.float64, device=device)
         self.gathered = {}
-        if world > 1 and mode != "none":
+        if self.collective and mode != "none":
             self.gathered["stats"] = torch.empty((world * T, _abi.STATS_DTYPE.itemsize), dtype=torch.uint8, device=device)
             if mode == "full":
                 self.gathered["X"] = torch.empty((world * T, N, 7), dtype=torch.float64, device=device)
@@ -101,7 +102,7 @@ class ResultGather:
         self.solver.export_device(self.X.data_ptr() if self.X is not None else None,
                                   self.U.data_ptr() if self.U is not None else None,
                                   None, self.stats.data_ptr())
-        if self.world == 1:
+        if not self.collective:
             return dict(X=self.X, U=self.U, stats=self.stats)
         dist.all_gather_into_tensor(self.gathered["stats"], self.stats, group=self.group)
         if self.mode == "full":
