@@ -92,6 +92,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     # TSAT_BENCH_FORCE_DIST=1 rehearses the RCCL path (init, all-gather, barrier, all-reduce) with a single rank
     use_dist = world > 1 or os.environ.get("TSAT_BENCH_FORCE_DIST") == "1"
+    # RCCL prints a version banner on stdout when the communicator comes up; the contract is ONE JSON line on stdout,
+    # so stdout is pointed at stderr until the result line is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -176,7 +181,10 @@ def main():
             sample = min(args.cpu_sample, T)
             threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
             out["cpu_baseline"] = cpu_baseline(batch, abi, res, sample, threads)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     solver.close()
     if use_dist:
         dist.barrier()
