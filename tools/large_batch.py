@@ -1,0 +1,32 @@
+"""Developer tool: timing of larger resident batches (configs[2]/[3] shapes, fp64) on one GPU."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from tsat_loader import load_package
+load_package()
+from tortoisesat_jl_amd import trajopt as to, slew_setup as ss
+
+def run(name, b, outer, inner, es=0):
+    opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = outer
+    opts.opts_uncon.iterations = inner; opts.opts_uncon.dJ_counter_limit = 1
+    s = to.AugmentedLagrangianSolver(None, opts)
+    o = opts.to_abi(b.N, b.n_tab, 3, error_state=es)
+    t = time.time(); s.upload(b, o.max_linesearch); up = time.time() - t
+    ms = s.run(o); ms = s.run(o)
+    st = s.download(want_K=False)["stats"]
+    print(f"{name}: T={b.T} N={b.N} {outer}x{inner} es={es}: kernel {ms:.1f} ms -> {b.T/(ms*1e-3):.0f} solves/s; upload {up:.2f} s; "
+          f"HBM {s.reserved_bytes()/2**30:.2f} GiB; status {np.bincount(st['status'], minlength=4)}; mean inner {st['inner_iters'].mean():.1f}", flush=True)
+    s.close()
+
+if __name__ == "__main__":
+    base = ss.workload_monte_carlo(T=1024, N=1000)
+    run("configs[1]", base, 5, 10)
+    run("configs[1] + quaternion hooks", base, 5, 10, es=1)
+    # larger batches re-use the 1024 draws (tiling) so that host-side setup stays cheap; tables are per trajectory
+    rep = lambda a, k: np.ascontiguousarray(np.concatenate([a] * k))
+    for k, nm in ((8, "configs[3] shard (8192 / GPU), budget 3x50"), (16, "configs[2] shape (16384), fp64")):
+        b = ss.workload_monte_carlo(T=1024, N=1000, seed=20190531, random_orbit=True)
+        big = ss.SlewBatch(b.N, b.n_tab, rep(b.x0, k), rep(b.xf, k), b.Btab, rep(b.btab_idx, k), rep(b.tau0, k), rep(b.dtau, k),
+                           rep(b.dt, k), rep(b.Jmat, k), rep(b.Qd, k), rep(b.Qfd, k), rep(b.Rd, k), rep(b.ulo, k), rep(b.uhi, k), rep(b.U0, k))
+        run(nm, big, 3 if k == 8 else 5, 50 if k == 8 else 10)
