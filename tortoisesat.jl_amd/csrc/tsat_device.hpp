@@ -801,40 +801,56 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
   }
   const int s4_hi = L_HUX + i4, s4_hj = L_HUX + j4, s4_ki = L_KD + i4, s4_kj = L_KD + j4;
 
+  // The recursion is software-pipelined by hand: in every step the reads that depend on the previous step are issued
+  // first, then the reads that do not (operands of later steps, the next knot's Jacobian columns), then a scheduling
+  // fence, then the arithmetic. LDS returns data in issue order, so the arithmetic waits only for the dependent
+  // reads while the prefetches ride along under it.
   bool pd_ok = true;
+  real fa1[NH], fb1[NH], fa2[NH], ini2;
+  {
+    const int rcb = L_REC + (nk - 1) * RECS;
+    for (int m = 0; m < NH; ++m) { fa1[m] = lds[rcb + s1_fa + m]; fb1[m] = lds[rcb + s1_fb + m]; fa2[m] = lds[rcb + s2_fa + m]; }
+    ini2 = lds[(s2_init >= 0) ? (rcb + s2_init) : L_ZERO];
+  }
   for (int l = nk - 1; l >= 0; --l) {
     const int rcb = L_REC + l * RECS;
     // step 1: W~ = [S; s'] [A|B]   ((NH+1) x (NH+3))
     {
-      real sv[NH], fa[NH], fb[NH];
-      for (int m = 0; m < NH; ++m) { sv[m] = lds[s1_st + m]; fa[m] = lds[rcb + s1_fa + m]; fb[m] = lds[rcb + s1_fb + m]; }
-      TSAT_SCHED_FENCE();   // all reads in flight before the first FMA: one LDS latency per step, not seven
+      real sv[NH];
+      for (int m = 0; m < NH; ++m) sv[m] = lds[s1_st + m];
+      TSAT_SCHED_FENCE();
       real acc = 0, acc2 = 0;
-      for (int m = 0; m < NH; ++m) { acc += sv[m] * fa[m]; acc2 += sv[m] * fb[m]; }
+      for (int m = 0; m < NH; ++m) { acc += sv[m] * fa1[m]; acc2 += sv[m] * fb1[m]; }
       lds[s1_oa] = acc;
       lds[s1_ob] = acc2;
     }
     TSAT_SYNC_LDS();
-    // step 2: Qxx = Q + A'SA, Qux = B'SA, Quu = luu + B'SB, Qu = lu + B's
+    // step 2: Qxx = lxx + A'SA, Qux = B'SA, Quu = luu + B'SB, Qu = lu + B's
     {
-      real fa[NH], wb[NH];
-      const real ini = lds[(s2_init >= 0) ? (rcb + s2_init) : L_ZERO];
-      for (int m = 0; m < NH; ++m) { fa[m] = lds[rcb + s2_fa + m]; wb[m] = lds[s2_b + m]; }
+      real wb[NH];
+      for (int m = 0; m < NH; ++m) wb[m] = lds[s2_b + m];
       TSAT_SCHED_FENCE();
-      real acc = s2_diag + ini;
-      for (int m = 0; m < NH; ++m) acc += fa[m] * wb[m];
+      real acc = s2_diag + ini2;
+      for (int m = 0; m < NH; ++m) acc += fa2[m] * wb[m];
       lds[s2_o1] = acc;
       lds[s2_o2] = acc;
     }
     TSAT_SYNC_LDS();
     // step 3: regularise, PD test (Sylvester), adjugate inverse, K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu
+    real hu[9], qu0, qu1, qu2, hi[3], hj[3], b1, b2;
     {
       const real* Huu = lds + L_HUU;
       const real* Hux = lds + L_HUX;
-      const real q00 = Huu[0] + rho, q11 = Huu[4] + rho, q22 = Huu[8] + rho;
-      const real q10 = Huu[1], q20 = Huu[2], q21 = Huu[5];
+      for (int c = 0; c < 9; ++c) hu[c] = Huu[c];
       const real h0 = Hux[0 * 8 + j3], h1 = Hux[1 * 8 + j3], h2 = Hux[2 * 8 + j3];
+      // prefetch for step 4 (all produced by step 2): Qu, the Qux columns i and j, the base terms
+      qu0 = lds[L_HUX + 7]; qu1 = lds[L_HUX + 15]; qu2 = lds[L_HUX + 23];
+      for (int c = 0; c < 3; ++c) { hi[c] = lds[s4_hi + c * 8]; hj[c] = lds[s4_hj + c * 8]; }
+      b1 = lds[(s4_b1rel >= 0) ? (rcb + s4_b1rel) : s4_b1];
+      b2 = lds[s4_b2];
       TSAT_SCHED_FENCE();
+      const real q00 = hu[0] + rho, q11 = hu[4] + rho, q22 = hu[8] + rho;
+      const real q10 = hu[1], q20 = hu[2], q21 = hu[5];
       const real c00 = q11 * q22 - q21 * q21;
       const real c01 = q20 * q21 - q10 * q22;
       const real c02 = q10 * q21 - q20 * q11;
@@ -859,14 +875,13 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
     //   Sxx = Qxx + sym(Qux'K) - rho K'K ;  Sx = Qx + sym(Qux'd, Qu'K) - rho K'd   (Appendix A, compacted;
     //   Qux'd = Qu'K in exact arithmetic, so the s-lanes run the very same formula with j = "column 7")
     {
-      const real* Huu = lds + L_HUU;
+      real ki[3], kj[3];
       const real d0 = lds[L_KD + 7], d1 = lds[L_KD + 15], d2 = lds[L_KD + 23];
-      const real qu0 = lds[L_HUX + 7], qu1 = lds[L_HUX + 15], qu2 = lds[L_HUX + 23];
-      real hu[9], hi[3], hj[3], ki[3], kj[3];
-      for (int c = 0; c < 9; ++c) hu[c] = Huu[c];
-      const real b1 = lds[(s4_b1rel >= 0) ? (rcb + s4_b1rel) : s4_b1], b2 = lds[s4_b2];
-      for (int c = 0; c < 3; ++c) {
-        hi[c] = lds[s4_hi + c * 8]; hj[c] = lds[s4_hj + c * 8]; ki[c] = lds[s4_ki + c * 8]; kj[c] = lds[s4_kj + c * 8];
+      for (int c = 0; c < 3; ++c) { ki[c] = lds[s4_ki + c * 8]; kj[c] = lds[s4_kj + c * 8]; }
+      if (l > 0) {   // prefetch the next knot's Jacobian columns (written by jacobian_chunk, never by this loop)
+        const int rcn = rcb - RECS;
+        for (int m = 0; m < NH; ++m) { fa1[m] = lds[rcn + s1_fa + m]; fb1[m] = lds[rcn + s1_fb + m]; fa2[m] = lds[rcn + s2_fa + m]; }
+        ini2 = lds[(s2_init >= 0) ? (rcn + s2_init) : L_ZERO];
       }
       TSAT_SCHED_FENCE();
       dV1 += d0 * qu0 + d1 * qu1 + d2 * qu2;
