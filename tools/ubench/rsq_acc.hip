@@ -13,6 +13,8 @@ __global__ void k(const double* s, double* o, int n) {
   double r0 = __builtin_amdgcn_rcp(x);
   double r1 = r0 * __builtin_fma(-x, r0, 2.0);
   double r2 = r1 * __builtin_fma(-x, r1, 2.0);
+  { double e3 = __builtin_fma(-(x * y0), y0, 1.0); double p3 = __builtin_fma(0.375, e3, 0.5) * e3; y2 = __builtin_fma(y0, p3, y0); }
+  { double e3 = __builtin_fma(-x, r0, 1.0); double p3 = __builtin_fma(e3, e3, e3); r2 = __builtin_fma(r0, p3, r0); }
   o[6 * i] = y0; o[6 * i + 1] = y1; o[6 * i + 2] = y2; o[6 * i + 3] = r0; o[6 * i + 4] = r1; o[6 * i + 5] = r2;
 }
 int main() {
@@ -28,5 +30,5 @@ int main() {
     for (int j = 0; j < 3; ++j) { double e = fabsl((o[6 * i + j] - ry) / ry); if (e > m[j]) m[j] = e; }
     for (int j = 3; j < 6; ++j) { double e = fabsl((o[6 * i + j] - rr) / rr); if (e > m[j]) m[j] = e; }
   }
-  printf("rsq: seed %.3e  1NR %.3e  2NR %.3e\nrcp: seed %.3e  1NR %.3e  2NR %.3e  (eps = 1.1e-16)\n", m[0], m[1], m[2], m[3], m[4], m[5]);
+  printf("rsq: seed %.3e  1 Newton %.3e  1 third-order step %.3e\nrcp: seed %.3e  1 Newton %.3e  1 third-order step %.3e  (eps = 1.1e-16)\n", m[0], m[1], m[2], m[3], m[4], m[5]);
 }

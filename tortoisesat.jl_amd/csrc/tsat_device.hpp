@@ -166,30 +166,34 @@ template <> TSAT_DEV double rsqrt_<double>(double s) { return 1.0 / std::sqrt(s)
 template <> TSAT_DEV float rsqrt_<float>(float s) { return 1.0f / std::sqrt(s); }
 TSAT_DEV double fabs_(double a) { return std::fabs(a); }
 TSAT_DEV double fmax_(double a, double b) { return a > b ? a : b; }   // NaN in b ignored, like v_max
+TSAT_DEV double fmaxabs_(double a, double b) { const double c = std::fabs(b); return a > c ? a : c; }
 TSAT_DEV double floor_(double a) { return std::floor(a); }
 TSAT_DEV double fma_(double a, double b, double c) { return std::fma(a, b, c); }
 TSAT_DEV double rcp_(double a) { return 1.0 / a; }
 #else
-// v_rsq_f64 seed + two Newton steps: ~1 ulp for s in the normal range (|q| is O(1) here)
+// v_rsq_f64 seed (rel. error <= 5.3e-8, profiles/r01/rsq_rcp_accuracy.txt) + ONE third-order step:
+// y (1 + e/2 + 3e^2/8), e = 1 - s y^2  ->  error O(e^3) ~ 1e-22, i.e. rounding only; 5 instructions instead of the 8
+// of two Newton steps
 template <> TSAT_DEV double rsqrt_<double>(double s) {
-  double y = __builtin_amdgcn_rsq(s);
-  double e = s * y * y;
-  y = y * __builtin_fma(-0.5, e, 1.5);
-  e = s * y * y;
-  y = y * __builtin_fma(-0.5, e, 1.5);
-  return y;
+  const double y = __builtin_amdgcn_rsq(s);
+  const double e = __builtin_fma(-(s * y), y, 1.0);
+  const double p = __builtin_fma(0.375, e, 0.5) * e;
+  return __builtin_fma(y, p, y);
 }
 template <> TSAT_DEV float rsqrt_<float>(float s) { return __builtin_amdgcn_rsqf(s); }
 TSAT_DEV double fabs_(double a) { return __builtin_fabs(a); }
-TSAT_DEV double fmax_(double a, double b) { return __builtin_fmax(a, b); }   // v_max_f64; a NaN operand is ignored
+// one v_max_f64 each. (__builtin_fmax costs two: the compiler first canonicalises the operands with an extra
+// v_max_f64 v,v,v; a NaN operand is ignored by the instruction either way, which is what the callers rely on.)
+TSAT_DEV double fmax_(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+TSAT_DEV double fmaxabs_(double a, double b) { double r; asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
 TSAT_DEV double floor_(double a) { return __builtin_floor(a); }
 TSAT_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
-// v_rcp_f64 seed + two Newton steps
+// v_rcp_f64 seed (rel. error <= 4.7e-8) + one third-order step y (1 + e + e^2), e = 1 - a y
 TSAT_DEV double rcp_(double a) {
-  double y = __builtin_amdgcn_rcp(a);
-  y = y * __builtin_fma(-a, y, 2.0);
-  y = y * __builtin_fma(-a, y, 2.0);
-  return y;
+  const double y = __builtin_amdgcn_rcp(a);
+  const double e = __builtin_fma(-a, y, 1.0);
+  const double p = __builtin_fma(e, e, e);
+  return __builtin_fma(y, p, y);
 }
 #endif
 
@@ -617,8 +621,8 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
           u[c] = v + alpha * kd[21 + c];
         }
       }
-      for (int i = 0; i < 7; ++i) amax = fmax_(amax, fabs_(x[i]));
-      for (int c = 0; c < 3; ++c) amax = fmax_(amax, fabs_(u[c]));
+      for (int i = 0; i < 7; ++i) amax = fmaxabs_(amax, x[i]);
+      for (int c = 0; c < 3; ++c) amax = fmaxabs_(amax, u[c]);
       J += stage_cost_gated(tr, hw, x, u, LMc + kk * LMW, GTc + kk * LMW);
       if (lane < n_cand) {
         TSAT_GLOBAL real* cr = Cg + (size_t)(k0 + kk) * XUW;
@@ -632,7 +636,7 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
     }
     TSAT_SYNC_LDS();  // the next chunk's staging writes must not overtake this chunk's LDS reads
   }
-  for (int i = 0; i < 7; ++i) amax = fmax_(amax, fabs_(x[i]));
+  for (int i = 0; i < 7; ++i) amax = fmaxabs_(amax, x[i]);
   real nu[7];
   for (int i = 0; i < 7; ++i) nu[i] = lds[L_NU + i];
   J += term_cost(tr, x, nu, mu, term_mask, true);
