@@ -60,14 +60,12 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
   a.P = P.data(); a.BT = BT.data(); a.bidx = bidx.data(); a.U0 = U0;
   a.XU = XU.data(); a.KD = KD.data(); a.LAM = LAM.data(); a.CAND = CAND.data();
   a.stats = stats; a.trace = trace; a.trace_rows = trace_rows;
-  bool diag = true;   // same variant selection as tsat_batch_upload
-  for (int64_t t = 0; t < T && diag; ++t)
-    for (int i = 0; i < 9; ++i)
-      if (i % 4 != 0 && Jmat[9 * t + i] != 0.0) { diag = false; break; }
+  const int cls = inertia_class(T, Jmat);   // same variant selection as tsat_batch_upload
   using blk_t = void (*)(const KArgs<double>&, int);
-  static const blk_t variants[2][2][2] = {{{run_block<3, 0, 0>, run_block<3, 0, 1>}, {run_block<3, 1, 0>, run_block<3, 1, 1>}},
-                                          {{run_block<4, 0, 0>, run_block<4, 0, 1>}, {run_block<4, 1, 0>, run_block<4, 1, 1>}}};
-  const blk_t blk = variants[o->integrator == 4 ? 1 : 0][diag ? 1 : 0][o->error_state ? 1 : 0];
+  static const blk_t variants[2][3][2] = {
+      {{run_block<3, 0, 0>, run_block<3, 0, 1>}, {run_block<3, 1, 0>, run_block<3, 1, 1>}, {run_block<3, 2, 0>, run_block<3, 2, 1>}},
+      {{run_block<4, 0, 0>, run_block<4, 0, 1>}, {run_block<4, 1, 0>, run_block<4, 1, 1>}, {run_block<4, 2, 0>, run_block<4, 2, 1>}}};
+  const blk_t blk = variants[o->integrator == 4 ? 1 : 0][cls][o->error_state ? 1 : 0];
   for (int t = 0; t < (int)T; ++t) blk(a, t);
   for (int64_t e = 0; e < T * (int64_t)N; ++e) export_record<double>(e, N, XU.data(), KD.data(), X, U, K);
   return 0;

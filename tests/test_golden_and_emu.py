@@ -142,3 +142,13 @@ def test_error_state_is_a_different_iteration_on_the_same_problem(pkg, ol):
         tr = tr[tr[:, 0] > 0]
         assert np.all(tr[:, 3] <= tr[:, 2])
     assert np.all(np.isfinite(r1["X"])) and np.all(r1["K"][:, :, 6, :] == 0)
+
+
+def test_emulated_kernel_diagonal_3u_inertia(pkg, ol, emu):
+    """the three dynamics specialisations: isotropic (1U/1P), diagonal (3U, src/input_parameters.jl:45-51), full"""
+    ss = pkg.slew_setup
+    b = ss.workload_monte_carlo(T=1, N=40, seed=41)
+    b.Jmat[:] = ss.jmat_cm(ss.INERTIA["3U"])
+    for es in (0, 1):
+        o = oracle_options(ol, max_outer=2, max_inner=3, error_state=es)
+        assert_same_solution(ol.solve_batch(b, o), emu.solve(b, o))

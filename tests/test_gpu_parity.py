@@ -132,6 +132,15 @@ def test_gpu_full_inertia_tensor(pkg, ol, solver):
     assert_same_solution(ol.solve_batch(b, o), gpu_solve(pkg, solver, b, o))
 
 
+def test_gpu_diagonal_3u_inertia(pkg, ol, solver):
+    ss = pkg.slew_setup
+    b = ss.workload_monte_carlo(T=4, N=300, seed=41)
+    b.Jmat[:] = ss.jmat_cm(ss.INERTIA["3U"])          # diagonal, not isotropic (src/input_parameters.jl:45-51)
+    for es in (0, 1):
+        o = oracle_options(ol, max_outer=3, max_inner=6, error_state=es)
+        assert_same_solution(ol.solve_batch(b, o, nthreads=4), gpu_solve(pkg, solver, b, o))
+
+
 def test_gpu_failure_statuses(pkg, ol, solver):
     ss, abi = pkg.slew_setup, pkg._abi
     b = ss.workload_monte_carlo(T=2, N=40, seed=5)

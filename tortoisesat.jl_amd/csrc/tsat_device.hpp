@@ -344,13 +344,14 @@ TSAT_DEV void dyn_h(const Traj<real>& tr, const real x[7], const real us[3], con
   const real t1 = us[2] * B0 - us[0] * B2;
   const real t2 = us[0] * B1 - us[1] * B0;
   // wdot = inv(J) (tau_c - w x Jw)  (:41)
-  // every inertia preset of the reference is diagonal (src/input_parameters.jl:29-51): DIAGJ drops the zero terms
+  // every inertia preset of the reference is diagonal (src/input_parameters.jl:29-51): DIAGJ = 1 drops the zero
+  // terms; the 1U and 1P presets are isotropic (J = j I), where w x Jw vanishes identically: DIAGJ = 2 drops it too
   const real Jw0 = DIAGJ ? tr.J[0] * w0 : tr.J[0] * w0 + tr.J[1] * w1 + tr.J[2] * w2;
   const real Jw1 = DIAGJ ? tr.J[4] * w1 : tr.J[3] * w0 + tr.J[4] * w1 + tr.J[5] * w2;
   const real Jw2 = DIAGJ ? tr.J[8] * w2 : tr.J[6] * w0 + tr.J[7] * w1 + tr.J[8] * w2;
-  const real r0 = t0 - (w1 * Jw2 - w2 * Jw1);
-  const real r1 = t1 - (w2 * Jw0 - w0 * Jw2);
-  const real r2 = t2 - (w0 * Jw1 - w1 * Jw0);
+  const real r0 = (DIAGJ == 2) ? t0 : t0 - (w1 * Jw2 - w2 * Jw1);
+  const real r1 = (DIAGJ == 2) ? t1 : t1 - (w2 * Jw0 - w0 * Jw2);
+  const real r2 = (DIAGJ == 2) ? t2 : t2 - (w0 * Jw1 - w1 * Jw0);
   k[0] = DIAGJ ? tr.hJi[0] * r0 : tr.hJi[0] * r0 + tr.hJi[1] * r1 + tr.hJi[2] * r2;
   k[1] = DIAGJ ? tr.hJi[4] * r1 : tr.hJi[3] * r0 + tr.hJi[4] * r1 + tr.hJi[5] * r2;
   k[2] = DIAGJ ? tr.hJi[8] * r2 : tr.hJi[6] * r0 + tr.hJi[7] * r1 + tr.hJi[8] * r2;
@@ -395,9 +396,9 @@ TSAT_DEV void dyn_h_jvp(const Traj<real>& tr, const StageBase<real>& sb, const r
   const real dJ0 = DIAGJ ? tr.J[0] * dw0 : tr.J[0] * dw0 + tr.J[1] * dw1 + tr.J[2] * dw2;
   const real dJ1 = DIAGJ ? tr.J[4] * dw1 : tr.J[3] * dw0 + tr.J[4] * dw1 + tr.J[5] * dw2;
   const real dJ2 = DIAGJ ? tr.J[8] * dw2 : tr.J[6] * dw0 + tr.J[7] * dw1 + tr.J[8] * dw2;
-  const real r0 = t0 - ((dw1 * sb.Jw[2] - dw2 * sb.Jw[1]) + (w1 * dJ2 - w2 * dJ1));
-  const real r1 = t1 - ((dw2 * sb.Jw[0] - dw0 * sb.Jw[2]) + (w2 * dJ0 - w0 * dJ2));
-  const real r2 = t2 - ((dw0 * sb.Jw[1] - dw1 * sb.Jw[0]) + (w0 * dJ1 - w1 * dJ0));
+  const real r0 = (DIAGJ == 2) ? t0 : t0 - ((dw1 * sb.Jw[2] - dw2 * sb.Jw[1]) + (w1 * dJ2 - w2 * dJ1));
+  const real r1 = (DIAGJ == 2) ? t1 : t1 - ((dw2 * sb.Jw[0] - dw0 * sb.Jw[2]) + (w2 * dJ0 - w0 * dJ2));
+  const real r2 = (DIAGJ == 2) ? t2 : t2 - ((dw0 * sb.Jw[1] - dw1 * sb.Jw[0]) + (w0 * dJ1 - w1 * dJ0));
   dk[0] = DIAGJ ? tr.hJi[0] * r0 : tr.hJi[0] * r0 + tr.hJi[1] * r1 + tr.hJi[2] * r2;
   dk[1] = DIAGJ ? tr.hJi[4] * r1 : tr.hJi[3] * r0 + tr.hJi[4] * r1 + tr.hJi[5] * r2;
   dk[2] = DIAGJ ? tr.hJi[8] * r2 : tr.hJi[6] * r0 + tr.hJi[7] * r1 + tr.hJi[8] * r2;

@@ -34,6 +34,19 @@ inline void inertia_inverse_rm(const double* Jcm, double* Jrm, double* Jirm) {
   Jirm[8] = (m(0, 0) * m(1, 1) - m(0, 1) * m(1, 0)) * id;
 }
 
+// inertia class of a batch: 2 = every tensor isotropic (J = j I: the 1U / 1P presets of src/input_parameters.jl:29-43),
+// 1 = every tensor diagonal (3U preset), 0 = general. Selects the dynamics specialisation of the kernel.
+inline int inertia_class(int64_t T, const double* Jmat) {
+  int cls = 2;
+  for (int64_t t = 0; t < T; ++t) {
+    const double* J = Jmat + 9 * t;
+    for (int i = 0; i < 9; ++i)
+      if (i % 4 != 0 && J[i] != 0.0) return 0;
+    if (!(J[0] == J[4] && J[4] == J[8])) cls = 1;
+  }
+  return cls;
+}
+
 // validate an options block against a reserved batch; returns "" or an error text
 inline std::string check_options(const tsat_options& o, int N, int n_tab, int max_ls_reserved) {
   if (o.n_knots != N) return "options.n_knots does not match the reserved batch";

@@ -41,7 +41,7 @@ struct tsat_handle {
   int64_t T = 0, n_btab = 0;
   int N = 0, n_tab = 0, max_ls = 0, trace_rows = 0;
   bool uploaded = false, solved = false;
-  bool diag_inertia = false;  // every uploaded inertia tensor is diagonal -> DIAGJ kernel variant
+  int inertia_class = 0;      // 0 full, 1 every uploaded inertia tensor diagonal, 2 every one isotropic -> DIAGJ variant
   double *P = nullptr, *BT = nullptr, *U0 = nullptr, *XU = nullptr, *KD = nullptr, *LAM = nullptr, *CAND = nullptr;
   int* bidx = nullptr;
   tsat_stats* stats = nullptr;
@@ -193,11 +193,7 @@ int tsat_batch_upload(tsat_handle* h, const double* x0, const double* xf, const 
   }
   for (int64_t t = 0; t < T; ++t)
     if (!(dt[t] > 0.0)) return fail(h, -1, "dt must be positive");
-  bool diag = true;
-  for (int64_t t = 0; t < T && diag; ++t)
-    for (int i = 0; i < 9; ++i)
-      if (i % 4 != 0 && Jmat[9 * t + i] != 0.0) { diag = false; break; }
-  h->diag_inertia = diag;
+  h->inertia_class = inertia_class(T, Jmat);
   std::vector<double> P((size_t)T * PSTRIDE), BT((size_t)h->n_btab * h->n_tab * 4);
   pack_params<double>(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, P.data());
   pack_btab<double>(h->n_btab, h->n_tab, Btab, BT.data());
@@ -222,14 +218,16 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
   a.XU = h->XU; a.KD = h->KD; a.LAM = h->LAM; a.CAND = h->CAND;
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
   // LDS is a static module-level array (tsat_device.hpp): nothing dynamic to request at launch
-  // kernel variant: integrator x diagonal-inertia fast path x error-state mode
+  // kernel variant: integrator x inertia class (full / diagonal / isotropic) x error-state mode
   using kern_t = void (*)(KArgs<double>);
-  static const kern_t variants[2][2][2] = {
+  static const kern_t variants[2][3][2] = {
       {{tsat_solve_kernel<double, 3, 0, 0>, tsat_solve_kernel<double, 3, 0, 1>},
-       {tsat_solve_kernel<double, 3, 1, 0>, tsat_solve_kernel<double, 3, 1, 1>}},
+       {tsat_solve_kernel<double, 3, 1, 0>, tsat_solve_kernel<double, 3, 1, 1>},
+       {tsat_solve_kernel<double, 3, 2, 0>, tsat_solve_kernel<double, 3, 2, 1>}},
       {{tsat_solve_kernel<double, 4, 0, 0>, tsat_solve_kernel<double, 4, 0, 1>},
-       {tsat_solve_kernel<double, 4, 1, 0>, tsat_solve_kernel<double, 4, 1, 1>}}};
-  const kern_t kern = variants[o->integrator == 4 ? 1 : 0][h->diag_inertia ? 1 : 0][o->error_state ? 1 : 0];
+       {tsat_solve_kernel<double, 4, 1, 0>, tsat_solve_kernel<double, 4, 1, 1>},
+       {tsat_solve_kernel<double, 4, 2, 0>, tsat_solve_kernel<double, 4, 2, 1>}}};
+  const kern_t kern = variants[o->integrator == 4 ? 1 : 0][h->inertia_class][o->error_state ? 1 : 0];
   if (h->trace) TSAT_HIP(h, hipMemsetAsync(h->trace, 0, (size_t)h->T * h->trace_rows * 8 * sizeof(double), h->stream));
   TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(kern, dim3((unsigned)h->T), dim3(64), 0, h->stream, a);
