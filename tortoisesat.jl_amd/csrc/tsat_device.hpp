@@ -842,11 +842,12 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
     }
     TSAT_SYNC_LDS();
     // step 3: regularise, PD test (Sylvester), adjugate inverse, K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu
-    real hu[9], qu0, qu1, qu2, hi[3], hj[3], b1, b2;
+    real qu0, qu1, qu2, hi[3], hj[3], b1, b2;
     {
       const real* Huu = lds + L_HUU;
       const real* Hux = lds + L_HUX;
-      for (int c = 0; c < 9; ++c) hu[c] = Huu[c];
+      real hu[9];
+      hu[0] = Huu[0]; hu[1] = Huu[1]; hu[2] = Huu[2]; hu[4] = Huu[4]; hu[5] = Huu[5]; hu[8] = Huu[8];
       const real h0 = Hux[0 * 8 + j3], h1 = Hux[1 * 8 + j3], h2 = Hux[2 * 8 + j3];
       // prefetch for step 4 (all produced by step 2): Qu, the Qux columns i and j, the base terms
       qu0 = lds[L_HUX + 7]; qu1 = lds[L_HUX + 15]; qu2 = lds[L_HUX + 23];
@@ -889,11 +890,10 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
         ini2 = lds[(s2_init >= 0) ? (rcn + s2_init) : L_ZERO];
       }
       TSAT_SCHED_FENCE();
-      dV1 += d0 * qu0 + d1 * qu1 + d2 * qu2;
-      const real t0 = hu[0] * d0 + hu[1] * d1 + hu[2] * d2;
-      const real t1 = hu[3] * d0 + hu[4] * d1 + hu[5] * d2;
-      const real t2 = hu[6] * d0 + hu[7] * d1 + hu[8] * d2;
-      dV2 += (real)0.5 * (d0 * t0 + d1 * t1 + d2 * t2);
+      // dV1 += d'Qu ; dV2 += 0.5 d'Quu d. With d = -Quu_reg^-1 Qu: Quu d = -Qu - rho d, so d'Quu d = -(d'Qu + rho d'd)
+      const real dqu = d0 * qu0 + d1 * qu1 + d2 * qu2;
+      dV1 += dqu;
+      dV2 -= (real)0.5 * (dqu + rho * (d0 * d0 + d1 * d1 + d2 * d2));
       real acc = b1 + b2;
       real sy = 0, kk = 0;
       for (int c = 0; c < 3; ++c) {
