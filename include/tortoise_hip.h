@@ -141,6 +141,11 @@ int  tsat_batch_upload(tsat_handle* h,
                        const double* tau0, const double* dtau, const double* dt, const double* Jmat,
                        const double* Qd, const double* Qfd, const double* Rd,
                        const double* ulo, const double* uhi, const double* U0);
+/* Ragged batches: give trajectory t its own knot count n_knots[t] in [2, N] (NULL: all N again). Replaces the
+ * per-run horizon of the reference's Monte-Carlo, t_total[i] = 0:0.2:t_final[i] (src/monte_carlo.jl:140-145).
+ * Arrays keep the common stride N; U0 entries beyond a trajectory's horizon are ignored and its X/U/K slabs are
+ * returned zero-filled beyond it. Call after tsat_batch_upload. */
+int  tsat_batch_knots(tsat_handle* h, const int32_t* n_knots /* T */);
 /* run the solve on the resident batch (always restarts from the uploaded U0); blocks until done.
  * *kernel_ms (may be NULL) receives the HIP-event time of the solve kernel on the handle's stream. */
 int  tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms);

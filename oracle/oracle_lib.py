@@ -145,7 +145,8 @@ def solve_batch(batch, opts, nthreads=1, want_K=True, trace_rows=0):
         batch.btab_idx.ctypes.data_as(C.POINTER(C.c_int32)), d(batch.tau0), d(batch.dtau), d(batch.dt),
         d(batch.Jmat), d(batch.Qd), d(batch.Qfd), d(batch.Rd), d(batch.ulo), d(batch.uhi), d(batch.U0),
         d(X), d(U), d(K) if want_K else None, stats.ctypes.data_as(C.c_void_p), C.c_int(nthreads),
-        d(trace) if trace_rows else None, C.c_int(trace_rows))
+        d(trace) if trace_rows else None, C.c_int(trace_rows),
+        None if batch.n_knots is None else np.ascontiguousarray(batch.n_knots, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32)))
     if rc != 0:
         raise RuntimeError(f"orc_solve_batch failed rc={rc}")
     return dict(X=X, U=U, K=K, stats=stats, trace=trace)

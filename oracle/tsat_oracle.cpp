@@ -775,12 +775,13 @@ static Traj make_traj(const tsat_options* o, int64_t t, const double* x0, const 
 
 /* Same argument list as tsat_solve_batch (include/tortoise_hip.h) minus the handle, plus:
  *   nthreads    OpenMP threads over trajectories (1 = serial);
- *   trace       optional 8 x trace_rows x T per-iteration log (see tsat_batch_trace).            */
+ *   trace       optional 8 x trace_rows x T per-iteration log (see tsat_batch_trace);
+ *   n_knots     optional per-trajectory knot counts (see tsat_batch_knots).                       */
 int orc_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab, const double* x0, const double* xf,
                     const double* Btab, const int32_t* btab_idx, const double* tau0, const double* dtau,
                     const double* dt, const double* Jmat, const double* Qd, const double* Qfd, const double* Rd,
                     const double* ulo, const double* uhi, const double* U0, double* X, double* U, double* K,
-                    tsat_stats* stats, int nthreads, double* trace, int trace_rows) {
+                    tsat_stats* stats, int nthreads, double* trace, int trace_rows, const int32_t* n_knots) {
   if (!o || o->n_knots < 2 || o->n_tab < 1 || (o->integrator != 3 && o->integrator != 4)) return -1;
   if (o->max_linesearch < 1 || o->max_linesearch > TSAT_MAX_LINESEARCH) return -1;
   if (o->error_state != 0 && o->error_state != 1) return -2;
@@ -792,8 +793,16 @@ int orc_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab, const doub
 #endif
   for (int64_t t = 0; t < T; ++t) {
     Traj tr = make_traj(o, t, x0, xf, Btab, btab_idx, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi);
-    solve_one(tr, *o, U0 + (size_t)3 * (N - 1) * t, X + (size_t)7 * N * t, U + (size_t)3 * (N - 1) * t,
-              K ? K + (size_t)21 * (N - 1) * t : nullptr, stats + t,
+    double* Xt = X + (size_t)7 * N * t;
+    double* Ut = U + (size_t)3 * (N - 1) * t;
+    double* Kt = K ? K + (size_t)21 * (N - 1) * t : nullptr;
+    if (n_knots) {   // ragged batch: own horizon, slabs zero-filled beyond it (as tsat_batch_knots)
+      tr.N = n_knots[t];
+      std::memset(Xt, 0, sizeof(double) * 7 * N);
+      std::memset(Ut, 0, sizeof(double) * 3 * (N - 1));
+      if (Kt) std::memset(Kt, 0, sizeof(double) * 21 * (N - 1));
+    }
+    solve_one(tr, *o, U0 + (size_t)3 * (N - 1) * t, Xt, Ut, Kt, stats + t,
               trace ? trace + (size_t)8 * trace_rows * t : nullptr, trace_rows);
   }
   return 0;

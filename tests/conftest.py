@@ -54,7 +54,8 @@ class Emu:
             C.byref(o), C.c_int64(T), C.c_int64(batch.Btab.shape[0]), d(batch.x0), d(batch.xf), d(batch.Btab),
             self.abi.as_ip(batch.btab_idx), d(batch.tau0), d(batch.dtau), d(batch.dt), d(batch.Jmat), d(batch.Qd),
             d(batch.Qfd), d(batch.Rd), d(batch.ulo), d(batch.uhi), d(batch.U0), d(X), d(U), d(K),
-            stats.ctypes.data_as(C.c_void_p), d(trace) if trace_rows else None, C.c_int(trace_rows))
+            stats.ctypes.data_as(C.c_void_p), d(trace) if trace_rows else None, C.c_int(trace_rows),
+            None if batch.n_knots is None else self.abi.as_ip(np.ascontiguousarray(batch.n_knots, dtype=np.int32)))
         if rc != 0:
             raise RuntimeError(f"emu_solve_batch rc={rc}")
         return dict(X=X, U=U, K=K, stats=stats, trace=trace)

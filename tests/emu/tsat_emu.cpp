@@ -44,7 +44,8 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
                                const double* Btab, const int32_t* btab_idx, const double* tau0, const double* dtau,
                                const double* dt, const double* Jmat, const double* Qd, const double* Qfd,
                                const double* Rd, const double* ulo, const double* uhi, const double* U0, double* X,
-                               double* U, double* K, tsat_stats* stats, double* trace, int trace_rows) {
+                               double* U, double* K, tsat_stats* stats, double* trace, int trace_rows,
+                               const int32_t* n_knots) {
   const int N = o->n_knots, n_tab = o->n_tab;
   if (!check_options(*o, N, n_tab, o->max_linesearch).empty()) return -1;
   const int max_ls = o->max_linesearch < NSTORE ? o->max_linesearch : NSTORE;   // stored candidate slots
@@ -57,7 +58,7 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
       LAM((size_t)T * (N - 1) * LMW, 0.0), CAND((size_t)T * max_ls * N * XUW, 0.0);
   KArgs<double> a;
   a.T = (int)T; a.N = N; a.n_tab = n_tab; a.max_ls = max_ls; a.opt = *o;
-  a.P = P.data(); a.BT = BT.data(); a.bidx = bidx.data(); a.U0 = U0;
+  a.P = P.data(); a.BT = BT.data(); a.bidx = bidx.data(); a.nk = n_knots; a.U0 = U0;
   a.XU = XU.data(); a.KD = KD.data(); a.LAM = LAM.data(); a.CAND = CAND.data();
   a.stats = stats; a.trace = trace; a.trace_rows = trace_rows;
   const int cls = inertia_class(T, Jmat);   // same variant selection as tsat_batch_upload
@@ -67,6 +68,6 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
       {{run_block<4, 0, 0>, run_block<4, 0, 1>}, {run_block<4, 1, 0>, run_block<4, 1, 1>}, {run_block<4, 2, 0>, run_block<4, 2, 1>}}};
   const blk_t blk = variants[o->integrator == 4 ? 1 : 0][cls][o->error_state ? 1 : 0];
   for (int t = 0; t < (int)T; ++t) blk(a, t);
-  for (int64_t e = 0; e < T * (int64_t)N; ++e) export_record<double>(e, N, XU.data(), KD.data(), X, U, K);
+  for (int64_t e = 0; e < T * (int64_t)N; ++e) export_record<double>(e, N, n_knots, XU.data(), KD.data(), X, U, K);
   return 0;
 }

@@ -152,3 +152,36 @@ def test_emulated_kernel_diagonal_3u_inertia(pkg, ol, emu):
     for es in (0, 1):
         o = oracle_options(ol, max_outer=2, max_inner=3, error_state=es)
         assert_same_solution(ol.solve_batch(b, o), emu.solve(b, o))
+
+
+def _ragged_batch(pkg, T=4, N=70, seed=51):
+    b = pkg.slew_setup.workload_monte_carlo(T=T, N=N, seed=seed, random_orbit=True)
+    b.n_knots = np.array([N, 2, 33, 58][:T], dtype=np.int32)
+    return b
+
+
+def test_ragged_batch_semantics_on_oracle(pkg, ol):
+    """tsat_batch_knots: a trajectory with its own horizon n solves exactly the n-knot problem on the same table;
+    its slabs are zero beyond the horizon (variable t_final per run, src/monte_carlo.jl:140-145)"""
+    ss = pkg.slew_setup
+    b = _ragged_batch(pkg)
+    o = oracle_options(ol, max_outer=2, max_inner=4)
+    r = ol.solve_batch(b, o)
+    for t, n in enumerate(b.n_knots):
+        one = b.slice(t, t + 1)
+        alone = ss.SlewBatch(int(n), one.n_tab, one.x0, one.xf, one.Btab, one.btab_idx, one.tau0, one.dtau, one.dt, one.Jmat,
+                             one.Qd, one.Qfd, one.Rd, one.ulo, one.uhi, np.ascontiguousarray(one.U0[:, : n - 1]))
+        ra = ol.solve_batch(alone, o)
+        assert np.array_equal(r["X"][t, :n], ra["X"][0]) and np.array_equal(r["U"][t, : n - 1], ra["U"][0])
+        assert np.all(r["X"][t, n:] == 0) and np.all(r["U"][t, n - 1:] == 0) and np.all(r["K"][t, n - 1:] == 0)
+        assert r["stats"]["inner_iters"][t] == ra["stats"]["inner_iters"][0]
+
+
+@pytest.mark.parametrize("es", [0, 1])
+def test_emulated_kernel_ragged_batch(pkg, ol, emu, es):
+    b = _ragged_batch(pkg)
+    o = oracle_options(ol, max_outer=2, max_inner=4, error_state=es)
+    r, g = ol.solve_batch(b, o), emu.solve(b, o)
+    assert_same_solution(r, g)
+    for t, n in enumerate(b.n_knots):
+        assert np.all(g["X"][t, n:] == 0) and np.all(g["U"][t, n - 1:] == 0) and np.all(g["K"][t, n - 1:] == 0)

@@ -141,6 +141,25 @@ def test_gpu_diagonal_3u_inertia(pkg, ol, solver):
         assert_same_solution(ol.solve_batch(b, o, nthreads=4), gpu_solve(pkg, solver, b, o))
 
 
+def test_gpu_ragged_batch(pkg, ol, solver):
+    """per-trajectory horizons (tsat_batch_knots): empty-ish (2 knots), chunk-boundary and full-length trajectories
+    in one launch, both modes; then back to a uniform batch on the same handle"""
+    lib = pkg._abi.load()
+    b = pkg.slew_setup.workload_monte_carlo(T=6, N=260, seed=51, random_orbit=True)
+    b.n_knots = np.array([260, 2, 57, 58, 113, 200], dtype=np.int32)
+    for es in (0, 1):
+        o = oracle_options(ol, max_outer=3, max_inner=5, dj_counter_limit=1, error_state=es)
+        r, g = ol.solve_batch(b, o, nthreads=4), gpu_solve(pkg, solver, b, o)
+        assert_same_solution(r, g)
+        for t, n in enumerate(b.n_knots):
+            assert np.all(g["X"][t, n:] == 0) and np.all(g["U"][t, n - 1:] == 0) and np.all(g["K"][t, n - 1:] == 0)
+    bad = np.array([260, 1, 57, 58, 113, 200], dtype=np.int32)
+    assert lib.tsat_batch_knots(solver._h, pkg._abi.as_ip(bad)) < 0        # knot counts are validated
+    b.n_knots = None
+    o = oracle_options(ol, max_outer=2, max_inner=3)
+    assert_same_solution(ol.solve_batch(b, o, nthreads=4), gpu_solve(pkg, solver, b, o))
+
+
 def test_gpu_failure_statuses(pkg, ol, solver):
     ss, abi = pkg.slew_setup, pkg._abi
     b = ss.workload_monte_carlo(T=2, N=40, seed=5)

@@ -67,6 +67,7 @@ PROTOTYPES = {
                                    _dp, _dp, _dp, C.c_void_p]),
     "tsat_batch_reserve": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int32]),
     "tsat_batch_upload": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "tsat_batch_knots": (C.c_int, [C.c_void_p, _ip]),
     "tsat_batch_run": (C.c_int, [C.c_void_p, C.POINTER(Options), C.POINTER(C.c_float)]),
     "tsat_batch_download": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_void_p]),
     "tsat_batch_export_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -93,6 +93,7 @@ struct KArgs {
   const real* P;      // [T][PSTRIDE]
   const real* BT;     // [n_btab][n_tab][4]
   const int* bidx;    // [T]
+  const int* nk;      // [T] knots of each trajectory (2 <= nk[t] <= N) or null: all N  (ragged batches)
   const real* U0;     // [T][N-1][3]
   real* XU;           // [T][N][10]      nominal knot records x(7),u(3)
   real* KD;           // [T][N-1][24]    K (3x7 row-major), d(3)
@@ -1078,16 +1079,19 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
   const tsat_options& o = a.opt;
-  const int N = a.N, n_tab = a.n_tab;
+  // the batch is laid out with the common stride a.N; a trajectory may use fewer knots (variable-horizon sweeps:
+  // t_total[i] = 0:0.2:t_final[i], src/monte_carlo.jl:140-145)
+  const int NS = a.N, n_tab = a.n_tab;
+  const int N = a.nk ? a.nk[traj] : a.N;
   TPtrs<real> p;
-  p.XU = (TSAT_GLOBAL real*)(a.XU + (size_t)traj * N * XUW);
-  p.KD = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * (N - 1) * KDW);
-  p.LAM = (TSAT_GLOBAL real*)(a.LAM + (size_t)traj * (N - 1) * LMW);
-  p.CAND = (TSAT_GLOBAL real*)(a.CAND + (size_t)traj * a.max_ls * (size_t)N * XUW);
+  p.XU = (TSAT_GLOBAL real*)(a.XU + (size_t)traj * NS * XUW);
+  p.KD = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * (NS - 1) * KDW);
+  p.LAM = (TSAT_GLOBAL real*)(a.LAM + (size_t)traj * (NS - 1) * LMW);
+  p.CAND = (TSAT_GLOBAL real*)(a.CAND + (size_t)traj * a.max_ls * (size_t)NS * XUW);
   p.bt = (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[traj] * n_tab * 4);
   stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)traj * PSTRIDE), (real)o.u_scale);
 
-  const real* U0g = a.U0 + (size_t)traj * (N - 1) * 3;
+  const real* U0g = a.U0 + (size_t)traj * (NS - 1) * 3;
   double* trace = a.trace ? a.trace + (size_t)traj * a.trace_rows * 8 : nullptr;
   int trow = 0;
 

@@ -106,20 +106,23 @@ void pack_btab(int64_t n_btab, int n_tab, const double* Btab, real* BT) {
 // element-wise export of the resident records into the ABI result arrays; `e` indexes knot records.
 //   X (T,N,7) <- XU[.,.,0:7];  U (T,N-1,3) <- XU[.,.,7:10];  K (T,N-1,7,3)[t][k][j][a] <- KD[t][k][a*7+j]
 template <typename real>
-TSAT_DEV void export_record(int64_t e, int N, const real* XU, const real* KD, double* X, double* U, double* K) {
+TSAT_DEV void export_record(int64_t e, int N, const int* nk, const real* XU, const real* KD, double* X, double* U,
+                            double* K) {
   const int64_t t = e / N;
   const int k = (int)(e - t * N);
+  const int n = nk ? nk[t] : N;           // knots this trajectory actually has; the rest of its slab is zero-filled
   const real* r = XU + (size_t)e * XUW;
   if (X)
-    for (int i = 0; i < 7; ++i) X[(size_t)e * 7 + i] = (double)r[i];
+    for (int i = 0; i < 7; ++i) X[(size_t)e * 7 + i] = (k < n) ? (double)r[i] : 0.0;
   if (k < N - 1) {
     const size_t ek = (size_t)t * (N - 1) + k;
+    const bool live = k < n - 1;
     if (U)
-      for (int c = 0; c < 3; ++c) U[ek * 3 + c] = (double)r[7 + c];
+      for (int c = 0; c < 3; ++c) U[ek * 3 + c] = live ? (double)r[7 + c] : 0.0;
     if (K) {
       const real* kd = KD + ek * KDW;
       for (int j = 0; j < 7; ++j)
-        for (int c = 0; c < 3; ++c) K[ek * 21 + j * 3 + c] = (double)kd[c * 7 + j];
+        for (int c = 0; c < 3; ++c) K[ek * 21 + j * 3 + c] = live ? (double)kd[c * 7 + j] : 0.0;
     }
   }
 }

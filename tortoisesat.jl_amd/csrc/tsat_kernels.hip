@@ -23,10 +23,10 @@ __global__ __launch_bounds__(64) void tsat_solve_kernel(KArgs<real> a) {
 }
 
 template <typename real>
-__global__ __launch_bounds__(256) void tsat_export_kernel(int64_t n_rec, int N, const real* XU, const real* KD,
-                                                          double* X, double* U, double* K) {
+__global__ __launch_bounds__(256) void tsat_export_kernel(int64_t n_rec, int N, const int* nk, const real* XU,
+                                                          const real* KD, double* X, double* U, double* K) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n_rec) export_record<real>(e, N, XU, KD, X, U, K);
+  if (e < n_rec) export_record<real>(e, N, nk, XU, KD, X, U, K);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -44,6 +44,8 @@ struct tsat_handle {
   int inertia_class = 0;      // 0 full, 1 every uploaded inertia tensor diagonal, 2 every one isotropic -> DIAGJ variant
   double *P = nullptr, *BT = nullptr, *U0 = nullptr, *XU = nullptr, *KD = nullptr, *LAM = nullptr, *CAND = nullptr;
   int* bidx = nullptr;
+  int* nk = nullptr;          // per-trajectory knot counts (ragged batch) or null
+  bool ragged = false;
   tsat_stats* stats = nullptr;
   double* trace = nullptr;
   int64_t bytes = 0;
@@ -63,11 +65,11 @@ int fail(tsat_handle* h, int code, const std::string& msg) {
   } while (0)
 
 void release(tsat_handle* h) {
-  void* ptrs[] = {h->P, h->BT, h->U0, h->XU, h->KD, h->LAM, h->CAND, h->bidx, h->stats, h->trace};
+  void* ptrs[] = {h->P, h->BT, h->U0, h->XU, h->KD, h->LAM, h->CAND, h->bidx, h->nk, h->stats, h->trace};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->P = h->BT = h->U0 = h->XU = h->KD = h->LAM = h->CAND = nullptr;
-  h->bidx = nullptr; h->stats = nullptr; h->trace = nullptr;
+  h->bidx = nullptr; h->nk = nullptr; h->ragged = false; h->stats = nullptr; h->trace = nullptr;
   h->T = 0; h->bytes = 0; h->uploaded = h->solved = false;
 }
 
@@ -149,6 +151,7 @@ int tsat_batch_reserve(tsat_handle* h, int64_t T, int32_t n_knots, int32_t n_tab
   rc |= dev_alloc(h, &h->P, Tn * PSTRIDE);
   rc |= dev_alloc(h, &h->BT, (size_t)n_btab * n_tab * 4);
   rc |= dev_alloc(h, &h->bidx, Tn);
+  rc |= dev_alloc(h, &h->nk, Tn);
   rc |= dev_alloc(h, &h->U0, Tn * (N - 1) * 3);
   rc |= dev_alloc(h, &h->XU, Tn * N * XUW);
   rc |= dev_alloc(h, &h->KD, Tn * (N - 1) * KDW);
@@ -203,6 +206,20 @@ int tsat_batch_upload(tsat_handle* h, const double* x0, const double* xf, const 
   TSAT_HIP(h, hipMemcpy(h->U0, U0, (size_t)T * (h->N - 1) * 3 * sizeof(double), hipMemcpyHostToDevice));
   h->uploaded = true;
   h->solved = false;
+  h->ragged = false;   // a fresh upload is a uniform batch until tsat_batch_knots says otherwise
+  return 0;
+}
+
+int tsat_batch_knots(tsat_handle* h, const int32_t* n_knots) {
+  if (!h) return -1;
+  if (!h->uploaded) return fail(h, -1, "tsat_batch_upload has not been called");
+  if (!n_knots) { h->ragged = false; return 0; }
+  for (int64_t t = 0; t < h->T; ++t)
+    if (n_knots[t] < 2 || n_knots[t] > h->N) return fail(h, -1, "n_knots[t] must be in [2, N]");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  TSAT_HIP(h, hipMemcpy(h->nk, n_knots, (size_t)h->T * sizeof(int), hipMemcpyHostToDevice));
+  h->ragged = true;
+  h->solved = false;
   return 0;
 }
 
@@ -214,7 +231,7 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
   TSAT_HIP(h, hipSetDevice(h->dev));
   KArgs<double> a;
   a.T = (int)h->T; a.N = h->N; a.n_tab = h->n_tab; a.max_ls = h->max_ls < NSTORE ? h->max_ls : NSTORE; a.opt = *o;
-  a.P = h->P; a.BT = h->BT; a.bidx = h->bidx; a.U0 = h->U0;
+  a.P = h->P; a.BT = h->BT; a.bidx = h->bidx; a.nk = h->ragged ? h->nk : nullptr; a.U0 = h->U0;
   a.XU = h->XU; a.KD = h->KD; a.LAM = h->LAM; a.CAND = h->CAND;
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
   // LDS is a static module-level array (tsat_device.hpp): nothing dynamic to request at launch
@@ -246,7 +263,8 @@ int tsat_batch_export_device(tsat_handle* h, void* X_dev, void* U_dev, void* K_d
   const int64_t n_rec = h->T * (int64_t)h->N;
   if (X_dev || U_dev || K_dev) {
     const unsigned blocks = (unsigned)((n_rec + 255) / 256);
-    hipLaunchKernelGGL(tsat_export_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, n_rec, h->N, h->XU, h->KD,
+    hipLaunchKernelGGL(tsat_export_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, n_rec, h->N,
+                       h->ragged ? h->nk : nullptr, h->XU, h->KD,
                        (double*)X_dev, (double*)U_dev, (double*)K_dev);
     TSAT_HIP(h, hipGetLastError());
   }

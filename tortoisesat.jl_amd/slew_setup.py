@@ -143,6 +143,7 @@ class SlewBatch:
     uhi: np.ndarray     # (T,3)
     U0: np.ndarray      # (T,N-1,3)
     meta: dict = field(default_factory=dict)
+    n_knots: np.ndarray = None   # (T,) int32 per-trajectory knot counts (ragged batch) or None: all N
 
     @property
     def T(self):
@@ -155,7 +156,7 @@ class SlewBatch:
         return SlewBatch(self.N, self.n_tab, c(self.x0[s]), c(self.xf[s]), self.Btab, c(self.btab_idx[s]),
                          c(self.tau0[s]), c(self.dtau[s]), c(self.dt[s]), c(self.Jmat[s]), c(self.Qd[s]),
                          c(self.Qfd[s]), c(self.Rd[s]), c(self.ulo[s]), c(self.uhi[s]), c(self.U0[s]),
-                         dict(self.meta))
+                         dict(self.meta), None if self.n_knots is None else c(self.n_knots[s]))
 
 
 def jmat_cm(J):

@@ -271,6 +271,9 @@ class AugmentedLagrangianSolver:
             self._h, d(batch.x0), d(batch.xf), d(batch.Btab), _abi.as_ip(batch.btab_idx), d(batch.tau0),
             d(batch.dtau), d(batch.dt), d(batch.Jmat), d(batch.Qd), d(batch.Qfd), d(batch.Rd), d(batch.ulo),
             d(batch.uhi), d(batch.U0)), "tsat_batch_upload")
+        if batch.n_knots is not None:   # ragged batch: per-trajectory horizons (src/monte_carlo.jl:140-145)
+            nk = np.ascontiguousarray(batch.n_knots, dtype=np.int32)
+            self._check(self._lib.tsat_batch_knots(self._h, _abi.as_ip(nk)), "tsat_batch_knots")
         self._shape = (batch.T, batch.N)
 
     def run(self, abi_opts):
