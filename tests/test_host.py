@@ -127,3 +127,25 @@ def test_model_hooks_select_error_state_mode(pkg):
         to.Model(f, 8, 3, lambda a, b: a - b, lambda *a: None).error_state
     o = to.AugmentedLagrangianSolverOptions().to_abi(10, 10, 3, error_state=1)
     assert o.error_state == 1
+
+
+def test_batch_of_problems_with_different_horizons_is_ragged(pkg):
+    """the Monte-Carlo gives every run its own horizon (src/monte_carlo.jl:140-145): BatchProblem pads to the longest"""
+    ss, to = pkg.slew_setup, pkg.trajopt
+    J = ss.INERTIA["1U"]
+    B = ss.dipole_btable(80, 0.2, 6771.0, 96.6)
+    probs = []
+    for N in (80, 50):
+        model = to.rk3(to.Model(to.DerivFunction(J, B, rows_per_knot=1.0), 8, 3))
+        obj = to.LQRObjective(np.diag([1.0] * 7 + [0.0]), np.eye(3), np.diag([10.0] * 7 + [0.0]), np.r_[0, 0, 0, 1, 0, 0, 0, 1.0], N)
+        cons = to.Constraints(N)
+        for k in range(1, N):
+            cons[k] += to.BoundConstraint(8, 3, u_max=19, u_min=-19)
+        cons[N] += to.goal_constraint(obj.xf)
+        p = to.Problem(model, obj, constraints=cons, x0=np.r_[0, 0, 0, 0, 1.0, 0, 0, 0], xf=obj.xf, N=N, dt=0.2)
+        to.initial_controls_(p, np.full((3, N - 1), 1e-3))
+        probs.append(p)
+    bp = to.BatchProblem(probs)
+    assert bp.arrays.N == 80 and list(bp.arrays.n_knots) == [80, 50]
+    assert bp.arrays.U0.shape == (2, 79, 3) and np.all(bp.arrays.U0[1, 49:] == 0) and np.all(bp.arrays.U0[1, :49] == 1e-3)
+    assert to.BatchProblem(probs[:1]).arrays.n_knots is None

@@ -343,7 +343,8 @@ class BatchProblem:
         if not problems:
             raise ValueError("empty batch")
         p0 = problems[0]
-        N, integ = p0.N, p0.model.integrator
+        integ = p0.model.integrator
+        N = max(p.N for p in problems)      # common stride; shorter horizons become a ragged batch (tsat_batch_knots)
         if integ not in (3, 4):
             raise ValueError("discretise the model with rk3(model) or rk4(model) first (src/TortoiseSat.jl:146)")
         self.problems = problems
@@ -356,10 +357,11 @@ class BatchProblem:
         Qd = np.zeros((T, 7)); Qfd = np.zeros((T, 7)); Rd = np.zeros((T, 3))
         ulo = np.zeros((T, 3)); uhi = np.zeros((T, 3)); U0 = np.zeros((T, N - 1, 3))
         tau0 = np.zeros(T); dtau = np.zeros(T); dt = np.zeros(T)
+        n_knots = np.array([p.N for p in problems], dtype=np.int32)
         for t, p in enumerate(problems):
-            if (p.N != N or p.model.integrator != integ or _terminal_mask(p) != self.terminal_mask
+            if (p.N < 2 or p.model.integrator != integ or _terminal_mask(p) != self.terminal_mask
                     or p.model.error_state != self.error_state):
-                raise ValueError("all problems of a batch must share N, integrator and constraint structure")
+                raise ValueError("all problems of a batch must share integrator, hooks and constraint structure")
             f = p.model.f
             key = id(f.B_ECI)
             if key not in seen:
@@ -373,10 +375,10 @@ class BatchProblem:
             ulo[t], uhi[t] = _control_box(p)
             if p.U0 is None:
                 raise ValueError("call initial_controls_(prob, U0) first (src/TortoiseSat.jl:191)")
-            U0[t] = p.U0.T
+            U0[t, : p.N - 1] = p.U0.T
             n_tab = tabs[idx[t]].shape[0]
             tau0[t] = f.tau0
-            dtau[t] = f.rows_per_knot if f.rows_per_knot is not None else n_tab / float(N)
+            dtau[t] = f.rows_per_knot if f.rows_per_knot is not None else n_tab / float(p.N)
             dt[t] = p.dt
         n_tab = tabs[0].shape[0]
         if any(tb.shape != (n_tab, 3) for tb in tabs):
@@ -385,6 +387,8 @@ class BatchProblem:
             raise ValueError("a finite control box is required (BoundConstraint, src/TortoiseSat.jl:178)")
         self.arrays = SlewBatch(N, n_tab, x0, xf, np.ascontiguousarray(np.stack(tabs)), idx, tau0, dtau, dt, Jm,
                                 Qd, Qfd, Rd, ulo, uhi, U0)
+        if np.any(n_knots != N):
+            self.arrays.n_knots = n_knots
 
     @classmethod
     def from_arrays(cls, batch: SlewBatch, integrator=3, terminal_mask=0x7F, error_state=0):
@@ -410,8 +414,8 @@ def solve_(prob, solver, want_K=True):
     res = solver.download(want_K=want_K)
     if batch.problems is not None:
         for t, p in enumerate(batch.problems):
-            p.X = np.ascontiguousarray(res["X"][t].T)
-            p.U = np.ascontiguousarray(res["U"][t].T)
-            p.K = np.ascontiguousarray(res["K"][t].transpose(2, 1, 0)) if want_K else None
+            p.X = np.ascontiguousarray(res["X"][t, : p.N].T)
+            p.U = np.ascontiguousarray(res["U"][t, : p.N - 1].T)
+            p.K = np.ascontiguousarray(res["K"][t, : p.N - 1].transpose(2, 1, 0)) if want_K else None
             p.stats = res["stats"][t]
     return res
