@@ -161,6 +161,54 @@ int64_t tsat_batch_bytes(const tsat_handle* h);
 int  tsat_batch_trace(tsat_handle* h, int32_t rows);
 int  tsat_batch_trace_download(tsat_handle* h, double* trace /* 8 x rows x T */);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Closed-loop tracking of a solved slew (the caller right after solve! in the reference): TVLQR gains around the
+ * optimised trajectory + simulation + the slew-time statistic.
+ *   attitude_simulation(f!, f_gains!, :rk4, X, U, dt, x0_lqr, t0, tf, Q_lqr, R_lqr, Qf_lqr)   src/attitude_controller.jl:1-48
+ *   attitude_lqr (Jacobians + G(q) reduction + Riccati)                                         src/attitude_controller.jl:50-119
+ *   simulator / gain_simulator (plant with / without injected noise)                            src/simulator.jl, src/gain_simulator.jl
+ *   slew-time / failure statistic                                                               src/monte_carlo.jl:242-262
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct tsat_tvlqr_options {
+  int32_t n_knots;          /* N                                                                              */
+  int32_t n_tab;            /* rows in each B table                                                           */
+  int32_t linearize_dt_sq;  /* 1: gains linearised over a step of dt^2 (the reference's `dt = S[end]^2`,
+                               src/attitude_controller.jl:137); 0: over dt                    */
+  int32_t min_steps;        /* statistic ignores the first min_steps samples (10, src/monte_carlo.jl:251)     */
+  double  u_scale;          /* 1e-2: `u/100` (src/gain_simulator.jl:42)                                       */
+  double  w_tol;            /* 0.05 rad/s   (src/monte_carlo.jl:70)                                           */
+  double  angle_tol;        /* 0.08727 rad  (src/monte_carlo.jl:71)                                           */
+} tsat_tvlqr_options;
+
+typedef struct tsat_tvlqr_stats {
+  int32_t slew_index;       /* first 1-based sample j > min_steps with |w| < w_tol and error angle < angle_tol; 0 = none */
+  int32_t failed;           /* 1 when no such sample exists (`fails[i]`, src/monte_carlo.jl:258-261)           */
+  double  slew_time;        /* dt * slew_index, or dt * N when failed (`slew_time[i]`, :237,252)               */
+  double  final_w_norm;     /* |w| of the last simulated sample                                                */
+  double  final_angle;      /* error angle of the last simulated sample                                        */
+} tsat_tvlqr_stats;
+
+void tsat_tvlqr_default_options(tsat_tvlqr_options* o);
+
+/*
+ * Host pointers in and out, column-major as everywhere in this ABI.
+ *   X 7xNxT, U 3x(N-1)xT        the optimised trajectories (outputs of tsat_solve_batch)
+ *   xf 7xT                       goal state: its quaternion is `q_final` of the statistic
+ *   Btab, btab_idx, tau0, dtau, dt, Jmat   as for tsat_solve_batch
+ *   Qd, Qfd 6xT, Rd 3xT          diagonals of Q_lqr, Qf_lqr, R_lqr (src/TortoiseSat.jl:251-260)
+ *   x0_sim 7xT                   perturbed initial state x0_lqr (src/TortoiseSat.jl:227-234)
+ *   noise 9x4x(N-1)xT or NULL    per step and RK4 stage: gyro noise(3), attitude-noise rotation vector(3), field
+ *                                noise(3) — the values the reference draws inside `simulator` (src/simulator.jl:5,10,22);
+ *                                NULL = noise-free plant (`gain_simulator`)
+ *   X_sim 7xNxT, U_sim 3x(N-1)xT, K_lqr 3x6x(N-1)xT (may be NULL), stats T        outputs
+ */
+int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int64_t n_btab,
+                      const double* X, const double* U, const double* xf,
+                      const double* Btab, const int32_t* btab_idx, const double* tau0, const double* dtau,
+                      const double* dt, const double* Jmat, const double* Qd, const double* Qfd, const double* Rd,
+                      const double* x0_sim, const double* noise,
+                      double* X_sim, double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,5 +152,35 @@ def solve_batch(batch, opts, nthreads=1, want_K=True, trace_rows=0):
     return dict(X=X, U=U, K=K, stats=stats, trace=trace)
 
 
+TvlqrOptions, TVLQR_STATS_DTYPE = _abi.TvlqrOptions, _abi.TVLQR_STATS_DTYPE
+
+
+def tvlqr_default_options():
+    o = TvlqrOptions()
+    load().orc_tvlqr_default_options(C.byref(o))
+    return o
+
+
+def tvlqr_batch(batch, X, U, Qd, Qfd, Rd, x0_sim, noise=None, opts=None, nthreads=1):
+    """Oracle closed-loop tracking of solved trajectories (see tsat_tvlqr_batch). Returns X_sim, U_sim, K_lqr, stats."""
+    lib = load()
+    T, N = batch.T, batch.N
+    o = opts or tvlqr_default_options()
+    o.n_knots, o.n_tab = N, batch.n_tab
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    X, U, Qd, Qfd, Rd, x0_sim = c(X), c(U), c(Qd), c(Qfd), c(Rd), c(x0_sim)
+    noise = None if noise is None else c(noise)
+    Xs = np.zeros((T, N, 7)); Us = np.zeros((T, N - 1, 3)); K = np.zeros((T, N - 1, 6, 3))
+    st = np.zeros(T, dtype=TVLQR_STATS_DTYPE)
+    d = lambda a: a.ctypes.data_as(_dp)
+    rc = lib.orc_tvlqr_batch(C.byref(o), C.c_int64(T), C.c_int64(batch.Btab.shape[0]), d(X), d(U), d(batch.xf), d(batch.Btab),
+                             batch.btab_idx.ctypes.data_as(C.POINTER(C.c_int32)), d(batch.tau0), d(batch.dtau), d(batch.dt),
+                             d(batch.Jmat), d(Qd), d(Qfd), d(Rd), d(x0_sim), d(noise) if noise is not None else None,
+                             d(Xs), d(Us), d(K), st.ctypes.data_as(C.c_void_p), C.c_int(nthreads))
+    if rc != 0:
+        raise RuntimeError(f"orc_tvlqr_batch failed rc={rc}")
+    return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)
+
+
 def num_procs():
     return load().orc_num_procs()

@@ -808,6 +808,133 @@ int orc_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab, const doub
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Closed-loop TVLQR tracking: literal restatement of attitude_simulation / attitude_lqr
+// (src/attitude_controller.jl:1-119), the plants (src/simulator.jl, src/gain_simulator.jl) and the slew-time statistic
+// (src/monte_carlo.jl:242-262). Randomness is an input: `noise` carries the values `simulator` would draw.
+// ------------------------------------------------------------------------------------------------------------
+void orc_tvlqr_default_options(tsat_tvlqr_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->linearize_dt_sq = 1; o->min_steps = 10; o->u_scale = 1e-2; o->w_tol = 0.05; o->angle_tol = 0.08727;
+}
+
+// src/simulator.jl:1-42 with the three random draws passed in (nz: gyro(3), attitude rotation vector(3), field(3));
+// nz == nullptr is src/gain_simulator.jl:1-53
+static void sim_dyn(const double x[7], const double u[3], const double b[3], const double* nz, const Phys& ph, double xd[7]) {
+  double w[3] = {x[0], x[1], x[2]};
+  double nq = std::sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+  double q[4] = {x[3] / nq, x[4] / nq, x[5] / nq, x[6] / nq};
+  double bb[3] = {b[0], b[1], b[2]};
+  if (nz) {
+    for (int i = 0; i < 3; ++i) w[i] += nz[i];
+    const double th = std::sqrt(nz[3] * nz[3] + nz[4] * nz[4] + nz[5] * nz[5]);
+    const double sh = std::sin(th / 2) / th;
+    double dq[4] = {std::cos(th / 2), nz[3] * sh, nz[4] * sh, nz[5] * sh}, qn[4];
+    qmult<double>(q, dq, qn);
+    for (int i = 0; i < 4; ++i) q[i] = qn[i];
+    for (int i = 0; i < 3; ++i) bb[i] += nz[6 + i];
+  }
+  double p[4] = {0, w[0], w[1], w[2]}, qd[4], BB[3], us[3] = {u[0] * ph.u_scale, u[1] * ph.u_scale, u[2] * ph.u_scale}, tau[3], Jw[3], wJw[3];
+  qmult<double>(q, p, qd);
+  qrot<double>(q, bb, BB);
+  cross3<double>(us, BB, tau);
+  for (int r = 0; r < 3; ++r) Jw[r] = ph.J[r] * w[0] + ph.J[r + 3] * w[1] + ph.J[r + 6] * w[2];
+  cross3<double>(w, Jw, wJw);
+  for (int r = 0; r < 3; ++r)
+    xd[r] = ph.Jinv[r] * (tau[0] - wJw[0]) + ph.Jinv[r + 3] * (tau[1] - wJw[1]) + ph.Jinv[r + 6] * (tau[2] - wJw[2]);
+  for (int i = 0; i < 4; ++i) xd[3 + i] = 0.5 * qd[i];
+}
+
+void orc_reduce_error_state(const double*, const double*, const double*, const double*, double*, double*);
+void orc_tvlqr_riccati(int, const double*, const double*, const double*, const double*, const double*, double*);
+
+int orc_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, const double* X, const double* U,
+                    const double* xf, const double* Btab, const int32_t* btab_idx, const double* tau0,
+                    const double* dtau, const double* dt, const double* Jmat, const double* Qd, const double* Qfd,
+                    const double* Rd, const double* x0_sim, const double* noise, double* X_sim, double* U_sim,
+                    double* K_lqr, tsat_tvlqr_stats* stats, int nthreads) {
+  if (!o || o->n_knots < 2 || o->n_tab < 1) return -1;
+  if (!btab_idx && n_btab != T) return -1;
+  const int N = o->n_knots;
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int64_t t = 0; t < T; ++t) {
+    Traj tr;
+    tr.N = N; tr.n_tab = o->n_tab; tr.integ = 4;
+    tr.Bt = Btab + (size_t)(btab_idx ? btab_idx[t] : t) * 3 * o->n_tab;
+    tr.tau0 = tau0[t]; tr.dtau = dtau[t]; tr.dt = dt[t];
+    std::memcpy(tr.ph.J, Jmat + 9 * t, sizeof(tr.ph.J));
+    inv3(tr.ph.J, tr.ph.Jinv);
+    tr.ph.u_scale = o->u_scale;
+    const double* Xt = X + (size_t)7 * N * t;
+    const double* Ut = U + (size_t)3 * (N - 1) * t;
+    const double h = tr.dt, hl = o->linearize_dt_sq ? h * h : h, frac = hl / h;
+    // gains: Jacobians of the rk4-discretised gain_simulator at (X_k, U_k) (src/attitude_controller.jl:95-119) ...
+    std::vector<double> Ah((size_t)36 * (N - 1)), Bh((size_t)18 * (N - 1)), Kt((size_t)18 * (N - 1));
+    for (int k = 0; k < N - 1; ++k) {
+      double A7[49], B7[21];
+      discrete_jacobian(4, Xt + 7 * k, Ut + 3 * k, brow(tr, k, 0.0), brow(tr, k, 0.5 * frac), brow(tr, k, frac), hl, tr.ph, A7, B7);
+      // ... reduced with G(q_k), G(q_{k+1}) (:59-81)
+      orc_reduce_error_state(A7, B7, Xt + 7 * k + 3, Xt + 7 * (k + 1) + 3, Ah.data() + (size_t)36 * k, Bh.data() + (size_t)18 * k);
+    }
+    double Q[36] = {0}, Qf[36] = {0}, R[9] = {0};
+    for (int i = 0; i < 6; ++i) { Q[i * 6 + i] = Qd[6 * t + i]; Qf[i * 6 + i] = Qfd[6 * t + i]; }
+    for (int i = 0; i < 3; ++i) R[i * 3 + i] = Rd[3 * t + i];
+    orc_tvlqr_riccati(N, Ah.data(), Bh.data(), Q, R, Qf, Kt.data());   // (:83-92)
+    // closed loop (:39-45)
+    double* Xs = X_sim + (size_t)7 * N * t;
+    double* Us = U_sim + (size_t)3 * (N - 1) * t;
+    for (int i = 0; i < 7; ++i) Xs[i] = x0_sim[7 * t + i];
+    for (int k = 0; k < N - 1; ++k) {
+      const double* xs = Xs + 7 * k;
+      const double* xr = Xt + 7 * k;
+      double dX[6], qi[4] = {xr[3], -xr[4], -xr[5], -xr[6]}, qe[4];
+      for (int i = 0; i < 3; ++i) dX[i] = xs[i] - xr[i];
+      qmult<double>(qi, xs + 3, qe);
+      for (int i = 0; i < 3; ++i) dX[3 + i] = qe[1 + i];
+      double us[3];
+      for (int a = 0; a < 3; ++a) {
+        double v = Ut[3 * k + a];
+        for (int j = 0; j < 6; ++j) v -= Kt[(size_t)18 * k + a * 6 + j] * dX[j];
+        us[a] = v;
+        Us[3 * k + a] = v;
+      }
+      const double* nz = noise ? noise + ((size_t)t * (N - 1) + k) * 36 : nullptr;
+      const double *b0 = brow(tr, k, 0.0), *b1 = brow(tr, k, 0.5), *b2 = brow(tr, k, 1.0);
+      double k1[7], k2[7], k3[7], k4[7], tmp[7];
+      sim_dyn(xs, us, b0, nz, tr.ph, k1);
+      for (int i = 0; i < 7; ++i) { k1[i] *= h; tmp[i] = xs[i] + k1[i] / 2; }
+      sim_dyn(tmp, us, b1, nz ? nz + 9 : nullptr, tr.ph, k2);
+      for (int i = 0; i < 7; ++i) { k2[i] *= h; tmp[i] = xs[i] + k2[i] / 2; }
+      sim_dyn(tmp, us, b1, nz ? nz + 18 : nullptr, tr.ph, k3);
+      for (int i = 0; i < 7; ++i) { k3[i] *= h; tmp[i] = xs[i] + k3[i]; }
+      sim_dyn(tmp, us, b2, nz ? nz + 27 : nullptr, tr.ph, k4);
+      for (int i = 0; i < 7; ++i) { k4[i] *= h; Xs[7 * (k + 1) + i] = xs[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6; }
+    }
+    if (K_lqr)
+      for (int k = 0; k < N - 1; ++k)
+        for (int a = 0; a < 3; ++a)
+          for (int j = 0; j < 6; ++j) K_lqr[((size_t)t * (N - 1) + k) * 18 + j * 3 + a] = Kt[(size_t)18 * k + a * 6 + j];
+    // slew-time statistic (src/monte_carlo.jl:242-262; the norm is taken at sample j — the reference indexes the
+    // run number there, an evident slip)
+    tsat_tvlqr_stats& st = stats[t];
+    st.slew_index = 0; st.failed = 1; st.slew_time = h * N;
+    const double* qf = xf + 7 * t + 3;
+    double qfi[4] = {qf[0], -qf[1], -qf[2], -qf[3]};
+    for (int j = 1; j <= N; ++j) {
+      const double* xs = Xs + 7 * (j - 1);
+      double wn = std::sqrt(xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2]), qe[4];
+      qmult<double>(qfi, xs + 3, qe);
+      double ang = 2.0 * std::acos(std::min(qe[0], 1.0));
+      if (j > o->min_steps && wn < o->w_tol && ang < o->angle_tol && st.slew_index == 0) { st.slew_index = j; st.failed = 0; st.slew_time = h * j; }
+      if (j == N) { st.final_w_norm = wn; st.final_angle = ang; }
+    }
+  }
+  return 0;
+}
+
 int orc_num_procs(void) {
 #ifdef _OPENMP
   return omp_get_num_procs();

@@ -61,6 +61,25 @@ class Emu:
         return dict(X=X, U=U, K=K, stats=stats, trace=trace)
 
 
+    def tvlqr(self, batch, X, U, Qd, Qfd, Rd, x0_sim, noise=None, opts=None):
+        T, N = batch.T, batch.N
+        o = opts or self.abi.TvlqrOptions(0, 0, 1, 10, 1e-2, 0.05, 0.08727)
+        o.n_knots, o.n_tab = N, batch.n_tab
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        X, U, Qd, Qfd, Rd, x0_sim = c(X), c(U), c(Qd), c(Qfd), c(Rd), c(x0_sim)
+        noise = None if noise is None else c(noise)
+        Xs = np.zeros((T, N, 7)); Us = np.zeros((T, N - 1, 3)); K = np.zeros((T, N - 1, 6, 3))
+        st = np.zeros(T, dtype=self.abi.TVLQR_STATS_DTYPE)
+        d = self.abi.as_dp
+        rc = self.lib.emu_tvlqr_batch(C.byref(o), C.c_int64(T), C.c_int64(batch.Btab.shape[0]), d(X), d(U), d(batch.xf),
+                                      d(batch.Btab), self.abi.as_ip(batch.btab_idx), d(batch.tau0), d(batch.dtau), d(batch.dt),
+                                      d(batch.Jmat), d(Qd), d(Qfd), d(Rd), d(x0_sim), d(noise), d(Xs), d(Us), d(K),
+                                      st.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"emu_tvlqr_batch rc={rc}")
+        return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)
+
+
 @pytest.fixture(scope="session")
 def emu(pkg):
     return Emu(pkg._abi)

@@ -71,3 +71,45 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
   for (int64_t e = 0; e < T * (int64_t)N; ++e) export_record<double>(e, N, n_knots, XU.data(), KD.data(), X, U, K);
   return 0;
 }
+
+template <int DIAGJ>
+static void run_tv_block(const TvArgs<double>& a, int traj) {
+  std::vector<double> lds(LDS_REALS, 0.0);
+  std::barrier<> bar(WAVE);
+  tsat_emu::g_bar = &bar;
+  tsat_emu::g_lds = lds.data();
+  std::vector<std::thread> th;
+  for (int l = 0; l < WAVE; ++l)
+    th.emplace_back([&, l]() {
+      tsat_emu::g_lane = l;
+      tvlqr_trajectory<double, DIAGJ>(a, traj);
+    });
+  for (auto& t : th) t.join();
+}
+
+extern "C" int emu_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, const double* X, const double* U,
+                               const double* xf, const double* Btab, const int32_t* btab_idx, const double* tau0,
+                               const double* dtau, const double* dt, const double* Jmat, const double* Qd,
+                               const double* Qfd, const double* Rd, const double* x0_sim, const double* noise,
+                               double* X_sim, double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats) {
+  if (!check_tv_options(*o).empty()) return -1;
+  const int N = o->n_knots, n_tab = o->n_tab;
+  std::vector<double> P((size_t)T * PSTRIDE), BT((size_t)n_btab * n_tab * 4), XUR((size_t)T * N * XUW),
+      KD((size_t)T * (N - 1) * KDW, 0.0), XS((size_t)T * N * XUW, 0.0);
+  std::vector<int> bidx(T);
+  pack_tv_params<double>(T, x0_sim, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, P.data());
+  pack_btab<double>(n_btab, n_tab, Btab, BT.data());
+  pack_xu_records<double>(T, N, X, U, XUR.data());
+  for (int64_t t = 0; t < T; ++t) bidx[t] = btab_idx ? btab_idx[t] : (int)t;
+  TvArgs<double> a;
+  a.T = (int)T; a.N = N; a.n_tab = n_tab; a.lin_sq = o->linearize_dt_sq; a.min_steps = o->min_steps;
+  a.us = o->u_scale; a.w_tol = o->w_tol; a.ang_tol = o->angle_tol;
+  a.P = P.data(); a.BT = BT.data(); a.bidx = bidx.data(); a.XUR = XUR.data(); a.NZ = noise; a.KD = KD.data(); a.XS = XS.data();
+  a.stats = stats;
+  const int cls = inertia_class(T, Jmat);
+  for (int t = 0; t < (int)T; ++t) {
+    if (cls == 2) run_tv_block<2>(a, t); else if (cls == 1) run_tv_block<1>(a, t); else run_tv_block<0>(a, t);
+  }
+  unpack_tv<double>(T, N, XS.data(), KD.data(), X_sim, U_sim, K_lqr);
+  return 0;
+}

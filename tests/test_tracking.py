@@ -1,0 +1,124 @@
+"""Closed-loop TVLQR tracking: oracle pinned against a NumPy transcription of the reference text,
+emulated kernel and (gpu tier) the real kernel against the oracle."""
+import numpy as np
+import pytest
+
+import refmath as rm
+from conftest import oracle_options
+
+
+def _solved(pkg, ol, T=2, N=60, seed=61, budget=(3, 6)):
+    b = pkg.slew_setup.workload_monte_carlo(T=T, N=N, seed=seed)
+    r = ol.solve_batch(b, oracle_options(ol, max_outer=budget[0], max_inner=budget[1], dj_counter_limit=1))
+    return b, r
+
+
+def _setup(pkg, b, seed=5, noisy=True):
+    tr = pkg.tracking
+    rng = np.random.default_rng(seed)
+    Qd, Qfd, Rd = tr.tvlqr_weights(b.T, r=0.5e3)
+    x0s = tr.perturbed_initial_state(b.x0, rng)
+    nz = tr.simulator_noise(b.T, b.N, rng) if noisy else None
+    return Qd, Qfd, Rd, x0s, nz
+
+
+def test_oracle_tracking_matches_reference_text(pkg, ol):
+    """gains: NumPy restatement of attitude_lqr (src/attitude_controller.jl:50-119) with central-difference Jacobians of
+    the rk4 map over dt^2; closed loop: src/attitude_controller.jl:39-45 with the noise-free plant"""
+    b, r = _solved(pkg, ol, T=1, N=40)
+    Qd, Qfd, Rd, x0s, _ = _setup(pkg, b, noisy=False)
+    tv = ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s)
+    X, U, N, dt = r["X"][0], r["U"][0], b.N, 0.2
+    J = np.diag([0.00125] * 3)
+    Bt = b.Btab[0]
+
+    def f(x, u, row):      # gain_simulator on the 7-state with the row already looked up
+        return rm.attitude_dynamics(x, u / 100.0, rm.qrot(x[3:7] / np.linalg.norm(x[3:7]), Bt[row]), J)
+
+    def rk4_lin(x, u, k):  # augmented rk4 with dt = S[end]^2 (src/attitude_controller.jl:134-145); rows stay at knot k
+        h = dt * dt
+        k1 = f(x, u, k) * h; k2 = f(x + k1 / 2, u, k) * h; k3 = f(x + k2 / 2, u, k) * h; k4 = f(x + k3, u, k) * h
+        return x + (k1 + 2 * k2 + 2 * k3 + k4) / 6
+
+    A = np.zeros((N - 1, 6, 6)); B = np.zeros((N - 1, 6, 3))
+    for k in range(N - 1):
+        Aq = np.zeros((7, 7)); Bq = np.zeros((7, 3))
+        for j in range(7):
+            e = np.zeros(7); e[j] = 1e-6
+            Aq[:, j] = (rk4_lin(X[k] + e, U[k], k) - rk4_lin(X[k] - e, U[k], k)) / 2e-6
+        for j in range(3):
+            e = np.zeros(3); e[j] = 1e-3
+            Bq[:, j] = (rk4_lin(X[k], U[k] + e, k) - rk4_lin(X[k], U[k] - e, k)) / 2e-3
+        A[k], B[k] = rm.reduce_error_state(Aq, Bq, X[k, 3:7], X[k + 1, 3:7])
+    K = rm.tvlqr_riccati(A, B, np.diag(Qd[0]), np.diag(Rd[0]), np.diag(Qfd[0]))
+    np.testing.assert_allclose(tv["K"][0].transpose(0, 2, 1), K, rtol=2e-5, atol=1e-8)
+
+    xs = x0s[0].copy()
+    for k in range(N - 1):
+        dX = np.r_[xs[:3] - X[k, :3], rm.qmult(rm.q_inv(X[k, 3:7]), xs[3:7])[1:]]
+        us = U[k] - tv["K"][0, k].T @ dX
+        np.testing.assert_allclose(tv["U_sim"][0, k], us, atol=1e-12)
+        g = lambda x, kk: f(x, us, kk)
+        k1 = g(xs, k) * dt; k2 = g(xs + k1 / 2, k) * dt; k3 = g(xs + k2 / 2, k) * dt; k4 = g(xs + k3, min(k + 1, N - 1)) * dt
+        xs = xs + (k1 + 2 * k2 + 2 * k3 + k4) / 6
+        np.testing.assert_allclose(tv["X_sim"][0, k + 1], xs, atol=1e-12)
+
+
+def test_oracle_tracking_statistic(pkg, ol):
+    """src/monte_carlo.jl:242-262 recomputed from X_sim"""
+    b, r = _solved(pkg, ol, T=3, N=400, budget=(5, 10))
+    Qd, Qfd, Rd, x0s, nz = _setup(pkg, b)
+    tv = ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz)
+    for t in range(b.T):
+        idx = 0
+        for j in range(1, b.N + 1):
+            xs = tv["X_sim"][t, j - 1]
+            ang = 2 * np.arccos(min(rm.qmult(rm.q_inv(b.xf[t, 3:]), xs[3:7])[0], 1.0))
+            if j > 10 and np.linalg.norm(xs[:3]) < 0.05 and ang < 0.08727:
+                idx = j
+                break
+        st = tv["stats"][t]
+        assert st["slew_index"] == idx and st["failed"] == (idx == 0)
+        assert st["slew_time"] == pytest.approx(0.2 * (idx if idx else b.N))
+    assert np.max(np.abs(tv["X_sim"] - r["X"])) < 0.05          # the loop tracks the plan
+
+
+@pytest.mark.parametrize("noisy", [False, True])
+def test_emulated_tracking_kernel_matches_oracle(pkg, ol, emu, noisy):
+    b, r = _solved(pkg, ol, T=2, N=60)
+    Qd, Qfd, Rd, x0s, nz = _setup(pkg, b, noisy=noisy)
+    ref = ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz)
+    got = emu.tvlqr(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz)
+    _same_tracking(ref, got)
+
+
+def _same_tracking(ref, got):
+    kscale = max(float(np.max(np.abs(ref["K"]))), 1.0)
+    assert np.max(np.abs(ref["K"] - got["K"])) < 1e-8 * kscale
+    assert np.max(np.abs(ref["X_sim"] - got["X_sim"])) < 1e-9
+    assert np.max(np.abs(ref["U_sim"] - got["U_sim"])) < 1e-8
+    assert np.array_equal(ref["stats"]["slew_index"], got["stats"]["slew_index"])
+    assert np.array_equal(ref["stats"]["failed"], got["stats"]["failed"])
+    np.testing.assert_allclose(got["stats"]["final_angle"], ref["stats"]["final_angle"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(got["stats"]["final_w_norm"], ref["stats"]["final_w_norm"], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_gpu_tracking_matches_oracle(pkg, ol):
+    """solve on the GPU, track on the GPU (1000 knots, noise injected), compare both stages with the oracle"""
+    to, tr = pkg.trajopt, pkg.tracking
+    b = pkg.slew_setup.workload_monte_carlo(T=12, N=1000)
+    opts = to.AugmentedLagrangianSolverOptions()
+    opts.iterations, opts.opts_uncon.iterations, opts.opts_uncon.dJ_counter_limit = 5, 10, 1
+    s = to.AugmentedLagrangianSolver(None, opts)
+    res = to.solve_(to.BatchProblem.from_arrays(b), s)
+    for noisy in (False, True):
+        Qd, Qfd, Rd, x0s, nz = _setup(pkg, b, noisy=noisy)
+        got = tr.attitude_simulation(s, b, res["X"], res["U"], x0s, Qd, Qfd, Rd, noise=nz)
+        ref = ol.tvlqr_batch(b, res["X"], res["U"], Qd, Qfd, Rd, x0s, noise=nz, nthreads=min(12, ol.num_procs()))
+        _same_tracking(ref, got)
+    got2 = tr.attitude_simulation(s, b, res["X"], res["U"], x0s, Qd, Qfd, Rd, noise=nz, linearize_dt_sq=False)
+    o = ol.tvlqr_default_options(); o.linearize_dt_sq = 0
+    _same_tracking(ol.tvlqr_batch(b, res["X"], res["U"], Qd, Qfd, Rd, x0s, noise=nz, opts=o, nthreads=8), got2)
+    assert np.max(np.abs(got2["K"] - got["K"])) > 1e-3          # the dt^2 quirk changes the gains
+    s.close()

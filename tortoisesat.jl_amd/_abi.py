@@ -52,6 +52,17 @@ STATS_DTYPE = np.dtype(
 )
 assert STATS_DTYPE.itemsize == C.sizeof(Stats) == 64
 
+class TvlqrOptions(C.Structure):
+    """``tsat_tvlqr_options`` — closed-loop tracking of a solved slew (src/attitude_controller.jl:1-119)."""
+
+    _fields_ = [("n_knots", C.c_int32), ("n_tab", C.c_int32), ("linearize_dt_sq", C.c_int32), ("min_steps", C.c_int32),
+                ("u_scale", C.c_double), ("w_tol", C.c_double), ("angle_tol", C.c_double)]
+
+
+TVLQR_STATS_DTYPE = np.dtype([("slew_index", "<i4"), ("failed", "<i4"), ("slew_time", "<f8"), ("final_w_norm", "<f8"),
+                              ("final_angle", "<f8")])
+assert TVLQR_STATS_DTYPE.itemsize == 32
+
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 
@@ -74,6 +85,9 @@ PROTOTYPES = {
     "tsat_batch_bytes": (C.c_int64, [C.c_void_p]),
     "tsat_batch_trace": (C.c_int, [C.c_void_p, C.c_int32]),
     "tsat_batch_trace_download": (C.c_int, [C.c_void_p, _dp]),
+    "tsat_tvlqr_default_options": (None, [C.POINTER(TvlqrOptions)]),
+    "tsat_tvlqr_batch": (C.c_int, [C.c_void_p, C.POINTER(TvlqrOptions), C.c_int64, C.c_int64, _dp, _dp, _dp, _dp, _ip,
+                                   _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
 }
 
 LIB_NAME = "libtortoise_hip.so"

@@ -171,6 +171,10 @@ TSAT_DEV double fmaxabs_(double a, double b) { const double c = std::fabs(b); re
 TSAT_DEV double floor_(double a) { return std::floor(a); }
 TSAT_DEV double fma_(double a, double b, double c) { return std::fma(a, b, c); }
 TSAT_DEV double rcp_(double a) { return 1.0 / a; }
+TSAT_DEV double sqrt_(double a) { return std::sqrt(a); }
+TSAT_DEV double sin_(double a) { return std::sin(a); }
+TSAT_DEV double cos_(double a) { return std::cos(a); }
+TSAT_DEV double acos_(double a) { return std::acos(a); }
 #else
 // v_rsq_f64 seed (rel. error <= 5.3e-8, profiles/r01/rsq_rcp_accuracy.txt) + ONE third-order step:
 // y (1 + e/2 + 3e^2/8), e = 1 - s y^2  ->  error O(e^3) ~ 1e-22, i.e. rounding only; 5 instructions instead of the 8
@@ -196,6 +200,10 @@ TSAT_DEV double rcp_(double a) {
   const double p = __builtin_fma(e, e, e);
   return __builtin_fma(y, p, y);
 }
+TSAT_DEV double sqrt_(double a) { return __builtin_sqrt(a); }
+TSAT_DEV double sin_(double a) { return ::sin(a); }     // HIP device math (ocml); used by the tracking kernel only
+TSAT_DEV double cos_(double a) { return ::cos(a); }
+TSAT_DEV double acos_(double a) { return ::acos(a); }
 #endif
 
 // phase timing for the diagnostic build (-DTSAT_PROFILE): shader-clock stamps accumulated per phase and written to
@@ -1236,6 +1244,218 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
 #else
     (void)pc_fwd; (void)pc_par;
 #endif
+  }
+}
+
+// ==================================================================================================
+// Closed-loop TVLQR tracking of a solved slew — the reference's attitude_simulation
+// (src/attitude_controller.jl:1-119) for a batch: one trajectory per wavefront, reusing the solver's machinery:
+//   gains     Jacobian lanes (rk4 over the linearisation step) + in-place G(q) reduction + riccati_chunk<real,6>.
+//             The iLQR recursion with zero gradients, Q0 = Q_lqr, luu = R_lqr, S_N = Qf_lqr is the TVLQR Riccati
+//             equation in Schur form; its gain is the negative of the reference's K (u = U - K dX).
+//   tracking  one sequential rk4 rollout of the (optionally noise-driven) plant, src/simulator.jl
+//   statistic first sample with |w| < w_tol and error angle < angle_tol (src/monte_carlo.jl:242-262), lanes = samples
+// ==================================================================================================
+constexpr int P_QATT = 58;   // spare slots of the parameter record: attitude weights of Q_lqr (3)
+
+template <typename real>
+struct TvArgs {
+  int T, N, n_tab, lin_sq, min_steps;
+  real us, w_tol, ang_tol;
+  const real* P;      // [T][PSTRIDE]
+  const real* BT;     // [n_btab][n_tab][4]
+  const int* bidx;    // [T]
+  const real* XUR;    // [T][N][10]   optimised (X,U) records
+  const real* NZ;     // [T][N-1][4][9] noise or null
+  real* KD;           // [T][N-1][24] gains (solver sign) + unused d
+  real* XS;           // [T][N][10]   simulated (x,u) records
+  tsat_tvlqr_stats* stats;
+};
+
+// plant with the reference's three noise sources injected (src/simulator.jl:5-23); nz == null: src/gain_simulator.jl
+template <typename real, int DIAGJ>
+TSAT_DEV void dyn_sim_h(const Traj<real>& tr, const real x[7], const real us[3], const real b[3],
+                        const TSAT_GLOBAL real* nz, real k[7]) {
+  real xx[7], bb[3];
+  for (int i = 0; i < 7; ++i) xx[i] = x[i];
+  for (int i = 0; i < 3; ++i) bb[i] = b[i];
+  if (nz) {
+    const real rn = rsqrt_<real>(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+    const real q0 = x[3] * rn, q1 = x[4] * rn, q2 = x[5] * rn, q3 = x[6] * rn;
+    const real n0 = nz[3], n1 = nz[4], n2 = nz[5];
+    const real th = sqrt_(n0 * n0 + n1 * n1 + n2 * n2);
+    const real sh = sin_((real)0.5 * th) / th, ch = cos_((real)0.5 * th);
+    const real d1 = n0 * sh, d2 = n1 * sh, d3 = n2 * sh;
+    for (int i = 0; i < 3; ++i) { xx[i] = x[i] + nz[i]; bb[i] = b[i] + nz[6 + i]; }
+    xx[3] = q0 * ch - (q1 * d1 + q2 * d2 + q3 * d3);          // qmult(q, [cos; r sin])
+    xx[4] = q0 * d1 + ch * q1 + (q2 * d3 - q3 * d2);
+    xx[5] = q0 * d2 + ch * q2 + (q3 * d1 - q1 * d3);
+    xx[6] = q0 * d3 + ch * q3 + (q1 * d2 - q2 * d1);
+  }
+  StageBase<real> sb;
+  dyn_h<real, DIAGJ>(tr, xx, us, bb, k, sb);   // normalises again inside: exact for the noise-free plant, 1 ulp otherwise
+}
+
+template <typename real, int DIAGJ>
+TSAT_PHASE void tv_jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, real hl, real frac) {
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE();
+  if (lane < nk) {
+    Traj<real> tr = load_traj<real>(N, n_tab, p.bt);
+    tr.h = hl; tr.hh = (real)0.5 * hl;
+    for (int i = 0; i < 9; ++i) tr.hJi[i] = hl * lds[L_TR + P_JI + i];
+    const int k = k0 + lane;
+    const TSAT_GLOBAL real* xu = p.XU + (size_t)k * XUW;
+    real x[7], u[3], b0[3], b1[3], b2[3];
+    for (int i = 0; i < 7; ++i) x[i] = xu[i];
+    for (int c = 0; c < 3; ++c) u[c] = xu[7 + c];
+    const TSAT_GLOBAL real* p0 = tr.bt + (size_t)brow_index(tr, k, 0.0) * 4;
+    const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5 * (double)frac) * 4;
+    const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, (double)frac) * 4;
+    for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
+    real* rc = lds + L_REC + lane * BwdCfg<1>::RECS;
+    real* F = rc + R_F;
+    rk_jacobian<real, 4, DIAGJ, 1>(tr, x, u, b0, b1, b2, F);
+    real qk[4], qn[4];
+    for (int i = 0; i < 4; ++i) { qk[i] = x[3 + i]; qn[i] = xu[XUW + 3 + i]; }
+    for (int i = 0; i < 7; ++i) {
+      real o[3];
+      gt_apply(qk, F[3 * FS + i], F[4 * FS + i], F[5 * FS + i], F[6 * FS + i], o);
+      F[3 * FS + i] = o[0]; F[4 * FS + i] = o[1]; F[5 * FS + i] = o[2];
+    }
+    for (int a = 0; a < 3; ++a)
+      for (int i = 0; i < 7; ++i) F[(6 + a) * FS + i] = F[(7 + a) * FS + i];
+    for (int c = 0; c < 9; ++c) {
+      real o[3];
+      gt_apply(qn, F[c * FS + 3], F[c * FS + 4], F[c * FS + 5], F[c * FS + 6], o);
+      F[c * FS + 3] = o[0]; F[c * FS + 4] = o[1]; F[c * FS + 5] = o[2];
+    }
+    for (int i = 0; i < 7; ++i) rc[R_LX + i] = 0;
+    for (int c = 0; c < 3; ++c) { rc[R_LU + c] = 0; rc[R_LUU + c] = lds[L_TR + P_RD + c]; }
+    rc[R_QQ + 0] = lds[L_TR + P_QATT + 0]; rc[R_QQ + 1] = 0; rc[R_QQ + 2] = 0;
+    rc[R_QQ + 3] = lds[L_TR + P_QATT + 1]; rc[R_QQ + 4] = 0; rc[R_QQ + 5] = lds[L_TR + P_QATT + 2];
+  }
+}
+
+template <typename real>
+TSAT_DEV real wave_min(real v, real* red) {
+  const int lane = TSAT_LANE();
+  for (int s = 1; s < WAVE; s <<= 1) {
+    red[lane] = v;
+    TSAT_SYNC_LDS();
+    real o = red[lane ^ s];
+    v = (o < v) ? o : v;
+    TSAT_SYNC_LDS();
+  }
+  return v;
+}
+
+template <typename real, int DIAGJ>
+TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE();
+  const int N = a.N, n_tab = a.n_tab;
+  TPtrs<real> p;
+  p.XU = (TSAT_GLOBAL real*)(a.XUR + (size_t)traj * N * XUW);
+  p.KD = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * (N - 1) * KDW);
+  p.LAM = nullptr; p.CAND = nullptr;
+  p.bt = (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[traj] * n_tab * 4);
+  stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)traj * PSTRIDE), a.us);
+  if (lane < 3) lds[L_TR + P_QATT + lane] = a.P[(size_t)traj * PSTRIDE + P_QATT + lane];
+  TSAT_SYNC();
+  const real h = lds[L_TR + P_DT];
+  const real hl = a.lin_sq ? h * h : h;
+  const real frac = hl / h;
+  // ---- gains: terminal S = Qf_lqr, then chunks of Jacobian lanes + Riccati ----------------------------
+  {
+    const int r1 = lane & 7, c1 = lane >> 3;
+    if (c1 < 6 && r1 <= 6) lds[L_ST + r1 * 9 + c1] = (r1 == c1) ? lds[L_TR + P_QFD + c1] : (real)0;
+    if (lane == 0) { lds[L_ZERO] = 0; lds[L_SINK] = 0; }
+  }
+  TSAT_SYNC();
+  constexpr int CHB = BwdCfg<1>::CHB;
+  BwdOut<real> acc;
+  acc.dV1 = 0; acc.dV2 = 0; acc.pd_ok = 1;
+  for (int ch = (N - 1 + CHB - 1) / CHB - 1; ch >= 0 && acc.pd_ok; --ch) {
+    const int k0 = ch * CHB;
+    const int nk = (N - 1 - k0 < CHB) ? (N - 1 - k0) : CHB;
+    tv_jacobian_chunk<real, DIAGJ>(p, N, n_tab, k0, nk, hl, frac);
+    TSAT_SYNC();
+    acc = riccati_chunk<real, 6>(p.KD, k0, nk, (real)0, acc.dV1, acc.dV2);
+    TSAT_SYNC();
+  }
+  // ---- tracking: x_sim(k+1) = rk4(plant)(x_sim(k), U(k) - K(k) dX(k))   (src/attitude_controller.jl:39-45) -----
+  const Traj<real> tr = load_traj<real>(N, n_tab, p.bt);
+  TSAT_GLOBAL real* XSg = (TSAT_GLOBAL real*)(a.XS + (size_t)traj * N * XUW);
+  const TSAT_GLOBAL real* NZg = a.NZ ? (const TSAT_GLOBAL real*)(a.NZ + (size_t)traj * (N - 1) * 36) : nullptr;
+  real x[7];
+  for (int i = 0; i < 7; ++i) x[i] = lds[L_TR + P_X0 + i];
+  for (int k = 0; k < N - 1; ++k) {
+    const TSAT_GLOBAL real* xr = p.XU + (size_t)k * XUW;
+    const TSAT_GLOBAL real* kd = p.KD + (size_t)k * KDW;
+    real dX[6];
+    for (int i = 0; i < 3; ++i) dX[i] = x[i] - xr[i];
+    {  // vector part of q_ref^-1 (x) q_sim  (:42)
+      const real s1 = xr[3], a1 = -xr[4], a2 = -xr[5], a3 = -xr[6];
+      dX[3] = s1 * x[4] + x[3] * a1 + (a2 * x[6] - a3 * x[5]);
+      dX[4] = s1 * x[5] + x[3] * a2 + (a3 * x[4] - a1 * x[6]);
+      dX[5] = s1 * x[6] + x[3] * a3 + (a1 * x[5] - a2 * x[4]);
+    }
+    real u[3];
+    for (int c = 0; c < 3; ++c) {
+      real v = xr[7 + c];
+      for (int j = 0; j < 6; ++j) v += kd[c * 7 + j] * dX[j];   // kd = -K_lqr
+      u[c] = v;
+    }
+    if (lane == 0) {
+      for (int i = 0; i < 7; ++i) XSg[(size_t)k * XUW + i] = x[i];
+      for (int c = 0; c < 3; ++c) XSg[(size_t)k * XUW + 7 + c] = u[c];
+    }
+    real b0[3], b1[3], b2[3];
+    const TSAT_GLOBAL real* p0 = tr.bt + (size_t)brow_index(tr, k, 0.0) * 4;
+    const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
+    const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
+    for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
+    const TSAT_GLOBAL real* nz = NZg ? NZg + (size_t)k * 36 : nullptr;
+    const real us[3] = {u[0] * tr.us, u[1] * tr.us, u[2] * tr.us};
+    real k1[7], k2[7], k3[7], k4[7], t[7];
+    dyn_sim_h<real, DIAGJ>(tr, x, us, b0, nz, k1);
+    for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k1[i];
+    dyn_sim_h<real, DIAGJ>(tr, t, us, b1, nz ? nz + 9 : nullptr, k2);
+    for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k2[i];
+    dyn_sim_h<real, DIAGJ>(tr, t, us, b1, nz ? nz + 18 : nullptr, k3);
+    for (int i = 0; i < 7; ++i) t[i] = x[i] + k3[i];
+    dyn_sim_h<real, DIAGJ>(tr, t, us, b2, nz ? nz + 27 : nullptr, k4);
+    for (int i = 0; i < 7; ++i) x[i] = x[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) * (real)(1.0 / 6.0);
+  }
+  if (lane == 0) {
+    for (int i = 0; i < 7; ++i) XSg[(size_t)(N - 1) * XUW + i] = x[i];
+    for (int c = 0; c < 3; ++c) XSg[(size_t)(N - 1) * XUW + 7 + c] = 0;
+  }
+  TSAT_SYNC();
+  // ---- statistic (src/monte_carlo.jl:242-262): lanes = samples ------------------------------------------
+  real first = (real)(N + 1), wN = 0, angN = 0;
+  const real qf0 = tr.xf[3], qf1 = -tr.xf[4], qf2 = -tr.xf[5], qf3 = -tr.xf[6];
+  for (int j = 1 + lane; j <= N; j += WAVE) {
+    const TSAT_GLOBAL real* xs = XSg + (size_t)(j - 1) * XUW;
+    const real wn = sqrt_(xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2]);
+    const real e0 = qf0 * xs[3] - (qf1 * xs[4] + qf2 * xs[5] + qf3 * xs[6]);
+    const real ang = 2 * acos_(e0 < 1 ? e0 : (real)1);
+    if (j > a.min_steps && wn < a.w_tol && ang < a.ang_tol && (real)j < first) first = (real)j;
+    if (j == N) { wN = wn; angN = ang; }
+  }
+  first = wave_min(first, lds + L_RED);
+  const int srcN = (N - 1) % WAVE;
+  wN = wave_bcast(wN, srcN, lds + L_RED);
+  angN = wave_bcast(angN, srcN, lds + L_RED);
+  if (lane == 0) {
+    tsat_tvlqr_stats& st = a.stats[traj];
+    const bool ok = first <= (real)N;
+    st.slew_index = ok ? (int)first : 0;
+    st.failed = ok ? 0 : 1;
+    st.slew_time = (double)h * (ok ? (double)first : (double)N);
+    st.final_w_norm = (double)wN;
+    st.final_angle = (double)angN;
   }
 }
 

@@ -127,4 +127,62 @@ TSAT_DEV void export_record(int64_t e, int N, const int* nk, const real* XU, con
   }
 }
 
+// ---- closed-loop tracking (tsat_tvlqr_batch): marshalling --------------------------------------------------
+// parameter record for the tracking kernel: x0 <- perturbed initial state, Qd[0:3]/P_QATT <- Q_lqr rate / attitude
+// weights, Qfd[0:6] <- Qf_lqr, Rd <- R_lqr (src/TortoiseSat.jl:251-260)
+template <typename real>
+void pack_tv_params(int64_t T, const double* x0_sim, const double* xf, const double* tau0, const double* dtau,
+                    const double* dt, const double* Jmat, const double* Qd6, const double* Qfd6, const double* Rd3,
+                    real* P) {
+  for (int64_t t = 0; t < T; ++t) {
+    real* p = P + (size_t)t * PSTRIDE;
+    for (int i = 0; i < PSTRIDE; ++i) p[i] = 0;
+    for (int i = 0; i < 7; ++i) { p[P_X0 + i] = (real)x0_sim[7 * t + i]; p[P_XF + i] = (real)xf[7 * t + i]; }
+    for (int i = 0; i < 3; ++i) {
+      p[P_QD + i] = (real)Qd6[6 * t + i];
+      p[P_QATT + i] = (real)Qd6[6 * t + 3 + i];
+      p[P_RD + i] = (real)Rd3[3 * t + i];
+    }
+    for (int i = 0; i < 6; ++i) p[P_QFD + i] = (real)Qfd6[6 * t + i];
+    double Jr[9], Ji[9];
+    inertia_inverse_rm(Jmat + 9 * t, Jr, Ji);
+    for (int i = 0; i < 9; ++i) { p[P_J + i] = (real)Jr[i]; p[P_JI + i] = (real)Ji[i]; }
+    p[P_TAU0] = (real)tau0[t];
+    p[P_DTAU] = (real)dtau[t];
+    p[P_DT] = (real)dt[t];
+  }
+}
+// X (T,N,7) + U (T,N-1,3) -> knot records [T][N][10]
+template <typename real>
+void pack_xu_records(int64_t T, int N, const double* X, const double* U, real* XU) {
+  for (int64_t t = 0; t < T; ++t)
+    for (int k = 0; k < N; ++k) {
+      real* r = XU + ((size_t)t * N + k) * XUW;
+      for (int i = 0; i < 7; ++i) r[i] = (real)X[((size_t)t * N + k) * 7 + i];
+      for (int c = 0; c < 3; ++c) r[7 + c] = (k < N - 1) ? (real)U[((size_t)t * (N - 1) + k) * 3 + c] : (real)0;
+    }
+}
+// simulated records + solver-sign gains -> X_sim, U_sim, K_lqr (3x6x(N-1)xT column-major, K_lqr = -K_solver)
+template <typename real>
+void unpack_tv(int64_t T, int N, const real* XS, const real* KD, double* X_sim, double* U_sim, double* K_lqr) {
+  for (int64_t t = 0; t < T; ++t)
+    for (int k = 0; k < N; ++k) {
+      const real* r = XS + ((size_t)t * N + k) * XUW;
+      for (int i = 0; i < 7; ++i) X_sim[((size_t)t * N + k) * 7 + i] = (double)r[i];
+      if (k < N - 1) {
+        const size_t ek = (size_t)t * (N - 1) + k;
+        for (int c = 0; c < 3; ++c) U_sim[ek * 3 + c] = (double)r[7 + c];
+        if (K_lqr)
+          for (int j = 0; j < 6; ++j)
+            for (int c = 0; c < 3; ++c) K_lqr[ek * 18 + j * 3 + c] = -(double)KD[ek * KDW + c * 7 + j];
+      }
+    }
+}
+inline std::string check_tv_options(const tsat_tvlqr_options& o) {
+  if (o.n_knots < 2) return "n_knots must be >= 2";
+  if (o.n_tab < 1) return "n_tab must be >= 1";
+  if (o.min_steps < 0) return "min_steps must be >= 0";
+  return "";
+}
+
 }  // namespace tsat

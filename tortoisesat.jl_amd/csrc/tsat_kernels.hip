@@ -22,6 +22,13 @@ __global__ __launch_bounds__(64) void tsat_solve_kernel(KArgs<real> a) {
   solve_trajectory<real, INTEG, DIAGJ, ES>(a, traj);
 }
 
+template <typename real, int DIAGJ>
+__global__ __launch_bounds__(64) void tsat_tvlqr_kernel(TvArgs<real> a) {
+  const int traj = blockIdx.x;
+  if (traj >= a.T) return;
+  tvlqr_trajectory<real, DIAGJ>(a, traj);
+}
+
 template <typename real>
 __global__ __launch_bounds__(256) void tsat_export_kernel(int64_t n_rec, int N, const int* nk, const real* XU,
                                                           const real* KD, double* X, double* U, double* K) {
@@ -317,6 +324,73 @@ int tsat_solve_batch(tsat_handle* h, const tsat_options* o, int64_t T, int64_t n
   rc = tsat_batch_run(h, o, nullptr);
   if (rc) return rc;
   return tsat_batch_download(h, X, U, K, stats);
+}
+
+void tsat_tvlqr_default_options(tsat_tvlqr_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->linearize_dt_sq = 1;   // `dt = S[end]^2`, src/attitude_controller.jl:137
+  o->min_steps = 10; o->u_scale = 1e-2; o->w_tol = 0.05; o->angle_tol = 0.08727;   // src/monte_carlo.jl:70-71,251
+}
+
+int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, const double* X,
+                     const double* U, const double* xf, const double* Btab, const int32_t* btab_idx,
+                     const double* tau0, const double* dtau, const double* dt, const double* Jmat, const double* Qd,
+                     const double* Qfd, const double* Rd, const double* x0_sim, const double* noise, double* X_sim,
+                     double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats) {
+  if (!h || !o) return -1;
+  const std::string why = check_tv_options(*o);
+  if (!why.empty()) return fail(h, -1, why);
+  if (T < 1 || n_btab < 1) return fail(h, -1, "bad batch dimensions");
+  if (!X || !U || !xf || !Btab || !tau0 || !dtau || !dt || !Jmat || !Qd || !Qfd || !Rd || !x0_sim || !X_sim || !U_sim || !stats)
+    return fail(h, -1, "null array");
+  if (!btab_idx && n_btab != T) return fail(h, -1, "btab_idx is NULL but n_btab != T");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  const int N = o->n_knots, n_tab = o->n_tab;
+  const size_t Tn = (size_t)T;
+  std::vector<int> bi(Tn);
+  for (int64_t t = 0; t < T; ++t) {
+    const int64_t v = btab_idx ? btab_idx[t] : t;
+    if (v < 0 || v >= n_btab) return fail(h, -1, "btab_idx out of range");
+    if (!(dt[t] > 0.0)) return fail(h, -1, "dt must be positive");
+    bi[(size_t)t] = (int)v;
+  }
+  std::vector<double> P(Tn * PSTRIDE), BT((size_t)n_btab * n_tab * 4), XUR(Tn * N * XUW);
+  pack_tv_params<double>(T, x0_sim, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, P.data());
+  pack_btab<double>(n_btab, n_tab, Btab, BT.data());
+  pack_xu_records<double>(T, N, X, U, XUR.data());
+  double *dP = nullptr, *dBT = nullptr, *dXUR = nullptr, *dNZ = nullptr, *dKD = nullptr, *dXS = nullptr;
+  int* dbi = nullptr;
+  tsat_tvlqr_stats* dst = nullptr;
+  const size_t nNZ = Tn * (size_t)(N - 1) * 36, nKD = Tn * (size_t)(N - 1) * KDW, nXS = Tn * N * XUW;
+  int rc = 0;
+  auto A = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 16) != hipSuccess) rc = -10; };
+  A((void**)&dP, P.size() * 8); A((void**)&dBT, BT.size() * 8); A((void**)&dXUR, XUR.size() * 8);
+  if (noise) A((void**)&dNZ, nNZ * 8);
+  A((void**)&dKD, nKD * 8); A((void**)&dXS, nXS * 8); A((void**)&dbi, Tn * sizeof(int)); A((void**)&dst, Tn * sizeof(tsat_tvlqr_stats));
+  auto C = [&](void* d, const void* s, size_t bytes) { if (!rc && hipMemcpy(d, s, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -10; };
+  C(dP, P.data(), P.size() * 8); C(dBT, BT.data(), BT.size() * 8); C(dXUR, XUR.data(), XUR.size() * 8);
+  if (noise) C(dNZ, noise, nNZ * 8);
+  C(dbi, bi.data(), Tn * sizeof(int));
+  if (!rc) {
+    TvArgs<double> a;
+    a.T = (int)T; a.N = N; a.n_tab = n_tab; a.lin_sq = o->linearize_dt_sq; a.min_steps = o->min_steps;
+    a.us = o->u_scale; a.w_tol = o->w_tol; a.ang_tol = o->angle_tol;
+    a.P = dP; a.BT = dBT; a.bidx = dbi; a.XUR = dXUR; a.NZ = dNZ; a.KD = dKD; a.XS = dXS; a.stats = dst;
+    const int cls = inertia_class(T, Jmat);
+    auto kern = cls == 2 ? tsat_tvlqr_kernel<double, 2> : (cls == 1 ? tsat_tvlqr_kernel<double, 1> : tsat_tvlqr_kernel<double, 0>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)T), dim3(64), 0, h->stream, a);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) rc = -10;
+  }
+  std::vector<double> XS(nXS), KD(nKD);
+  if (!rc && hipMemcpy(XS.data(), dXS, nXS * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && hipMemcpy(KD.data(), dKD, nKD * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && hipMemcpy(stats, dst, Tn * sizeof(tsat_tvlqr_stats), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc) unpack_tv<double>(T, N, XS.data(), KD.data(), X_sim, U_sim, K_lqr);
+  void* fr[] = {dP, dBT, dXUR, dNZ, dKD, dXS, dbi, dst};
+  for (void* q : fr)
+    if (q) (void)hipFree(q);
+  if (rc) h->err = "device allocation, copy or launch failed in tsat_tvlqr_batch";
+  return rc;
 }
 
 }  // extern "C"

@@ -1,0 +1,69 @@
+"""Closed-loop tracking of solved slews on the GPU — the caller right after ``solve!`` in the reference.
+
+``attitude_simulation(f!, f_gains!, integration, X, U, dt, x0_lqr, t0, tf, Q_lqr, R_lqr, Qf_lqr)``
+(src/attitude_controller.jl:1-48) computes TVLQR gains around the optimised trajectory (``attitude_lqr``, :50-119),
+simulates the noisy plant (src/simulator.jl) under ``U_sim = U - K dX`` and returns ``X_sim, U_sim, dX, K``;
+src/monte_carlo.jl:242-262 then turns ``X_sim`` into a slew time / failure flag. Here the same call runs for a whole
+batch through ``tsat_tvlqr_batch``; randomness is an explicit input so that runs are reproducible and checkable.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from .slew_setup import SlewBatch, qmult
+
+
+def tvlqr_weights(T, alpha=10.0, beta=10.0, r=7.5e3):
+    """Q_lqr = diag(alpha 1_3, beta 1_3), Qf_lqr = 100 Q_lqr, R_lqr = r I (src/TortoiseSat.jl:251-260; the
+    Monte-Carlo uses r = 0.5e3, src/monte_carlo.jl:228)."""
+    Qd = np.tile(np.r_[np.full(3, alpha), np.full(3, beta)], (T, 1))
+    return Qd, 100.0 * Qd, np.full((T, 3), float(r))
+
+
+def perturbed_initial_state(x0, rng, sigma=(np.pi / 180.0) ** 2):
+    """x0_lqr of src/TortoiseSat.jl:227-234: rates kept, attitude rotated by a random small rotation vector."""
+    x0 = np.asarray(x0, dtype=np.float64)
+    out = x0.copy()
+    for t in range(x0.shape[0]):
+        nq = rng.standard_normal(3) * sigma
+        th = np.linalg.norm(nq)
+        out[t, 3:7] = qmult(x0[t, 3:7], np.r_[np.cos(th / 2.0), nq / th * np.sin(th / 2.0)])
+    return out
+
+
+def simulator_noise(T, N, rng):
+    """The draws ``simulator`` makes per dynamics evaluation (src/simulator.jl:5,10,22), laid out (T, N-1, 4, 9):
+    gyro noise randn(3)(0.38 deg)^2, attitude-noise rotation vector randn(3)(1 deg)^2, field noise rand(3) 1e-10."""
+    g = rng.standard_normal((T, N - 1, 4, 3)) * (0.38 * np.pi / 180.0) ** 2
+    a = rng.standard_normal((T, N - 1, 4, 3)) * (1.0 * np.pi / 180.0) ** 2
+    b = rng.random((T, N - 1, 4, 3)) * (1.0e-5) ** 2
+    return np.ascontiguousarray(np.concatenate([g, a, b], axis=3))
+
+
+def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noise=None, linearize_dt_sq=True,
+                        u_scale=1e-2, min_steps=10, w_tol=0.05, angle_tol=0.08727):
+    """Batched ``attitude_simulation`` + slew-time statistic. ``solver`` is an AugmentedLagrangianSolver (owns the GPU
+    handle); X (T,N,7), U (T,N-1,3) are the solved trajectories. Returns dict(X_sim, U_sim, K (T,N-1,6,3), stats)."""
+    lib = _abi.load()
+    T, N = batch.T, batch.N
+    o = _abi.TvlqrOptions()
+    lib.tsat_tvlqr_default_options(C.byref(o))
+    o.n_knots, o.n_tab, o.linearize_dt_sq, o.min_steps = N, batch.n_tab, int(bool(linearize_dt_sq)), int(min_steps)
+    o.u_scale, o.w_tol, o.angle_tol = float(u_scale), float(w_tol), float(angle_tol)
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    X, U, x0_sim, Qd, Qfd, Rd = c(X), c(U), c(x0_sim), c(Qd), c(Qfd), c(Rd)
+    if X.shape != (T, N, 7) or U.shape != (T, N - 1, 3) or Qd.shape != (T, 6) or Qfd.shape != (T, 6) or Rd.shape != (T, 3):
+        raise ValueError("array shapes do not match the batch")
+    if noise is not None:
+        noise = c(noise)
+        if noise.shape != (T, N - 1, 4, 9):
+            raise ValueError("noise must be (T, N-1, 4, 9)")
+    Xs = np.empty((T, N, 7)); Us = np.empty((T, N - 1, 3)); K = np.empty((T, N - 1, 6, 3))
+    st = np.zeros(T, dtype=_abi.TVLQR_STATS_DTYPE)
+    d = _abi.as_dp
+    rc = lib.tsat_tvlqr_batch(solver._h, C.byref(o), T, batch.Btab.shape[0], d(X), d(U), d(batch.xf), d(batch.Btab),
+                              _abi.as_ip(batch.btab_idx), d(batch.tau0), d(batch.dtau), d(batch.dt), d(batch.Jmat),
+                              d(Qd), d(Qfd), d(Rd), d(x0_sim), d(noise), d(Xs), d(Us), d(K), st.ctypes.data_as(C.c_void_p))
+    solver._check(rc, "tsat_tvlqr_batch")
+    return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)
