@@ -209,6 +209,18 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
                       const double* x0_sim, const double* noise,
                       double* X_sim, double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Horizon selection (the caller right before the solve): cumulative magnetic Gramian of a field table and the first
+ * row at which its condition number drops below `cutoff`.
+ *   magnetic_gramian(B_N, dt)          src/magnetic_toolbox.jl:1-12   G_1 = hat(B_1)hat(B_1)', G_i = G_{i-1} + hat(B_i)hat(B_i)' dt
+ *   condition_based_time(B_gram, cut)  src/magnetic_toolbox.jl:14-31  first 1-based i with cond(G_i) < cut, 0 if none
+ * Call sites src/TortoiseSat.jl:73-82, src/monte_carlo.jl:137-140 (t_final = index * (tf - t0) / N).
+ *   Btab 3 x n_rows x T (one coarse table per trajectory), dt_row T, cutoff T
+ *   tf_index T out (1-based, 0 = never), cond_at T out (condition number at that row; may be NULL)
+ * ------------------------------------------------------------------------------------------------------------ */
+int  tsat_horizon_batch(tsat_handle* h, int64_t T, int32_t n_rows, const double* Btab, const double* dt_row,
+                        const double* cutoff, int32_t* tf_index, double* cond_at);
+
 #ifdef __cplusplus
 }
 #endif

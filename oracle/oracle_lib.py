@@ -182,5 +182,22 @@ def tvlqr_batch(batch, X, U, Qd, Qfd, Rd, x0_sim, noise=None, opts=None, nthread
     return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)
 
 
+def horizon_batch(Btab, dt_row, cutoff, want_all=False):
+    """Oracle magnetic_gramian + condition_based_time. Btab (T, n_rows, 3). Returns (tf_index, cond_at[, cond_all])."""
+    lib = load()
+    Btab = np.ascontiguousarray(Btab, dtype=np.float64)
+    T, n = Btab.shape[0], Btab.shape[1]
+    dt_row = np.ascontiguousarray(np.broadcast_to(dt_row, (T,)), dtype=np.float64)
+    cutoff = np.ascontiguousarray(np.broadcast_to(cutoff, (T,)), dtype=np.float64)
+    idx = np.zeros(T, dtype=np.int32); cat = np.zeros(T)
+    call = np.zeros((T, n)) if want_all else None
+    d = lambda a: a.ctypes.data_as(_dp)
+    rc = lib.orc_horizon_batch(C.c_int64(T), C.c_int32(n), d(Btab), d(dt_row), d(cutoff), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                               d(cat), d(call) if want_all else None)
+    if rc != 0:
+        raise RuntimeError("orc_horizon_batch failed")
+    return (idx, cat, call) if want_all else (idx, cat)
+
+
 def num_procs():
     return load().orc_num_procs()

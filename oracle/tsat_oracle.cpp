@@ -935,6 +935,53 @@ int orc_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, cons
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Horizon selection: src/magnetic_toolbox.jl:1-31 restated. cond() of the symmetric PSD 3x3 Gramian by
+// cyclic Jacobi rotations (2-norm condition number = lambda_max / lambda_min).
+// ------------------------------------------------------------------------------------------------------------
+static double cond_sym3(const double G[6]) {  // G = [g00 g01 g02 g11 g12 g22]
+  double a[3][3] = {{G[0], G[1], G[2]}, {G[1], G[3], G[4]}, {G[2], G[4], G[5]}};
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    if (off == 0.0) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (a[p][q] == 0.0) continue;
+        double th = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+        double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 3; ++k) { double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - sn * akq; a[k][q] = sn * akp + c * akq; }
+        for (int k = 0; k < 3; ++k) { double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - sn * aqk; a[q][k] = sn * apk + c * aqk; }
+      }
+  }
+  double l0 = std::fabs(a[0][0]), l1 = std::fabs(a[1][1]), l2 = std::fabs(a[2][2]);
+  double mx = std::max(l0, std::max(l1, l2)), mn = std::min(l0, std::min(l1, l2));
+  return mn > 0.0 ? mx / mn : std::numeric_limits<double>::infinity();
+}
+
+int orc_horizon_batch(int64_t T, int32_t n_rows, const double* Btab, const double* dt_row, const double* cutoff,
+                      int32_t* tf_index, double* cond_at, double* cond_all /* T x n_rows or NULL */) {
+  if (T < 1 || n_rows < 1) return -1;
+  for (int64_t t = 0; t < T; ++t) {
+    const double* B = Btab + (size_t)t * n_rows * 3;
+    double G[6] = {0, 0, 0, 0, 0, 0};
+    tf_index[t] = 0;
+    if (cond_at) cond_at[t] = std::numeric_limits<double>::infinity();
+    for (int i = 0; i < n_rows; ++i) {
+      const double b0 = B[3 * i], b1 = B[3 * i + 1], b2 = B[3 * i + 2];
+      const double w = (i == 0) ? 1.0 : dt_row[t];          // the first slice is not scaled by dt (:6)
+      // hat(b) hat(b)' = |b|^2 I - b b'
+      const double n2 = b0 * b0 + b1 * b1 + b2 * b2;
+      G[0] += (n2 - b0 * b0) * w; G[1] += (-b0 * b1) * w; G[2] += (-b0 * b2) * w;
+      G[3] += (n2 - b1 * b1) * w; G[4] += (-b1 * b2) * w; G[5] += (n2 - b2 * b2) * w;
+      const double c = cond_sym3(G);
+      if (cond_all) cond_all[(size_t)t * n_rows + i] = c;
+      if (tf_index[t] == 0 && c < cutoff[t]) { tf_index[t] = i + 1; if (cond_at) cond_at[t] = c; if (!cond_all) break; }
+    }
+  }
+  return 0;
+}
+
 int orc_num_procs(void) {
 #ifdef _OPENMP
   return omp_get_num_procs();

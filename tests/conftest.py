@@ -80,6 +80,17 @@ class Emu:
         return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)
 
 
+    def horizon(self, Btab, dt_row, cutoff):
+        Btab = np.ascontiguousarray(Btab, dtype=np.float64)
+        T, n = Btab.shape[0], Btab.shape[1]
+        dt_row = np.ascontiguousarray(np.broadcast_to(dt_row, (T,)), dtype=np.float64)
+        cutoff = np.ascontiguousarray(np.broadcast_to(cutoff, (T,)), dtype=np.float64)
+        idx = np.zeros(T, dtype=np.int32); cond = np.zeros(T)
+        d = self.abi.as_dp
+        self.lib.emu_horizon_batch(C.c_int64(T), C.c_int32(n), d(Btab), d(dt_row), d(cutoff), self.abi.as_ip(idx), d(cond))
+        return idx, cond
+
+
 @pytest.fixture(scope="session")
 def emu(pkg):
     return Emu(pkg._abi)

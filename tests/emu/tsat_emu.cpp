@@ -113,3 +113,20 @@ extern "C" int emu_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n
   unpack_tv<double>(T, N, XS.data(), KD.data(), X_sim, U_sim, K_lqr);
   return 0;
 }
+
+extern "C" int emu_horizon_batch(int64_t T, int32_t n_rows, const double* Btab, const double* dt_row, const double* cutoff,
+                                 int32_t* tf_index, double* cond_at) {
+  HzArgs<double> a;
+  a.T = (int)T; a.n_rows = n_rows; a.BT = Btab; a.dt_row = dt_row; a.cutoff = cutoff; a.tf_index = tf_index; a.cond_at = cond_at;
+  for (int t = 0; t < (int)T; ++t) {
+    std::vector<double> lds(LDS_REALS, 0.0);
+    std::barrier<> bar(WAVE);
+    tsat_emu::g_bar = &bar;
+    tsat_emu::g_lds = lds.data();
+    std::vector<std::thread> th;
+    for (int l = 0; l < WAVE; ++l)
+      th.emplace_back([&, l]() { tsat_emu::g_lane = l; horizon_trajectory<double>(a, t); });
+    for (auto& x : th) x.join();
+  }
+  return 0;
+}

@@ -1459,4 +1459,83 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
   }
 }
 
+// ==================================================================================================
+// Horizon selection: magnetic_gramian + condition_based_time (src/magnetic_toolbox.jl:1-31) for a
+// batch. One trajectory per wavefront, lanes = table rows: each 64-row block is an inclusive wave scan of the six
+// unique Gramian entries plus the carry of the previous blocks; every lane then has ITS prefix Gramian and evaluates
+// its condition number with the closed-form (trigonometric) eigenvalues of a symmetric 3x3.
+// ==================================================================================================
+template <typename real>
+struct HzArgs {
+  int T, n_rows;
+  const real* BT;       // [T][n_rows][3]
+  const real* dt_row;   // [T]
+  const real* cutoff;   // [T]
+  int* tf_index;        // [T]
+  real* cond_at;        // [T] or null
+};
+
+template <typename real>
+TSAT_DEV real cond_sym3(real a00, real a01, real a02, real a11, real a12, real a22) {
+  const real p1 = a01 * a01 + a02 * a02 + a12 * a12;
+  const real q = (a00 + a11 + a22) * (real)(1.0 / 3.0);
+  const real d0 = a00 - q, d1 = a11 - q, d2 = a22 - q;
+  const real p2 = d0 * d0 + d1 * d1 + d2 * d2 + 2 * p1;
+  if (!(p2 > 0)) return (q > 0) ? (real)1 : inf_<real>();     // multiple of the identity
+  const real p = sqrt_(p2 * (real)(1.0 / 6.0));
+  const real ip = (real)1 / p;
+  const real b00 = d0 * ip, b11 = d1 * ip, b22 = d2 * ip, b01 = a01 * ip, b02 = a02 * ip, b12 = a12 * ip;
+  real r = (real)0.5 * (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02));
+  r = r < -1 ? (real)-1 : (r > 1 ? (real)1 : r);
+  const real phi = acos_(r) * (real)(1.0 / 3.0);
+  const real lmax = q + 2 * p * cos_(phi);
+  const real lmin = q + 2 * p * cos_(phi + (real)2.0943951023931954923);   // + 2 pi / 3
+  return (lmin > 0) ? lmax / lmin : inf_<real>();
+}
+
+template <typename real>
+TSAT_DEV void horizon_trajectory(const HzArgs<real>& a, int traj) {
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE();
+  const int n = a.n_rows;
+  const real* B = a.BT + (size_t)traj * n * 3;
+  const real dt = a.dt_row[traj], cut = a.cutoff[traj];
+  real carry[6] = {0, 0, 0, 0, 0, 0};
+  int found = 0;
+  real cfound = inf_<real>();
+  for (int i0 = 0; i0 < n && !found; i0 += WAVE) {
+    const int i = i0 + lane;
+    real g[6] = {0, 0, 0, 0, 0, 0};
+    if (i < n) {
+      const real b0 = B[3 * i], b1 = B[3 * i + 1], b2 = B[3 * i + 2];
+      const real w = (i == 0) ? (real)1 : dt;                  // the first slice is not scaled by dt (:6)
+      const real n2 = b0 * b0 + b1 * b1 + b2 * b2;
+      g[0] = (n2 - b0 * b0) * w; g[1] = (-b0 * b1) * w; g[2] = (-b0 * b2) * w;
+      g[3] = (n2 - b1 * b1) * w; g[4] = (-b1 * b2) * w; g[5] = (n2 - b2 * b2) * w;
+    }
+    // inclusive scan over the lanes (Hillis-Steele through LDS), six entries
+    for (int c = 0; c < 6; ++c) {
+      real v = g[c];
+      for (int s = 1; s < WAVE; s <<= 1) {
+        lds[L_RED + lane] = v;
+        TSAT_SYNC_LDS();
+        if (lane >= s) v += lds[L_RED + lane - s];
+        TSAT_SYNC_LDS();
+      }
+      g[c] = v + carry[c];
+    }
+    const real cnd = (i < n) ? cond_sym3(g[0], g[1], g[2], g[3], g[4], g[5]) : inf_<real>();
+    const int first = wave_first<real>(cnd < cut, lds + L_RED);
+    if (first < WAVE) {
+      found = i0 + first + 1;
+      cfound = wave_bcast(cnd, first, lds + L_RED);
+    }
+    for (int c = 0; c < 6; ++c) carry[c] = wave_bcast(g[c], WAVE - 1, lds + L_RED);
+  }
+  if (lane == 0) {
+    a.tf_index[traj] = found;
+    if (a.cond_at) a.cond_at[traj] = cfound;
+  }
+}
+
 }  // namespace tsat

@@ -30,6 +30,13 @@ __global__ __launch_bounds__(64) void tsat_tvlqr_kernel(TvArgs<real> a) {
 }
 
 template <typename real>
+__global__ __launch_bounds__(64) void tsat_horizon_kernel(HzArgs<real> a) {
+  const int traj = blockIdx.x;
+  if (traj >= a.T) return;
+  horizon_trajectory<real>(a, traj);
+}
+
+template <typename real>
 __global__ __launch_bounds__(256) void tsat_export_kernel(int64_t n_rec, int N, const int* nk, const real* XU,
                                                           const real* KD, double* X, double* U, double* K) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -390,6 +397,35 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
   for (void* q : fr)
     if (q) (void)hipFree(q);
   if (rc) h->err = "device allocation, copy or launch failed in tsat_tvlqr_batch";
+  return rc;
+}
+
+int tsat_horizon_batch(tsat_handle* h, int64_t T, int32_t n_rows, const double* Btab, const double* dt_row,
+                       const double* cutoff, int32_t* tf_index, double* cond_at) {
+  if (!h) return -1;
+  if (T < 1 || n_rows < 1) return fail(h, -1, "bad dimensions");
+  if (!Btab || !dt_row || !cutoff || !tf_index) return fail(h, -1, "null array");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  const size_t Tn = (size_t)T, nB = Tn * (size_t)n_rows * 3;
+  double *dB = nullptr, *ddt = nullptr, *dcut = nullptr, *dc = nullptr;
+  int* di = nullptr;
+  int rc = 0;
+  auto A = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 16) != hipSuccess) rc = -10; };
+  A((void**)&dB, nB * 8); A((void**)&ddt, Tn * 8); A((void**)&dcut, Tn * 8); A((void**)&dc, Tn * 8); A((void**)&di, Tn * sizeof(int));
+  auto Cp = [&](void* d, const void* s, size_t bytes) { if (!rc && hipMemcpy(d, s, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -10; };
+  Cp(dB, Btab, nB * 8); Cp(ddt, dt_row, Tn * 8); Cp(dcut, cutoff, Tn * 8);
+  if (!rc) {
+    HzArgs<double> a;
+    a.T = (int)T; a.n_rows = n_rows; a.BT = dB; a.dt_row = ddt; a.cutoff = dcut; a.tf_index = di; a.cond_at = dc;
+    hipLaunchKernelGGL(tsat_horizon_kernel<double>, dim3((unsigned)T), dim3(64), 0, h->stream, a);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) rc = -10;
+  }
+  if (!rc && hipMemcpy(tf_index, di, Tn * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && cond_at && hipMemcpy(cond_at, dc, Tn * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  void* fr[] = {dB, ddt, dcut, dc, di};
+  for (void* q : fr)
+    if (q) (void)hipFree(q);
+  if (rc) h->err = "device allocation, copy or launch failed in tsat_horizon_batch";
   return rc;
 }
 
