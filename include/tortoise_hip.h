@@ -221,6 +221,33 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
 int  tsat_horizon_batch(tsat_handle* h, int64_t T, int32_t n_rows, const double* Btab, const double* dt_row,
                         const double* cutoff, int32_t* tf_index, double* cond_at);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Field-table generation (the first step of the reference's per-run setup): orbit from Keplerian elements, fixed-step
+ * Euler propagation, GMST rotation, geocentric latitude/longitude, IGRF-12 (degree 13, epoch 2015 + secular variation),
+ * NED -> ENU -> ECEF -> ECI.
+ *   magnetic_simulation(p, t0, tf, N, mag_field)   src/magnetic_toolbox.jl:33-106   (2N rows, the last one left zero)
+ *   kep_ECI(kep, t0, GM)                           src/kep_ECI.jl:1-35
+ *   OrbitPlotter(x, p, t)                          src/OrbitPlotter.jl:1-52
+ *   igrf12(date, r, lat, lon) (geocentric)         src/igrf.jl:70-274, src/legendre.jl:254-292, src/dlegendre.jl:221-309
+ * Reference quirks are reproduced: the fixed IGRF radius (alt + R_E), the GMST expression as written, the J2 term as
+ * written, element 6 used as mean anomaly.
+ *   kep 6 x T   [e, a (km), i, RAAN, argp, anomaly] in degrees     t0, tf T   seconds
+ *   Btab 3 x 2N x T out [Tesla, ECI] — directly usable as the `Btab` of tsat_solve_batch with n_tab = 2N
+ *   pos  3 x (2N+1) x T out [km, ECI] (may be NULL)
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct tsat_btable_options {
+  int32_t n_half;       /* N of magnetic_simulation: step (tf - t0)/N, 2N table rows                              */
+  int32_t reserved;
+  double  mjd;          /* p.MJD  (58155.0, src/TortoiseSat.jl:44)                                                */
+  double  gm;           /* p.GM   km^3/s^2 (3.986004418e5, src/input_parameters.jl:26)                            */
+  double  r_igrf_km;    /* alt + R_E = 400 + 6371 (src/magnetic_toolbox.jl:44,81)                                 */
+  double  date;         /* decimal year handed to igrf12 (2019); 2015 <= date < 2020 is supported                 */
+} tsat_btable_options;
+
+void tsat_btable_default_options(tsat_btable_options* o);
+int  tsat_btable_batch(tsat_handle* h, const tsat_btable_options* o, int64_t T, const double* kep, const double* t0,
+                       const double* tf, double* Btab, double* pos);
+
 #ifdef __cplusplus
 }
 #endif

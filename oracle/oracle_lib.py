@@ -182,6 +182,35 @@ def tvlqr_batch(batch, X, U, Qd, Qfd, Rd, x0_sim, noise=None, opts=None, nthread
     return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)
 
 
+class BtableOptions(C.Structure):
+    _fields_ = [("n_half", C.c_int32), ("reserved", C.c_int32), ("mjd", C.c_double), ("gm", C.c_double),
+                ("r_igrf_km", C.c_double), ("date", C.c_double)]
+
+
+def igrf12(date, r_m, lat, lon):
+    return _call_vec("orc_igrf12", 3, float(date), float(r_m), float(lat), float(lon))
+
+
+def kep_eci(kep, t0, GM):
+    return _call_vec("orc_kep_eci", (3, 3), np.asarray(kep, dtype=np.float64), float(t0), float(GM))
+
+
+def btable_batch(kep, t0, tf, n_half, mjd=58155.0, gm=3.986004418e5, r_igrf_km=6771.0, date=2019.0, want_pos=True):
+    """Oracle magnetic_simulation for T orbits. Returns (Btab (T, 2N, 3), pos (T, 2N+1, 3))."""
+    lib = load()
+    kep = np.ascontiguousarray(kep, dtype=np.float64)
+    T = kep.shape[0]
+    t0 = np.ascontiguousarray(np.broadcast_to(t0, (T,)), dtype=np.float64)
+    tf = np.ascontiguousarray(np.broadcast_to(tf, (T,)), dtype=np.float64)
+    o = BtableOptions(int(n_half), 0, mjd, gm, r_igrf_km, date)
+    B = np.zeros((T, 2 * n_half, 3)); pos = np.zeros((T, 2 * n_half + 1, 3))
+    d = lambda a: a.ctypes.data_as(_dp)
+    rc = lib.orc_btable_batch(C.byref(o), C.c_int64(T), d(kep), d(t0), d(tf), d(B), d(pos) if want_pos else None)
+    if rc != 0:
+        raise RuntimeError("orc_btable_batch failed")
+    return B, pos
+
+
 def horizon_batch(Btab, dt_row, cutoff, want_all=False):
     """Oracle magnetic_gramian + condition_based_time. Btab (T, n_rows, 3). Returns (tf_index, cond_at[, cond_all])."""
     lib = load()

@@ -37,6 +37,7 @@
 #include <omp.h>
 #endif
 #include "../include/tortoise_hip.h"
+#include "../include/igrf12_2015_coeffs.h"   // IGRF-12 model constants (data)
 
 namespace {
 
@@ -977,6 +978,172 @@ int orc_horizon_batch(int64_t T, int32_t n_rows, const double* Btab, const doubl
       const double c = cond_sym3(G);
       if (cond_all) cond_all[(size_t)t * n_rows + i] = c;
       if (tf_index[t] == 0 && c < cutoff[t]) { tf_index[t] = i + 1; if (cond_at) cond_at[t] = c; if (!cond_all) break; }
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Field-table generation: src/magnetic_toolbox.jl:33-106 with src/kep_ECI.jl, src/OrbitPlotter.jl,
+// src/igrf.jl:70-274, src/legendre.jl:254-292, src/dlegendre.jl:221-309 restated.
+// ------------------------------------------------------------------------------------------------------------
+void orc_btable_default_options(tsat_btable_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->n_half = 5000; o->mjd = 58155.0; o->gm = 3.986004418e14 * 1e-9; o->r_igrf_km = 400.0 + 6371.0; o->date = 2019.0;
+}
+
+// igrf12(date, r [m], lat, lon) geocentric, 2015 <= date < 2020: returns [x; y; z] in nT (src/igrf.jl:70-274)
+void orc_igrf12(double date, double r, double lam, double Om, double* out) {
+  const int NM = IGRF12_NMAX;
+  const double theta = M_PI / 2 - lam;
+  const double phi = (Om >= 0) ? Om : 2 * M_PI + Om;
+  r /= 1000;
+  const double dt = date - 2015.0;
+  double P[NM + 1][NM + 3], dP[NM + 1][NM + 3];
+  for (int i = 0; i <= NM; ++i) for (int j = 0; j < NM + 3; ++j) { P[i][j] = 0; dP[i][j] = 0; }
+  {  // legendre_schmidt_quasi_normalized!, ph_term = false (src/legendre.jl:254-292)
+    const double c = std::cos(theta), s = std::sqrt(1 - c * c);
+    P[0][0] = 1; P[1][0] = c; P[1][1] = s;
+    for (int n = 2; n <= NM; ++n) {
+      for (int m = 0; m < n; ++m) {
+        const double aux = (double)((n - m) * (n + m));
+        const double a_nm = std::sqrt(((2.0 * n - 1) * (2.0 * n - 1)) / aux);
+        const double b_nm = std::sqrt(((double)(n + m - 1) * (n - m - 1)) / aux);
+        P[n][m] = a_nm * c * P[n - 1][m] - b_nm * P[n - 2][m];
+      }
+      P[n][n] = s * std::sqrt((2.0 * n - 1) / (2.0 * n)) * P[n - 1][n - 1];
+    }
+  }
+  {  // dlegendre_fully_normalized! (src/dlegendre.jl:221-309), ph_term = false
+    const double fact = (std::fmod(theta, 2 * M_PI) > M_PI) ? -1.0 : 1.0;
+    for (int n = 1; n <= NM; ++n)
+      for (int m = 0; m <= n; ++m) {
+        double v;
+        if (m == 0) {
+          const double aux = std::sqrt(n * (n + 1) / 2.0);
+          v = -(0.5 * aux) * P[n][1] + (-0.5 * aux) * P[n][1];
+        } else if (m == 1) {
+          v = 0.5 * std::sqrt(2.0 * n * (n + 1)) * P[n][0] - 0.5 * std::sqrt((double)(n + 2) * (n - 1)) * P[n][2];
+        } else if (n != m) {
+          v = 0.5 * std::sqrt((double)(n + m) * (n - m + 1)) * P[n][m - 1] - 0.5 * std::sqrt((double)(n + m + 1) * (n - m)) * P[n][m + 1];
+        } else {
+          v = 0.5 * std::sqrt((double)(n + m) * (n - m + 1)) * P[n][m - 1];
+        }
+        dP[n][m] = v * fact;
+      }
+  }
+  const double a = 6371.2;
+  const double sin_p = std::sin(phi), cos_p = std::cos(phi);
+  const double ratio = a / r;
+  double fact = ratio, dVr = 0, dVt = 0, dVp = 0;
+  int kg = 0, kh = 0;
+  for (int n = 1; n <= NM; ++n) {
+    double ar = 0, at = 0, ap = 0;
+    double Gnm = IGRF12_G2015[kg] + IGRF12_GSV[kg] * dt;
+    ++kg;
+    ar += -(n + 1) / r * Gnm * P[n][0];
+    at += Gnm * dP[n][0];
+    double sin_m1 = 0.0, sin_m2 = -sin_p, cos_m1 = 1.0, cos_m2 = cos_p;
+    for (int m = 1; m <= n; ++m) {
+      const double sin_m = 2 * cos_p * sin_m1 - sin_m2;
+      const double cos_m = 2 * cos_p * cos_m1 - cos_m2;
+      Gnm = IGRF12_G2015[kg] + IGRF12_GSV[kg] * dt;
+      const double Hnm = IGRF12_H2015[kh] + IGRF12_HSV[kh] * dt;
+      ++kg; ++kh;
+      const double GcHs = Gnm * cos_m + Hnm * sin_m, GsHc = Gnm * sin_m - Hnm * cos_m;
+      ar += -(n + 1) / r * GcHs * P[n][m];
+      at += GcHs * dP[n][m];
+      ap += (theta == 0) ? -m * GsHc * dP[n][m] : -m * GsHc * P[n][m];
+      sin_m2 = sin_m1; sin_m1 = sin_m; cos_m2 = cos_m1; cos_m1 = cos_m;
+    }
+    fact *= ratio;
+    dVr += ar * fact; dVp += ap * fact; dVt += at * fact;
+  }
+  dVr *= a; dVp *= a; dVt *= a;
+  out[0] = 1 / r * dVt;
+  out[1] = (theta == 0) ? -1 / r * dVp : -1 / (r * std::sin(theta)) * dVp;
+  out[2] = dVr;
+}
+
+static void rz_deg(double ang, double M[9]) {   // R_z of src/kep_ECI.jl:37-42 (row-major)
+  const double c = std::cos(ang * M_PI / 180), s = std::sin(ang * M_PI / 180);
+  double R[9] = {c, s, 0, -s, c, 0, 0, 0, 1};
+  std::memcpy(M, R, sizeof(R));
+}
+static void rx_deg(double ang, double M[9]) {   // R_x of src/kep_ECI.jl:44-49
+  const double c = std::cos(ang * M_PI / 180), s = std::sin(ang * M_PI / 180);
+  double R[9] = {1, 0, 0, 0, c, s, 0, -s, c};
+  std::memcpy(M, R, sizeof(R));
+}
+static void mm3(const double* A, const double* B, double* C) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double a = 0; for (int k = 0; k < 3; ++k) a += A[3 * i + k] * B[3 * k + j]; C[3 * i + j] = a; }
+}
+// kep_ECI (src/kep_ECI.jl:1-35)
+void orc_kep_eci(const double* kep, double t0, double GM, double* r, double* v) {
+  double A[6];
+  for (int i = 0; i < 6; ++i) A[i] = kep[i];
+  A[5] = std::fmod(kep[5] + t0 * std::sqrt(GM / (kep[1] * kep[1] * kep[1])), 360.0);
+  double E = A[5] / 180 * M_PI;
+  for (int i = 0; i < 100; ++i) E = E - (E - A[0] * std::sin(E) - A[5] / 180 * M_PI) / (1 - A[0] * std::cos(E));
+  const double nu = 2 * std::atan2(std::sqrt(1 + A[0]) * std::sin(E / 2), std::sqrt(1 - A[0]) * std::cos(E / 2)) * 180 / M_PI;
+  const double r_c = A[1] * (1 - A[0] * std::cos(E));
+  const double o[3] = {r_c * std::cos(nu * M_PI / 180), r_c * std::sin(nu * M_PI / 180), 0};
+  const double k = std::sqrt(GM * A[1]) / r_c;
+  const double od[3] = {k * -std::sin(E), k * std::sqrt(1 - A[0] * A[0]) * std::cos(E), 0};
+  double Ra[9], Rb[9], Rc[9], T1[9], M[9];
+  rz_deg(-A[3], Ra); rx_deg(-A[2], Rb); rz_deg(-A[4], Rc);
+  mm3(Ra, Rb, T1); mm3(T1, Rc, M);
+  for (int i = 0; i < 3; ++i) {
+    r[i] = M[3 * i] * o[0] + M[3 * i + 1] * o[1] + M[3 * i + 2] * o[2];
+    v[i] = M[3 * i] * od[0] + M[3 * i + 1] * od[1] + M[3 * i + 2] * od[2];
+  }
+}
+// OrbitPlotter (src/OrbitPlotter.jl:1-48): two-body + the J2 term as written
+static void orbit_rhs(const double* x, double* xd) {
+  const double GM = 3.986004418E14 * (1.0 / 1000) * (1.0 / 1000) * (1.0 / 1000);
+  const double nr = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  const double J2 = 0.0010826359, nr7 = std::pow(nr, 7);
+  const double rho2 = x[0] * x[0] + x[1] * x[1];
+  const double fj[3] = {J2 * x[0] / nr7 * (6 * x[2] - 1.5 * rho2), J2 * x[1] / nr7 * (6 * x[2] - 1.5 * rho2), J2 * x[2] / nr7 * (3 * x[2] - 4.5 * rho2)};
+  for (int i = 0; i < 3; ++i) { xd[i] = x[3 + i]; xd[3 + i] = GM / (nr * nr) * -x[i] / nr + fj[i]; }
+}
+
+int orc_btable_batch(const tsat_btable_options* o, int64_t T, const double* kep, const double* t0, const double* tf,
+                     double* Btab, double* pos) {
+  if (!o || o->n_half < 1 || !(o->date >= 2015.0 && o->date < 2020.0)) return -1;
+  const int N = o->n_half;
+  for (int64_t t = 0; t < T; ++t) {
+    double u[6], ud[6];
+    orc_kep_eci(kep + 6 * t, t0[t], o->gm, u, u + 3);
+    const double dt = (tf[t] - t0[t]) / N;
+    std::vector<double> P((size_t)3 * (2 * N + 1));
+    for (int i = 0; i <= 2 * N; ++i) {          // Euler(), adaptive = false, tspan = (t0, 2 tf) (src/magnetic_toolbox.jl:51-54)
+      for (int c = 0; c < 3; ++c) P[3 * i + c] = u[c];
+      orbit_rhs(u, ud);
+      for (int c = 0; c < 6; ++c) u[c] += dt * ud[c];
+    }
+    if (pos) std::memcpy(pos + (size_t)t * 3 * (2 * N + 1), P.data(), sizeof(double) * P.size());
+    double* B = Btab + (size_t)t * 3 * 2 * N;
+    for (int i = 0; i < 2 * N; ++i) {
+      double* b = B + 3 * i;
+      b[0] = b[1] = b[2] = 0.0;
+      if (i == 2 * N - 1) break;                // the last row is left zero (:76)
+      const double ti = t0[t] + dt * i;
+      const double gmst = (280.4606 + 360.9856473 * (ti / 24 / 60 / 60 + o->mjd) - 51544.5) / 180 * M_PI;   // as written (:60)
+      const double cg = std::cos(gmst), sg = std::sin(gmst);
+      const double* p = P.data() + 3 * i;
+      const double pe[3] = {cg * p[0] + sg * p[1], -sg * p[0] + cg * p[1], p[2]};
+      const double lat = std::asin(pe[2] / std::sqrt(pe[0] * pe[0] + pe[1] * pe[1] + pe[2] * pe[2]));
+      const double lon = std::atan2(pe[1], pe[0]);
+      double bn[3];
+      orc_igrf12(o->date, o->r_igrf_km * 1000, lat, lon, bn);
+      for (int c = 0; c < 3; ++c) bn[c] /= 1.0e9;
+      const double e[3] = {bn[1], bn[0], -bn[2]};                       // NED_to_ENU (:74)
+      const double sl = std::sin(lon), cl = std::cos(lon), sa = std::sin(lat), ca = std::cos(lat);
+      const double xyz[3] = {-sl * e[0] - sa * cl * e[1] + ca * cl * e[2], cl * e[0] - sa * sl * e[1] + ca * sl * e[2], ca * e[1] + sa * e[2]};   // (:92-95)
+      b[0] = cg * xyz[0] - sg * xyz[1];                                 // Rz(GMST)' (:96)
+      b[1] = sg * xyz[0] + cg * xyz[1];
+      b[2] = xyz[2];
     }
   }
   return 0;

@@ -80,6 +80,17 @@ class Emu:
         return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)
 
 
+    def btable(self, kep, t0, tf, N, mjd=58155.0, gm=3.986004418e5, r_igrf_km=6771.0, date=2019.0):
+        kep = np.ascontiguousarray(kep, dtype=np.float64)
+        T = kep.shape[0]
+        t0 = np.ascontiguousarray(np.broadcast_to(t0, (T,)), dtype=np.float64)
+        tf = np.ascontiguousarray(np.broadcast_to(tf, (T,)), dtype=np.float64)
+        o = self.abi.BtableOptions(int(N), 0, mjd, gm, r_igrf_km, date)
+        B = np.zeros((T, 2 * N, 3)); pos = np.zeros((T, 2 * N + 1, 3))
+        d = self.abi.as_dp
+        self.lib.emu_btable_batch(C.byref(o), C.c_int64(T), d(kep), d(t0), d(tf), d(B), d(pos))
+        return B, pos
+
     def horizon(self, Btab, dt_row, cutoff):
         Btab = np.ascontiguousarray(Btab, dtype=np.float64)
         T, n = Btab.shape[0], Btab.shape[1]

@@ -7,9 +7,10 @@ Only the hot path lives here: ``csrc/`` holds the hand-written H
   slew_setup  problem setup the reference keeps in its scripts (weights, guesses, workloads)
   trajopt     mirror of the TrajectoryOptimization.jl surface used at src/TortoiseSat.jl:145-199
   sweep       Monte-Carlo sharding over GPUs + RCCL all-gather (src/monte_carlo.jl:118-235)
+  magnetic    orbit + IGRF-12 field tables (src/magnetic_toolbox.jl:33-106)
   horizon     Gramian-based horizon selection (src/magnetic_toolbox.jl:1-31)
   tracking    closed-loop TVLQR tracking + slew-time statistic (src/attitude_controller.jl:1-119)
 """
-from . import _abi, horizon, slew_setup, sweep, tracking, trajopt  # noqa: F401
+from . import _abi, horizon, magnetic, slew_setup, sweep, tracking, trajopt  # noqa: F401
 
-__all__ = ["_abi", "horizon", "slew_setup", "sweep", "tracking", "trajopt"]
+__all__ = ["_abi", "horizon", "magnetic", "slew_setup", "sweep", "tracking", "trajopt"]

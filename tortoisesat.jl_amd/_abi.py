@@ -59,6 +59,13 @@ class TvlqrOptions(C.Structure):
                 ("u_scale", C.c_double), ("w_tol", C.c_double), ("angle_tol", C.c_double)]
 
 
+class BtableOptions(C.Structure):
+    """``tsat_btable_options`` — field-table generation (src/magnetic_toolbox.jl:33-106)."""
+
+    _fields_ = [("n_half", C.c_int32), ("reserved", C.c_int32), ("mjd", C.c_double), ("gm", C.c_double),
+                ("r_igrf_km", C.c_double), ("date", C.c_double)]
+
+
 TVLQR_STATS_DTYPE = np.dtype([("slew_index", "<i4"), ("failed", "<i4"), ("slew_time", "<f8"), ("final_w_norm", "<f8"),
                               ("final_angle", "<f8")])
 assert TVLQR_STATS_DTYPE.itemsize == 32
@@ -85,6 +92,8 @@ PROTOTYPES = {
     "tsat_batch_bytes": (C.c_int64, [C.c_void_p]),
     "tsat_batch_trace": (C.c_int, [C.c_void_p, C.c_int32]),
     "tsat_batch_trace_download": (C.c_int, [C.c_void_p, _dp]),
+    "tsat_btable_default_options": (None, [C.POINTER(BtableOptions)]),
+    "tsat_btable_batch": (C.c_int, [C.c_void_p, C.POINTER(BtableOptions), C.c_int64, _dp, _dp, _dp, _dp, _dp]),
     "tsat_horizon_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, _ip, _dp]),
     "tsat_tvlqr_default_options": (None, [C.POINTER(TvlqrOptions)]),
     "tsat_tvlqr_batch": (C.c_int, [C.c_void_p, C.POINTER(TvlqrOptions), C.c_int64, C.c_int64, _dp, _dp, _dp, _dp, _ip,

@@ -175,6 +175,9 @@ TSAT_DEV double sqrt_(double a) { return std::sqrt(a); }
 TSAT_DEV double sin_(double a) { return std::sin(a); }
 TSAT_DEV double cos_(double a) { return std::cos(a); }
 TSAT_DEV double acos_(double a) { return std::acos(a); }
+TSAT_DEV double asin_(double a) { return std::asin(a); }
+TSAT_DEV double atan2_(double a, double b) { return std::atan2(a, b); }
+TSAT_DEV double fmod_(double a, double b) { return std::fmod(a, b); }
 #else
 // v_rsq_f64 seed (rel. error <= 5.3e-8, profiles/r01/rsq_rcp_accuracy.txt) + ONE third-order step:
 // y (1 + e/2 + 3e^2/8), e = 1 - s y^2  ->  error O(e^3) ~ 1e-22, i.e. rounding only; 5 instructions instead of the 8
@@ -204,6 +207,9 @@ TSAT_DEV double sqrt_(double a) { return __builtin_sqrt(a); }
 TSAT_DEV double sin_(double a) { return ::sin(a); }     // HIP device math (ocml); used by the tracking kernel only
 TSAT_DEV double cos_(double a) { return ::cos(a); }
 TSAT_DEV double acos_(double a) { return ::acos(a); }
+TSAT_DEV double asin_(double a) { return ::asin(a); }
+TSAT_DEV double atan2_(double a, double b) { return ::atan2(a, b); }
+TSAT_DEV double fmod_(double a, double b) { return ::fmod(a, b); }
 #endif
 
 // phase timing for the diagnostic build (-DTSAT_PROFILE): shader-clock stamps accumulated per phase and written to
@@ -1535,6 +1541,184 @@ TSAT_DEV void horizon_trajectory(const HzArgs<real>& a, int traj) {
   if (lane == 0) {
     a.tf_index[traj] = found;
     if (a.cond_at) a.cond_at[traj] = cfound;
+  }
+}
+
+// ==================================================================================================
+// Field-table generation: magnetic_simulation (src/magnetic_toolbox.jl:33-106) for a batch.
+// One orbit per wavefront: the Euler orbit is a short sequential loop (every lane runs it, lane 0 stores the
+// positions); then lanes = table rows, each evaluating the degree-13 IGRF-12 sum for its sample with the Legendre
+// recurrences fully unrolled (three rolling rows of P in registers, coefficients broadcast from LDS).
+// ==================================================================================================
+constexpr int IGRF_NMAX = 13, IGRF_NG = 104, IGRF_NH = 91;
+constexpr int L_IGRF = L_UNION;   // g(104) h(91), already advanced to the requested date
+
+template <typename real>
+struct BtArgs {
+  int T, n_half;
+  real mjd, gm, r_igrf_km, dty;     // dty = date - 2015
+  const real* coef;                 // [390] g2015, gsv, h2015, hsv
+  const real* kep;                  // [T][6]
+  const real* t0;                   // [T]
+  const real* tf;                   // [T]
+  real* pos;                        // [T][2N+1][3]
+  real* B;                          // [T][2N][3]
+};
+
+// igrf12(date, r, lat, lon) geocentric, nT (src/igrf.jl:70-274; Legendre: src/legendre.jl:254-292, src/dlegendre.jl:221-309)
+template <typename real>
+TSAT_DEV void igrf12_eval(const real* gh, real r_km, real lat, real lon, real out[3]) {
+  const real PI = (real)3.14159265358979323846;
+  const real theta = PI / 2 - lat;
+  const real phi = (lon >= 0) ? lon : 2 * PI + lon;
+  const real c = cos_(theta), s = sqrt_(1 - c * c);
+  const real a = (real)6371.2, r = r_km;
+  const real sin_p = sin_(phi), cos_p = cos_(phi);
+  const real ratio = a / r;
+  const real dfact = (fmod_(theta, 2 * PI) > PI) ? (real)-1 : (real)1;
+  real fact = ratio, dVr = 0, dVt = 0, dVp = 0;
+  real Pa[IGRF_NMAX + 3], Pb[IGRF_NMAX + 3], Pc[IGRF_NMAX + 3];   // rows n-2, n-1, n (zero beyond the diagonal)
+  for (int i = 0; i < IGRF_NMAX + 3; ++i) { Pa[i] = 0; Pb[i] = 0; Pc[i] = 0; }
+  Pb[0] = 1;   // P[0][0]
+  int kg = 0, kh = 0;
+#ifndef TSAT_EMU
+#pragma unroll
+#endif
+  for (int n = 1; n <= IGRF_NMAX; ++n) {
+    // row n of the Schmidt quasi-normalised functions
+    if (n == 1) {
+      Pc[0] = c; Pc[1] = s;
+    } else {
+#ifndef TSAT_EMU
+#pragma unroll
+#endif
+      for (int m = 0; m < n; ++m) {
+        const double aux = (double)((n - m) * (n + m));
+        const real a_nm = (real)sqrt_(((2.0 * n - 1) * (2.0 * n - 1)) / aux);
+        const real b_nm = (real)sqrt_(((double)(n + m - 1) * (n - m - 1)) / aux);
+        Pc[m] = a_nm * c * Pb[m] - b_nm * Pa[m];
+      }
+      Pc[n] = s * (real)sqrt_((2.0 * n - 1) / (2.0 * n)) * Pb[n - 1];
+    }
+    Pc[n + 1] = 0;
+    real ar = 0, at = 0, ap = 0;
+    {
+      const real Gnm = gh[kg];
+      ++kg;
+      const real aux = (real)sqrt_(n * (n + 1) / 2.0);
+      const real dP0 = (-((real)0.5 * aux) * Pc[1] + (-(real)0.5 * aux) * Pc[1]) * dfact;
+      ar += -(real)(n + 1) / r * Gnm * Pc[0];
+      at += Gnm * dP0;
+    }
+    real sin_m1 = 0, sin_m2 = -sin_p, cos_m1 = 1, cos_m2 = cos_p;
+#ifndef TSAT_EMU
+#pragma unroll
+#endif
+    for (int m = 1; m <= n; ++m) {
+      const real sin_m = 2 * cos_p * sin_m1 - sin_m2;
+      const real cos_m = 2 * cos_p * cos_m1 - cos_m2;
+      const real Gnm = gh[kg], Hnm = gh[IGRF_NG + kh];
+      ++kg; ++kh;
+      real dPm;
+      if (m == 1)
+        dPm = (real)(0.5 * sqrt_(2.0 * n * (n + 1))) * Pc[0] - (real)(0.5 * sqrt_((double)(n + 2) * (n - 1))) * Pc[2];
+      else if (n != m)
+        dPm = (real)(0.5 * sqrt_((double)(n + m) * (n - m + 1))) * Pc[m - 1] - (real)(0.5 * sqrt_((double)(n + m + 1) * (n - m))) * Pc[m + 1];
+      else
+        dPm = (real)(0.5 * sqrt_((double)(n + m) * (n - m + 1))) * Pc[m - 1];
+      dPm *= dfact;
+      const real GcHs = Gnm * cos_m + Hnm * sin_m, GsHc = Gnm * sin_m - Hnm * cos_m;
+      ar += -(real)(n + 1) / r * GcHs * Pc[m];
+      at += GcHs * dPm;
+      ap += (theta == 0) ? -(real)m * GsHc * dPm : -(real)m * GsHc * Pc[m];
+      sin_m2 = sin_m1; sin_m1 = sin_m; cos_m2 = cos_m1; cos_m1 = cos_m;
+    }
+    fact *= ratio;
+    dVr += ar * fact; dVp += ap * fact; dVt += at * fact;
+    for (int i = 0; i < IGRF_NMAX + 3; ++i) { Pa[i] = Pb[i]; Pb[i] = Pc[i]; }
+  }
+  dVr *= a; dVp *= a; dVt *= a;
+  out[0] = 1 / r * dVt;
+  out[1] = (theta == 0) ? -1 / r * dVp : -1 / (r * sin_(theta)) * dVp;
+  out[2] = dVr;
+}
+
+template <typename real>
+TSAT_DEV void btable_trajectory(const BtArgs<real>& a, int traj) {
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE();
+  const int N = a.n_half;
+  const real PI = (real)3.14159265358979323846, D2R = PI / 180;
+  // coefficients at the requested date: g = g2015 + sv (date - 2015)   (src/igrf.jl:172-177)
+  for (int i = lane; i < IGRF_NG + IGRF_NH; i += WAVE) {
+    const int src = (i < IGRF_NG) ? i : (2 * IGRF_NG + (i - IGRF_NG));
+    const int sv = (i < IGRF_NG) ? (IGRF_NG + i) : (2 * IGRF_NG + IGRF_NH + (i - IGRF_NG));
+    lds[L_IGRF + i] = a.coef[src] + a.coef[sv] * a.dty;
+  }
+  // ---- kep_ECI (src/kep_ECI.jl:1-35) ---------------------------------------------------------------
+  const real* kp = a.kep + (size_t)traj * 6;
+  const real t0 = a.t0[traj], tf = a.tf[traj];
+  const real e = kp[0], sma = kp[1];
+  const real Ma = fmod_(kp[5] + t0 * sqrt_(a.gm / (sma * sma * sma)), (real)360);
+  real E = Ma / 180 * PI;
+  for (int i = 0; i < 100; ++i) E = E - (E - e * sin_(E) - Ma / 180 * PI) / (1 - e * cos_(E));
+  const real nu = 2 * atan2_(sqrt_(1 + e) * sin_(E / 2), sqrt_(1 - e) * cos_(E / 2)) * 180 / PI;
+  const real r_c = sma * (1 - e * cos_(E));
+  const real o0 = r_c * cos_(nu * D2R), o1 = r_c * sin_(nu * D2R);
+  const real kk = sqrt_(a.gm * sma) / r_c;
+  const real od0 = kk * -sin_(E), od1 = kk * sqrt_(1 - e * e) * cos_(E);
+  real M[9];
+  {  // R_z(-RAAN) R_x(-i) R_z(-argp), degree rotations [c s 0; -s c 0; 0 0 1] / [1 0 0; 0 c s; 0 -s c]
+    const real ca = cos_(-kp[3] * D2R), sa = sin_(-kp[3] * D2R);
+    const real cb = cos_(-kp[2] * D2R), sb = sin_(-kp[2] * D2R);
+    const real cc = cos_(-kp[4] * D2R), sc = sin_(-kp[4] * D2R);
+    const real A[9] = {ca, sa, 0, -sa, ca, 0, 0, 0, 1}, Bm[9] = {1, 0, 0, 0, cb, sb, 0, -sb, cb}, Cm[9] = {cc, sc, 0, -sc, cc, 0, 0, 0, 1};
+    real T1[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { real v = 0; for (int k = 0; k < 3; ++k) v += A[3 * i + k] * Bm[3 * k + j]; T1[3 * i + j] = v; }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { real v = 0; for (int k = 0; k < 3; ++k) v += T1[3 * i + k] * Cm[3 * k + j]; M[3 * i + j] = v; }
+  }
+  real u[6];
+  for (int i = 0; i < 3; ++i) { u[i] = M[3 * i] * o0 + M[3 * i + 1] * o1; u[3 + i] = M[3 * i] * od0 + M[3 * i + 1] * od1; }
+  // ---- Euler orbit, 2N+1 samples (src/magnetic_toolbox.jl:51-54, src/OrbitPlotter.jl:1-48) ---------------
+  const real dt = (tf - t0) / (real)N;
+  real* Pg = a.pos + (size_t)traj * 3 * (2 * N + 1);
+  const real GMo = (real)(3.986004418E14 * 1e-9), J2 = (real)0.0010826359;
+  for (int i = 0; i <= 2 * N; ++i) {
+    if (lane == 0) { Pg[3 * i] = u[0]; Pg[3 * i + 1] = u[1]; Pg[3 * i + 2] = u[2]; }
+    const real nr = sqrt_(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    const real nr2 = nr * nr, nr7 = nr2 * nr2 * nr2 * nr;
+    const real rho2 = u[0] * u[0] + u[1] * u[1];
+    const real g = GMo / nr2 / nr;
+    const real ax = g * -u[0] + J2 * u[0] / nr7 * (6 * u[2] - (real)1.5 * rho2);
+    const real ay = g * -u[1] + J2 * u[1] / nr7 * (6 * u[2] - (real)1.5 * rho2);
+    const real az = g * -u[2] + J2 * u[2] / nr7 * (3 * u[2] - (real)4.5 * rho2);
+    const real v0 = u[3], v1 = u[4], v2 = u[5];
+    u[0] += dt * v0; u[1] += dt * v1; u[2] += dt * v2;
+    u[3] += dt * ax; u[4] += dt * ay; u[5] += dt * az;
+  }
+  TSAT_SYNC();
+  // ---- rows: GMST, lat/long, IGRF, NED -> ENU -> ECEF -> ECI (src/magnetic_toolbox.jl:56-98) ------------------
+  real* Bg = a.B + (size_t)traj * 3 * 2 * N;
+  for (int i = lane; i < 2 * N; i += WAVE) {
+    real b0 = 0, b1 = 0, b2 = 0;
+    if (i < 2 * N - 1) {                        // the last row is left zero (:76)
+      const real ti = t0 + dt * (real)i;
+      const real gmst = ((real)280.4606 + (real)360.9856473 * (ti / 24 / 60 / 60 + a.mjd) - (real)51544.5) / 180 * PI;   // as written (:60)
+      const real cg = cos_(gmst), sg = sin_(gmst);
+      const real p0 = Pg[3 * i], p1 = Pg[3 * i + 1], p2 = Pg[3 * i + 2];
+      const real e0 = cg * p0 + sg * p1, e1 = -sg * p0 + cg * p1, e2 = p2;
+      const real lat = asin_(e2 / sqrt_(e0 * e0 + e1 * e1 + e2 * e2));
+      const real lon = atan2_(e1, e0);
+      real bn[3];
+      igrf12_eval<real>(lds + L_IGRF, a.r_igrf_km, lat, lon, bn);
+      const real en0 = bn[1] * (real)1e-9, en1 = bn[0] * (real)1e-9, en2 = -bn[2] * (real)1e-9;    // /1e9, NED_to_ENU
+      const real sl = sin_(lon), cl = cos_(lon), sa = sin_(lat), ca = cos_(lat);
+      const real x = -sl * en0 - sa * cl * en1 + ca * cl * en2;
+      const real y = cl * en0 - sa * sl * en1 + ca * sl * en2;
+      const real z = ca * en1 + sa * en2;
+      b0 = cg * x - sg * y; b1 = sg * x + cg * y; b2 = z;
+    }
+    Bg[3 * i] = b0; Bg[3 * i + 1] = b1; Bg[3 * i + 2] = b2;
   }
 }
 

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "tsat_host_pack.hpp"
+#include "../../include/igrf12_2015_coeffs.h"   // IGRF-12 model constants (data), uploaded per call
 
 using namespace tsat;
 
@@ -27,6 +28,13 @@ __global__ __launch_bounds__(64) void tsat_tvlqr_kernel(TvArgs<real> a) {
   const int traj = blockIdx.x;
   if (traj >= a.T) return;
   tvlqr_trajectory<real, DIAGJ>(a, traj);
+}
+
+template <typename real>
+__global__ __launch_bounds__(64) void tsat_btable_kernel(BtArgs<real> a) {
+  const int traj = blockIdx.x;
+  if (traj >= a.T) return;
+  btable_trajectory<real>(a, traj);
 }
 
 template <typename real>
@@ -426,6 +434,55 @@ int tsat_horizon_batch(tsat_handle* h, int64_t T, int32_t n_rows, const double* 
   for (void* q : fr)
     if (q) (void)hipFree(q);
   if (rc) h->err = "device allocation, copy or launch failed in tsat_horizon_batch";
+  return rc;
+}
+
+void tsat_btable_default_options(tsat_btable_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->n_half = 5000;                          // src/TortoiseSat.jl:61
+  o->mjd = 58155.0;                          // src/TortoiseSat.jl:44
+  o->gm = 3.986004418e14 * 1e-9;             // km^3/s^2, src/input_parameters.jl:26
+  o->r_igrf_km = 400.0 + 6371.0;             // alt + R_E, src/magnetic_toolbox.jl:44,81
+  o->date = 2019.0;                          // src/magnetic_toolbox.jl:81
+}
+
+int tsat_btable_batch(tsat_handle* h, const tsat_btable_options* o, int64_t T, const double* kep, const double* t0,
+                      const double* tf, double* Btab, double* pos) {
+  if (!h || !o) return -1;
+  if (T < 1 || o->n_half < 1) return fail(h, -1, "bad dimensions");
+  if (!(o->date >= 2015.0 && o->date < 2020.0)) return fail(h, -1, "date must be in [2015, 2020): IGRF-12 epoch 2015 + secular variation");
+  if (!kep || !t0 || !tf || !Btab) return fail(h, -1, "null array");
+  for (int64_t t = 0; t < T; ++t)
+    if (!(kep[6 * t] >= 0.0 && kep[6 * t] < 1.0) || !(kep[6 * t + 1] > 0.0) || !(tf[t] > t0[t]))
+      return fail(h, -1, "need 0 <= e < 1, a > 0 and tf > t0");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  const int N = o->n_half;
+  const size_t Tn = (size_t)T, nP = Tn * 3 * (2 * (size_t)N + 1), nB = Tn * 3 * 2 * (size_t)N;
+  std::vector<double> coef(2 * IGRF12_NG + 2 * IGRF12_NH);
+  std::memcpy(coef.data(), IGRF12_G2015, sizeof(IGRF12_G2015));
+  std::memcpy(coef.data() + IGRF12_NG, IGRF12_GSV, sizeof(IGRF12_GSV));
+  std::memcpy(coef.data() + 2 * IGRF12_NG, IGRF12_H2015, sizeof(IGRF12_H2015));
+  std::memcpy(coef.data() + 2 * IGRF12_NG + IGRF12_NH, IGRF12_HSV, sizeof(IGRF12_HSV));
+  double *dc = nullptr, *dk = nullptr, *d0 = nullptr, *d1 = nullptr, *dP = nullptr, *dB = nullptr;
+  int rc = 0;
+  auto A = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 16) != hipSuccess) rc = -10; };
+  A((void**)&dc, coef.size() * 8); A((void**)&dk, Tn * 6 * 8); A((void**)&d0, Tn * 8); A((void**)&d1, Tn * 8);
+  A((void**)&dP, nP * 8); A((void**)&dB, nB * 8);
+  auto Cp = [&](void* d, const void* s, size_t bytes) { if (!rc && hipMemcpy(d, s, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -10; };
+  Cp(dc, coef.data(), coef.size() * 8); Cp(dk, kep, Tn * 6 * 8); Cp(d0, t0, Tn * 8); Cp(d1, tf, Tn * 8);
+  if (!rc) {
+    BtArgs<double> a;
+    a.T = (int)T; a.n_half = N; a.mjd = o->mjd; a.gm = o->gm; a.r_igrf_km = o->r_igrf_km; a.dty = o->date - 2015.0;
+    a.coef = dc; a.kep = dk; a.t0 = d0; a.tf = d1; a.pos = dP; a.B = dB;
+    hipLaunchKernelGGL(tsat_btable_kernel<double>, dim3((unsigned)T), dim3(64), 0, h->stream, a);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) rc = -10;
+  }
+  if (!rc && hipMemcpy(Btab, dB, nB * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && pos && hipMemcpy(pos, dP, nP * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  void* fr[] = {dc, dk, d0, d1, dP, dB};
+  for (void* q : fr)
+    if (q) (void)hipFree(q);
+  if (rc) h->err = "device allocation, copy or launch failed in tsat_btable_batch";
   return rc;
 }
 
