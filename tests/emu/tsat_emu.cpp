@@ -20,7 +20,6 @@ void* lds() { return g_lds; }
 }  // namespace tsat_emu
 
 #include "../../tortoisesat.jl_amd/csrc/tsat_host_pack.hpp"
-#include "../../include/igrf12_2015_coeffs.h"
 
 using namespace tsat;
 
@@ -135,14 +134,11 @@ extern "C" int emu_horizon_batch(int64_t T, int32_t n_rows, const double* Btab, 
 extern "C" int emu_btable_batch(const tsat_btable_options* o, int64_t T, const double* kep, const double* t0, const double* tf,
                                 double* Btab, double* pos) {
   const int N = o->n_half;
-  std::vector<double> coef(2 * IGRF12_NG + 2 * IGRF12_NH), P((size_t)T * 3 * (2 * N + 1));
-  std::memcpy(coef.data(), IGRF12_G2015, sizeof(IGRF12_G2015));
-  std::memcpy(coef.data() + IGRF12_NG, IGRF12_GSV, sizeof(IGRF12_GSV));
-  std::memcpy(coef.data() + 2 * IGRF12_NG, IGRF12_H2015, sizeof(IGRF12_H2015));
-  std::memcpy(coef.data() + 2 * IGRF12_NG + IGRF12_NH, IGRF12_HSV, sizeof(IGRF12_HSV));
+  std::vector<double> coef, P((size_t)T * 3 * (2 * N + 1));
+  igrf_records(o->date, o->r_igrf_km, coef);
   BtArgs<double> a;
-  a.T = (int)T; a.n_half = N; a.mjd = o->mjd; a.gm = o->gm; a.r_igrf_km = o->r_igrf_km; a.dty = o->date - 2015.0;
-  a.coef = coef.data(); a.kep = kep; a.t0 = t0; a.tf = tf; a.pos = P.data(); a.B = Btab;
+  a.T = (int)T; a.n_half = N; a.mjd = o->mjd; a.gm = o->gm; a.r_igrf_km = o->r_igrf_km;
+  a.tab = coef.data(); a.kep = kep; a.t0 = t0; a.tf = tf; a.pos = P.data(); a.B = Btab;
   for (int t = 0; t < (int)T; ++t) {
     std::vector<double> lds(LDS_REALS, 0.0);
     std::barrier<> bar(WAVE);

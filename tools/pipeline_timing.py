@@ -1,12 +1,12 @@
 """Developer tool: the reference's whole per-batch sequence on one GPU at the bench size —
-horizon selection -> AL-iLQR solve -> TVLQR tracking — for rocprofv3 --kernel-trace --stats."""
+field tables -> horizon selection -> AL-iLQR solve -> TVLQR tracking — for rocprofv3 --kernel-trace --stats."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from tsat_loader import load_package
 load_package()
-from tortoisesat_jl_amd import trajopt as to, slew_setup as ss, tracking as tr, horizon as hz
+from tortoisesat_jl_amd import trajopt as to, slew_setup as ss, tracking as tr, horizon as hz, magnetic as mg
 
 T, N = 1024, 1000
 b = ss.workload_monte_carlo(T=T, N=N)
@@ -14,9 +14,11 @@ opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = 5
 opts.opts_uncon.iterations = 10; opts.opts_uncon.dJ_counter_limit = 1
 s = to.AugmentedLagrangianSolver(None, opts)
 rng = np.random.default_rng(1)
-coarse = np.stack([ss.dipole_btable(5000, 2400.0 / 5000, 6771.0, 96.6, rng.random() * 360, rng.random() * 360) for _ in range(64)])
-coarse = np.ascontiguousarray(np.tile(coarse, (T // 64, 1, 1)))
+kep = np.tile([0.0, 6771.0, 96.6, 0.0, 0.0, 0.0], (T, 1)); kep[:, 3] = rng.random(T) * 360; kep[:, 5] = rng.random(T) * 360
 for rep in range(2):
+    tb = time.time(); coarse, _ = mg.magnetic_simulation(s, kep, 0.0, 2400.0, 5000, want_pos=False); coarse = coarse[:, :5000]
+    print(f"rep {rep}: field tables {1e3*(time.time()-tb):.1f} ms (host-inclusive, {T} orbits x 10000 rows)", flush=True)
+    coarse = np.ascontiguousarray(coarse)
     t0 = time.time(); idx, cond = hz.condition_based_time(s, coarse, 2400.0 / 5000, 30.0); t1 = time.time()
     res = to.solve_(to.BatchProblem.from_arrays(b), s, want_K=False); t2 = time.time()
     Qd, Qfd, Rd = tr.tvlqr_weights(T, r=0.5e3)

@@ -26,6 +26,7 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 #define TSAT_PHASE inline
 #define TSAT_FWD inline
 #define TSAT_GLOBAL
+#define TSAT_CONSTMEM
 #define TSAT_LANE() (tsat_emu::lane())
 #define TSAT_SYNC() (tsat_emu::sync())
 #define TSAT_SYNC_LDS() (tsat_emu::sync())
@@ -42,8 +43,10 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 // access through them is a flat_* instruction (both memory pipes, both wait counters) instead of global_*.
 #if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
 #define TSAT_GLOBAL __attribute__((address_space(1)))
+#define TSAT_CONSTMEM __attribute__((address_space(4)))   /* read-only for the kernel's lifetime: uniform reads become s_load */
 #else
 #define TSAT_GLOBAL   /* host pass of the same translation unit: only parses the device functions */
+#define TSAT_CONSTMEM
 #endif
 #define TSAT_LANE() ((int)threadIdx.x)
 // full fence: orders global AND LDS traffic between the lanes of the wave (s_waitcnt vmcnt(0) lgkmcnt(0))
@@ -1550,14 +1553,16 @@ TSAT_DEV void horizon_trajectory(const HzArgs<real>& a, int traj) {
 // positions); then lanes = table rows, each evaluating the degree-13 IGRF-12 sum for its sample with the Legendre
 // recurrences fully unrolled (three rolling rows of P in registers, coefficients broadcast from LDS).
 // ==================================================================================================
-constexpr int IGRF_NMAX = 13, IGRF_NG = 104, IGRF_NH = 91;
-constexpr int L_IGRF = L_UNION;   // g(104) h(91), already advanced to the requested date
-
+constexpr int IGRF_NMAX = 13, IGRF_NREC = 104, IGRF_RECW = 8;
+// One record per (n, m), m = 0..n, n = 1..13, built on the host for the call's date and radius (tsat_host_pack.hpp,
+// igrf_records): {g, h, d1, d2, a', b', -(n+1)/r, (a/r)^(n+1)}, where (a', b') are the Schmidt recurrence factors of the
+// NEXT function the sweep needs (P[n][m+1], or P[n+1][0] on the diagonal). Every lane reads the same record, so the
+// table is read with scalar loads (one s_load_dwordx16 per harmonic) and the loop carries no per-lane constants.
 template <typename real>
 struct BtArgs {
   int T, n_half;
-  real mjd, gm, r_igrf_km, dty;     // dty = date - 2015
-  const real* coef;                 // [390] g2015, gsv, h2015, hsv
+  real mjd, gm, r_igrf_km;
+  const real* tab;                  // [104][8] records
   const real* kep;                  // [T][6]
   const real* t0;                   // [T]
   const real* tf;                   // [T]
@@ -1567,79 +1572,77 @@ struct BtArgs {
 
 // igrf12(date, r, lat, lon) geocentric, nT (src/igrf.jl:70-274; Legendre: src/legendre.jl:254-292, src/dlegendre.jl:221-309)
 template <typename real>
-TSAT_DEV void igrf12_eval(const real* gh, real r_km, real lat, real lon, real out[3]) {
+TSAT_DEV void igrf12_eval(const TSAT_CONSTMEM real* tab, real r_km, real lat, real lon, real out[3]) {
   const real PI = (real)3.14159265358979323846;
   const real theta = PI / 2 - lat;
   const real phi = (lon >= 0) ? lon : 2 * PI + lon;
   const real c = cos_(theta), s = sqrt_(1 - c * c);
   const real a = (real)6371.2, r = r_km;
   const real sin_p = sin_(phi), cos_p = cos_(phi);
-  const real ratio = a / r;
   const real dfact = (fmod_(theta, 2 * PI) > PI) ? (real)-1 : (real)1;
-  real fact = ratio, dVr = 0, dVt = 0, dVp = 0;
+  const bool pole = (theta == 0);
+  // sin(m phi), cos(m phi) by the reference's two-term recurrences (src/igrf.jl:208-246): the same for every degree
+  real sm[IGRF_NMAX + 1], cm[IGRF_NMAX + 1];
+  {
+    real s1 = 0, s2 = -sin_p, c1 = 1, c2 = cos_p;
+#ifndef TSAT_EMU
+#pragma unroll
+#endif
+    for (int m = 1; m <= IGRF_NMAX; ++m) {
+      sm[m] = 2 * cos_p * s1 - s2;
+      cm[m] = 2 * cos_p * c1 - c2;
+      s2 = s1; s1 = sm[m]; c2 = c1; c1 = cm[m];
+    }
+  }
+  real dVr = 0, dVt = 0, dVp = 0;
   real Pa[IGRF_NMAX + 3], Pb[IGRF_NMAX + 3], Pc[IGRF_NMAX + 3];   // rows n-2, n-1, n (zero beyond the diagonal)
   for (int i = 0; i < IGRF_NMAX + 3; ++i) { Pa[i] = 0; Pb[i] = 0; Pc[i] = 0; }
-  Pb[0] = 1;   // P[0][0]
-  int kg = 0, kh = 0;
+  Pb[0] = 1; Pc[0] = c; Pc[1] = s;   // P[0][0]; P[1][0], P[1][1]
+  const TSAT_CONSTMEM real* nxt = tab;
+  real ar = 0, at = 0, ap = 0;
 #ifndef TSAT_EMU
 #pragma unroll
 #endif
   for (int n = 1; n <= IGRF_NMAX; ++n) {
-    // row n of the Schmidt quasi-normalised functions
-    if (n == 1) {
-      Pc[0] = c; Pc[1] = s;
-    } else {
 #ifndef TSAT_EMU
 #pragma unroll
 #endif
-      for (int m = 0; m < n; ++m) {
-        const double aux = (double)((n - m) * (n + m));
-        const real a_nm = (real)sqrt_(((2.0 * n - 1) * (2.0 * n - 1)) / aux);
-        const real b_nm = (real)sqrt_(((double)(n + m - 1) * (n - m - 1)) / aux);
-        Pc[m] = a_nm * c * Pb[m] - b_nm * Pa[m];
+    for (int m = 0; m <= n; ++m) {
+      const TSAT_CONSTMEM real* rec = nxt;   // record (n, m)
+      nxt = rec + IGRF_RECW;
+#ifndef TSAT_EMU
+      // The records are invariant loads: left alone, all 104 x 8 values are hoisted to the top and spill 800 SGPRs.
+      // Tying the NEXT record's address to this harmonic's running sum keeps exactly one record in flight ahead.
+      asm volatile("" : "+s"(nxt), "+v"(ar), "+v"(at), "+v"(ap));
+#endif
+      if (n >= 2 && m + 1 <= n)     // P[n][m+1]: recurrence below the diagonal, closed form on it
+        Pc[m + 1] = (m + 1 < n) ? rec[4] * c * Pb[m + 1] - rec[5] * Pa[m + 1] : s * rec[4] * Pb[n - 1];
+      const real q = rec[6];
+      if (m == 0) {
+        const real dP0 = (rec[2] * Pc[1] + rec[3] * Pc[1]) * dfact;
+        ar = q * rec[0] * Pc[0];
+        at = rec[0] * dP0;
+        ap = 0;
+      } else {
+        const real Gnm = rec[0], Hnm = rec[1];
+        const real dPm = (rec[2] * Pc[m - 1] + rec[3] * Pc[m + 1]) * dfact;
+        const real GcHs = Gnm * cm[m] + Hnm * sm[m], GsHc = Gnm * sm[m] - Hnm * cm[m];
+        ar += q * GcHs * Pc[m];
+        at += GcHs * dPm;
+        ap += -(real)m * GsHc * (pole ? dPm : Pc[m]);
       }
-      Pc[n] = s * (real)sqrt_((2.0 * n - 1) / (2.0 * n)) * Pb[n - 1];
+      if (m == n) {
+        const real fact = rec[7];
+        dVr += ar * fact; dVp += ap * fact; dVt += at * fact;
+        for (int i = 0; i < IGRF_NMAX + 3; ++i) { Pa[i] = Pb[i]; Pb[i] = Pc[i]; }
+        Pc[n + 1] = 0; Pc[n + 2] = 0;
+        if (n < IGRF_NMAX) Pc[0] = rec[4] * c * Pb[0] - rec[5] * Pa[0];   // P[n+1][0]
+      }
     }
-    Pc[n + 1] = 0;
-    real ar = 0, at = 0, ap = 0;
-    {
-      const real Gnm = gh[kg];
-      ++kg;
-      const real aux = (real)sqrt_(n * (n + 1) / 2.0);
-      const real dP0 = (-((real)0.5 * aux) * Pc[1] + (-(real)0.5 * aux) * Pc[1]) * dfact;
-      ar += -(real)(n + 1) / r * Gnm * Pc[0];
-      at += Gnm * dP0;
-    }
-    real sin_m1 = 0, sin_m2 = -sin_p, cos_m1 = 1, cos_m2 = cos_p;
-#ifndef TSAT_EMU
-#pragma unroll
-#endif
-    for (int m = 1; m <= n; ++m) {
-      const real sin_m = 2 * cos_p * sin_m1 - sin_m2;
-      const real cos_m = 2 * cos_p * cos_m1 - cos_m2;
-      const real Gnm = gh[kg], Hnm = gh[IGRF_NG + kh];
-      ++kg; ++kh;
-      real dPm;
-      if (m == 1)
-        dPm = (real)(0.5 * sqrt_(2.0 * n * (n + 1))) * Pc[0] - (real)(0.5 * sqrt_((double)(n + 2) * (n - 1))) * Pc[2];
-      else if (n != m)
-        dPm = (real)(0.5 * sqrt_((double)(n + m) * (n - m + 1))) * Pc[m - 1] - (real)(0.5 * sqrt_((double)(n + m + 1) * (n - m))) * Pc[m + 1];
-      else
-        dPm = (real)(0.5 * sqrt_((double)(n + m) * (n - m + 1))) * Pc[m - 1];
-      dPm *= dfact;
-      const real GcHs = Gnm * cos_m + Hnm * sin_m, GsHc = Gnm * sin_m - Hnm * cos_m;
-      ar += -(real)(n + 1) / r * GcHs * Pc[m];
-      at += GcHs * dPm;
-      ap += (theta == 0) ? -(real)m * GsHc * dPm : -(real)m * GsHc * Pc[m];
-      sin_m2 = sin_m1; sin_m1 = sin_m; cos_m2 = cos_m1; cos_m1 = cos_m;
-    }
-    fact *= ratio;
-    dVr += ar * fact; dVp += ap * fact; dVt += at * fact;
-    for (int i = 0; i < IGRF_NMAX + 3; ++i) { Pa[i] = Pb[i]; Pb[i] = Pc[i]; }
   }
   dVr *= a; dVp *= a; dVt *= a;
   out[0] = 1 / r * dVt;
-  out[1] = (theta == 0) ? -1 / r * dVp : -1 / (r * sin_(theta)) * dVp;
+  out[1] = pole ? -1 / r * dVp : -1 / (r * sin_(theta)) * dVp;
   out[2] = dVr;
 }
 
@@ -1649,12 +1652,6 @@ TSAT_DEV void btable_trajectory(const BtArgs<real>& a, int traj) {
   const int lane = TSAT_LANE();
   const int N = a.n_half;
   const real PI = (real)3.14159265358979323846, D2R = PI / 180;
-  // coefficients at the requested date: g = g2015 + sv (date - 2015)   (src/igrf.jl:172-177)
-  for (int i = lane; i < IGRF_NG + IGRF_NH; i += WAVE) {
-    const int src = (i < IGRF_NG) ? i : (2 * IGRF_NG + (i - IGRF_NG));
-    const int sv = (i < IGRF_NG) ? (IGRF_NG + i) : (2 * IGRF_NG + IGRF_NH + (i - IGRF_NG));
-    lds[L_IGRF + i] = a.coef[src] + a.coef[sv] * a.dty;
-  }
   // ---- kep_ECI (src/kep_ECI.jl:1-35) ---------------------------------------------------------------
   const real* kp = a.kep + (size_t)traj * 6;
   const real t0 = a.t0[traj], tf = a.tf[traj];
@@ -1710,7 +1707,7 @@ TSAT_DEV void btable_trajectory(const BtArgs<real>& a, int traj) {
       const real lat = asin_(e2 / sqrt_(e0 * e0 + e1 * e1 + e2 * e2));
       const real lon = atan2_(e1, e0);
       real bn[3];
-      igrf12_eval<real>(lds + L_IGRF, a.r_igrf_km, lat, lon, bn);
+      igrf12_eval<real>((const TSAT_CONSTMEM real*)a.tab, a.r_igrf_km, lat, lon, bn);
       const real en0 = bn[1] * (real)1e-9, en1 = bn[0] * (real)1e-9, en2 = -bn[2] * (real)1e-9;    // /1e9, NED_to_ENU
       const real sl = sin_(lon), cl = cos_(lon), sa = sin_(lat), ca = cos_(lat);
       const real x = -sl * en0 - sa * cl * en1 + ca * cl * en2;

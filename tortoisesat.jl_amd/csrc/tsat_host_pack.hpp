@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "tsat_device.hpp"
+#include "../../include/igrf12_2015_coeffs.h"   // IGRF-12 model constants (data)
 
 namespace tsat {
 
@@ -183,6 +184,49 @@ inline std::string check_tv_options(const tsat_tvlqr_options& o) {
   if (o.n_tab < 1) return "n_tab must be >= 1";
   if (o.min_steps < 0) return "min_steps must be >= 0";
   return "";
+}
+
+// Records of the field-table kernel (tsat_device.hpp, igrf12_eval): per (n, m) the Gauss coefficients advanced to
+// `date` (src/igrf.jl:172-177), the derivative factors (src/dlegendre.jl:221-309), the Schmidt recurrence factors
+// (src/legendre.jl:254-292) of the next function the sweep computes, and the two radial factors of degree n
+// (src/igrf.jl:196-252).
+inline void igrf_schmidt_factors(int n, int m, double& a_nm, double& b_nm) {   // P[n][m], n >= 2
+  if (m < n) {
+    const double aux = (double)((n - m) * (n + m));
+    a_nm = std::sqrt(((2.0 * n - 1) * (2.0 * n - 1)) / aux);
+    b_nm = std::sqrt(((double)(n + m - 1) * (n - m - 1)) / aux);
+  } else {
+    a_nm = std::sqrt((2.0 * n - 1) / (2.0 * n));
+    b_nm = 0.0;
+  }
+}
+
+inline void igrf_records(double date, double r_km, std::vector<double>& tab) {
+  tab.assign((size_t)IGRF_NREC * IGRF_RECW, 0.0);
+  const double dt = date - 2015.0, ratio = 6371.2 / r_km;
+  double fact = ratio;
+  int kg = 0, kh = 0;
+  for (int n = 1; n <= IGRF_NMAX; ++n) {
+    fact *= ratio;
+    for (int m = 0; m <= n; ++m, ++kg) {
+      double* rec = tab.data() + (size_t)kg * IGRF_RECW;
+      rec[0] = IGRF12_G2015[kg] + IGRF12_GSV[kg] * dt;
+      if (m > 0) { rec[1] = IGRF12_H2015[kh] + IGRF12_HSV[kh] * dt; ++kh; }
+      if (m == 0) {
+        const double aux = std::sqrt(n * (n + 1) / 2.0);
+        rec[2] = -(0.5 * aux); rec[3] = -0.5 * aux;
+      } else if (m == 1) {
+        rec[2] = 0.5 * std::sqrt(2.0 * n * (n + 1)); rec[3] = -(0.5 * std::sqrt((double)(n + 2) * (n - 1)));
+      } else {
+        rec[2] = 0.5 * std::sqrt((double)(n + m) * (n - m + 1));
+        rec[3] = (n != m) ? -(0.5 * std::sqrt((double)(n + m + 1) * (n - m))) : 0.0;
+      }
+      if (m < n) { if (n >= 2) igrf_schmidt_factors(n, m + 1, rec[4], rec[5]); }
+      else if (n < IGRF_NMAX) igrf_schmidt_factors(n + 1, 0, rec[4], rec[5]);
+      rec[6] = -(n + 1) / r_km;
+      rec[7] = fact;
+    }
+  }
 }
 
 }  // namespace tsat

@@ -9,7 +9,6 @@
 #include <string>
 #include <vector>
 #include "tsat_host_pack.hpp"
-#include "../../include/igrf12_2015_coeffs.h"   // IGRF-12 model constants (data), uploaded per call
 
 using namespace tsat;
 
@@ -458,11 +457,8 @@ int tsat_btable_batch(tsat_handle* h, const tsat_btable_options* o, int64_t T, c
   TSAT_HIP(h, hipSetDevice(h->dev));
   const int N = o->n_half;
   const size_t Tn = (size_t)T, nP = Tn * 3 * (2 * (size_t)N + 1), nB = Tn * 3 * 2 * (size_t)N;
-  std::vector<double> coef(2 * IGRF12_NG + 2 * IGRF12_NH);
-  std::memcpy(coef.data(), IGRF12_G2015, sizeof(IGRF12_G2015));
-  std::memcpy(coef.data() + IGRF12_NG, IGRF12_GSV, sizeof(IGRF12_GSV));
-  std::memcpy(coef.data() + 2 * IGRF12_NG, IGRF12_H2015, sizeof(IGRF12_H2015));
-  std::memcpy(coef.data() + 2 * IGRF12_NG + IGRF12_NH, IGRF12_HSV, sizeof(IGRF12_HSV));
+  std::vector<double> coef;
+  igrf_records(o->date, o->r_igrf_km, coef);
   double *dc = nullptr, *dk = nullptr, *d0 = nullptr, *d1 = nullptr, *dP = nullptr, *dB = nullptr;
   int rc = 0;
   auto A = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 16) != hipSuccess) rc = -10; };
@@ -472,8 +468,8 @@ int tsat_btable_batch(tsat_handle* h, const tsat_btable_options* o, int64_t T, c
   Cp(dc, coef.data(), coef.size() * 8); Cp(dk, kep, Tn * 6 * 8); Cp(d0, t0, Tn * 8); Cp(d1, tf, Tn * 8);
   if (!rc) {
     BtArgs<double> a;
-    a.T = (int)T; a.n_half = N; a.mjd = o->mjd; a.gm = o->gm; a.r_igrf_km = o->r_igrf_km; a.dty = o->date - 2015.0;
-    a.coef = dc; a.kep = dk; a.t0 = d0; a.tf = d1; a.pos = dP; a.B = dB;
+    a.T = (int)T; a.n_half = N; a.mjd = o->mjd; a.gm = o->gm; a.r_igrf_km = o->r_igrf_km;
+    a.tab = dc; a.kep = dk; a.t0 = d0; a.tf = d1; a.pos = dP; a.B = dB;
     hipLaunchKernelGGL(tsat_btable_kernel<double>, dim3((unsigned)T), dim3(64), 0, h->stream, a);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) rc = -10;
   }
