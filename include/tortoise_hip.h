@@ -201,13 +201,17 @@ void tsat_tvlqr_default_options(tsat_tvlqr_options* o);
  *                                noise(3) — the values the reference draws inside `simulator` (src/simulator.jl:5,10,22);
  *                                NULL = noise-free plant (`gain_simulator`)
  *   X_sim 7xNxT, U_sim 3x(N-1)xT, K_lqr 3x6x(N-1)xT (may be NULL), stats T        outputs
+ *   n_knots T or NULL            per-trajectory horizons as for tsat_batch_knots (`t_total[i]`, src/monte_carlo.jl:145):
+ *                                trajectory t is tracked over its first n_knots[t] samples, the rest of its slabs is
+ *                                zero and its statistic counts n_knots[t] samples; NULL = all N
  */
 int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int64_t n_btab,
                       const double* X, const double* U, const double* xf,
                       const double* Btab, const int32_t* btab_idx, const double* tau0, const double* dtau,
                       const double* dt, const double* Jmat, const double* Qd, const double* Qfd, const double* Rd,
                       const double* x0_sim, const double* noise,
-                      double* X_sim, double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats);
+                      double* X_sim, double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats,
+                      const int32_t* n_knots);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Horizon selection (the caller right before the solve): cumulative magnetic Gramian of a field table and the first

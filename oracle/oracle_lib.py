@@ -176,7 +176,8 @@ def tvlqr_batch(batch, X, U, Qd, Qfd, Rd, x0_sim, noise=None, opts=None, nthread
     rc = lib.orc_tvlqr_batch(C.byref(o), C.c_int64(T), C.c_int64(batch.Btab.shape[0]), d(X), d(U), d(batch.xf), d(batch.Btab),
                              batch.btab_idx.ctypes.data_as(C.POINTER(C.c_int32)), d(batch.tau0), d(batch.dtau), d(batch.dt),
                              d(batch.Jmat), d(Qd), d(Qfd), d(Rd), d(x0_sim), d(noise) if noise is not None else None,
-                             d(Xs), d(Us), d(K), st.ctypes.data_as(C.c_void_p), C.c_int(nthreads))
+                             d(Xs), d(Us), d(K), st.ctypes.data_as(C.c_void_p), C.c_int(nthreads),
+                             None if batch.n_knots is None else np.ascontiguousarray(batch.n_knots, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32)))
     if rc != 0:
         raise RuntimeError(f"orc_tvlqr_batch failed rc={rc}")
     return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)

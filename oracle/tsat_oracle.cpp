@@ -853,24 +853,25 @@ int orc_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, cons
                     const double* xf, const double* Btab, const int32_t* btab_idx, const double* tau0,
                     const double* dtau, const double* dt, const double* Jmat, const double* Qd, const double* Qfd,
                     const double* Rd, const double* x0_sim, const double* noise, double* X_sim, double* U_sim,
-                    double* K_lqr, tsat_tvlqr_stats* stats, int nthreads) {
+                    double* K_lqr, tsat_tvlqr_stats* stats, int nthreads, const int32_t* n_knots) {
   if (!o || o->n_knots < 2 || o->n_tab < 1) return -1;
   if (!btab_idx && n_btab != T) return -1;
-  const int N = o->n_knots;
+  const int NS = o->n_knots;   // slab stride; a ragged trajectory uses its first n_knots[t] samples (zero beyond)
   (void)nthreads;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1)
 #endif
   for (int64_t t = 0; t < T; ++t) {
     Traj tr;
+    const int N = n_knots ? n_knots[t] : NS;
     tr.N = N; tr.n_tab = o->n_tab; tr.integ = 4;
     tr.Bt = Btab + (size_t)(btab_idx ? btab_idx[t] : t) * 3 * o->n_tab;
     tr.tau0 = tau0[t]; tr.dtau = dtau[t]; tr.dt = dt[t];
     std::memcpy(tr.ph.J, Jmat + 9 * t, sizeof(tr.ph.J));
     inv3(tr.ph.J, tr.ph.Jinv);
     tr.ph.u_scale = o->u_scale;
-    const double* Xt = X + (size_t)7 * N * t;
-    const double* Ut = U + (size_t)3 * (N - 1) * t;
+    const double* Xt = X + (size_t)7 * NS * t;
+    const double* Ut = U + (size_t)3 * (NS - 1) * t;
     const double h = tr.dt, hl = o->linearize_dt_sq ? h * h : h, frac = hl / h;
     // gains: Jacobians of the rk4-discretised gain_simulator at (X_k, U_k) (src/attitude_controller.jl:95-119) ...
     std::vector<double> Ah((size_t)36 * (N - 1)), Bh((size_t)18 * (N - 1)), Kt((size_t)18 * (N - 1));
@@ -885,8 +886,11 @@ int orc_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, cons
     for (int i = 0; i < 3; ++i) R[i * 3 + i] = Rd[3 * t + i];
     orc_tvlqr_riccati(N, Ah.data(), Bh.data(), Q, R, Qf, Kt.data());   // (:83-92)
     // closed loop (:39-45)
-    double* Xs = X_sim + (size_t)7 * N * t;
-    double* Us = U_sim + (size_t)3 * (N - 1) * t;
+    double* Xs = X_sim + (size_t)7 * NS * t;
+    double* Us = U_sim + (size_t)3 * (NS - 1) * t;
+    std::memset(Xs, 0, sizeof(double) * 7 * NS);
+    std::memset(Us, 0, sizeof(double) * 3 * (NS - 1));
+    if (K_lqr) std::memset(K_lqr + (size_t)t * (NS - 1) * 18, 0, sizeof(double) * 18 * (NS - 1));
     for (int i = 0; i < 7; ++i) Xs[i] = x0_sim[7 * t + i];
     for (int k = 0; k < N - 1; ++k) {
       const double* xs = Xs + 7 * k;
@@ -902,7 +906,7 @@ int orc_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, cons
         us[a] = v;
         Us[3 * k + a] = v;
       }
-      const double* nz = noise ? noise + ((size_t)t * (N - 1) + k) * 36 : nullptr;
+      const double* nz = noise ? noise + ((size_t)t * (NS - 1) + k) * 36 : nullptr;
       const double *b0 = brow(tr, k, 0.0), *b1 = brow(tr, k, 0.5), *b2 = brow(tr, k, 1.0);
       double k1[7], k2[7], k3[7], k4[7], tmp[7];
       sim_dyn(xs, us, b0, nz, tr.ph, k1);
@@ -917,7 +921,7 @@ int orc_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, cons
     if (K_lqr)
       for (int k = 0; k < N - 1; ++k)
         for (int a = 0; a < 3; ++a)
-          for (int j = 0; j < 6; ++j) K_lqr[((size_t)t * (N - 1) + k) * 18 + j * 3 + a] = Kt[(size_t)18 * k + a * 6 + j];
+          for (int j = 0; j < 6; ++j) K_lqr[((size_t)t * (NS - 1) + k) * 18 + j * 3 + a] = Kt[(size_t)18 * k + a * 6 + j];
     // slew-time statistic (src/monte_carlo.jl:242-262; the norm is taken at sample j — the reference indexes the
     // run number there, an evident slip)
     tsat_tvlqr_stats& st = stats[t];

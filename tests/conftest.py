@@ -74,7 +74,8 @@ class Emu:
         rc = self.lib.emu_tvlqr_batch(C.byref(o), C.c_int64(T), C.c_int64(batch.Btab.shape[0]), d(X), d(U), d(batch.xf),
                                       d(batch.Btab), self.abi.as_ip(batch.btab_idx), d(batch.tau0), d(batch.dtau), d(batch.dt),
                                       d(batch.Jmat), d(Qd), d(Qfd), d(Rd), d(x0_sim), d(noise), d(Xs), d(Us), d(K),
-                                      st.ctypes.data_as(C.c_void_p))
+                                      st.ctypes.data_as(C.c_void_p),
+                                      None if batch.n_knots is None else self.abi.as_ip(np.ascontiguousarray(batch.n_knots, dtype=np.int32)))
         if rc != 0:
             raise RuntimeError(f"emu_tvlqr_batch rc={rc}")
         return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)

@@ -22,6 +22,15 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = load_package()
     ss, sweep = pkg.slew_setup, pkg.sweep
+    if len(sys.argv) > 3 and sys.argv[3] == "mc":   # the whole experiment, summaries all-gathered in trial order
+        from mc_stages import OracleStages
+        mc = pkg.monte_carlo
+        r = mc.monte_carlo(OracleStages(ol, nthreads=2), number_sims=T_total, seed=8, rank=rank, world=world, chunk=2,
+                           setup=mc.MonteCarloSetup(N=600, dt=1.0, outer=2, inner=4))
+        np.savez(f"{out}.rank{rank}.npz", **{k: r[k] for k in ("A", "t_final", "slew_time", "fails", "n_knots")})
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     full = ss.workload_monte_carlo(T=T_total, N=40, seed=99, random_orbit=True)
     o = ol.default_options()
     o.max_outer, o.max_inner = 2, 3

@@ -39,3 +39,23 @@ def test_two_rank_sweep_equals_single_process(pkg, ol, tmp_path, T_total):
         # independent trajectories: the sharded sweep is the concatenation of the shards, bit for bit
         assert np.array_equal(z["X"], ref["X"]) and np.array_equal(z["U"], ref["U"])
         assert np.array_equal(z["stats"], ref["stats"])
+
+
+def test_two_rank_monte_carlo_equals_single_process(pkg, ol, tmp_path):
+    """the full experiment (tables -> horizon -> solve -> tracking -> statistic) sharded over two ranks"""
+    from mc_stages import OracleStages
+    port = free_port()
+    out = str(tmp_path / "mc")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), out, "5", "mc"], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    mc = pkg.monte_carlo
+    ref = mc.monte_carlo(OracleStages(ol), number_sims=5, seed=8, setup=mc.MonteCarloSetup(N=600, dt=1.0, outer=2, inner=4))
+    for r in range(2):
+        z = np.load(f"{out}.rank{r}.npz")
+        for k in ("A", "t_final", "slew_time", "fails", "n_knots"):
+            assert np.array_equal(z[k], ref[k]), k

@@ -92,6 +92,34 @@ def test_emulated_tracking_kernel_matches_oracle(pkg, ol, emu, noisy):
     _same_tracking(ref, got)
 
 
+def _ragged(pkg, ol, T=3, N=60, nk=(60, 37, 12)):
+    b = pkg.slew_setup.workload_monte_carlo(T=T, N=N, seed=77)
+    b.n_knots = np.array(nk, dtype=np.int32)
+    r = ol.solve_batch(b, oracle_options(ol, max_outer=3, max_inner=6, dj_counter_limit=1))
+    return b, r
+
+
+def test_ragged_tracking_equals_separate_runs(pkg, ol, emu):
+    """variable horizons (t_total[i], src/monte_carlo.jl:145): each trajectory is tracked over its own knots — same
+    numbers as tracking it alone in a batch of its own length — and its slabs are zero beyond"""
+    b, r = _ragged(pkg, ol)
+    Qd, Qfd, Rd, x0s, nz = _setup(pkg, b)
+    ref = ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz)
+    got = emu.tvlqr(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz)
+    _same_tracking(ref, got)
+    for t, n in enumerate(b.n_knots):
+        assert np.all(ref["X_sim"][t, n:] == 0) and np.all(ref["U_sim"][t, n - 1:] == 0) and np.all(got["X_sim"][t, n:] == 0)
+        assert np.all(got["K"][t, n - 1:] == 0)
+        one = b.slice(t, t + 1)
+        one.N, one.n_knots = int(n), None
+        one.U0 = np.ascontiguousarray(one.U0[:, :n - 1])
+        alone = ol.tvlqr_batch(one, r["X"][t:t + 1, :n], r["U"][t:t + 1, :n - 1], Qd[t:t + 1], Qfd[t:t + 1], Rd[t:t + 1],
+                               x0s[t:t + 1], noise=nz[t:t + 1, :n - 1])
+        assert np.array_equal(alone["X_sim"][0], ref["X_sim"][t, :n])
+        assert alone["stats"]["slew_index"][0] == ref["stats"]["slew_index"][t]
+        assert alone["stats"]["slew_time"][0] == ref["stats"]["slew_time"][t]
+
+
 def _same_tracking(ref, got):
     kscale = max(float(np.max(np.abs(ref["K"]))), 1.0)
     assert np.max(np.abs(ref["K"] - got["K"])) < 1e-8 * kscale
@@ -121,4 +149,11 @@ def test_gpu_tracking_matches_oracle(pkg, ol):
     o = ol.tvlqr_default_options(); o.linearize_dt_sq = 0
     _same_tracking(ol.tvlqr_batch(b, res["X"], res["U"], Qd, Qfd, Rd, x0s, noise=nz, opts=o, nthreads=8), got2)
     assert np.max(np.abs(got2["K"] - got["K"])) > 1e-3          # the dt^2 quirk changes the gains
+    # ragged batch through the C ABI
+    b, r = _ragged(pkg, ol, T=5, N=300, nk=(300, 211, 64, 65, 2))
+    Qd, Qfd, Rd, x0s, nz = _setup(pkg, b)
+    got = tr.attitude_simulation(s, b, r["X"], r["U"], x0s, Qd, Qfd, Rd, noise=nz)
+    _same_tracking(ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz, nthreads=5), got)
+    for t, n in enumerate(b.n_knots):
+        assert np.all(got["X_sim"][t, n:] == 0) and np.all(got["U_sim"][t, n - 1:] == 0)
     s.close()

@@ -11,6 +11,6 @@ Only the hot path lives here: ``csrc/`` holds the hand-written H
   horizon     Gramian-based horizon selection (src/magnetic_toolbox.jl:1-31)
   tracking    closed-loop TVLQR tracking + slew-time statistic (src/attitude_controller.jl:1-119)
 """
-from . import _abi, horizon, magnetic, slew_setup, sweep, tracking, trajopt  # noqa: F401
+from . import _abi, horizon, magnetic, monte_carlo, results, slew_setup, sweep, tracking, trajopt  # noqa: F401
 
-__all__ = ["_abi", "horizon", "magnetic", "slew_setup", "sweep", "tracking", "trajopt"]
+__all__ = ["_abi", "horizon", "magnetic", "monte_carlo", "results", "slew_setup", "sweep", "tracking", "trajopt"]

@@ -97,7 +97,7 @@ PROTOTYPES = {
     "tsat_horizon_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, _ip, _dp]),
     "tsat_tvlqr_default_options": (None, [C.POINTER(TvlqrOptions)]),
     "tsat_tvlqr_batch": (C.c_int, [C.c_void_p, C.POINTER(TvlqrOptions), C.c_int64, C.c_int64, _dp, _dp, _dp, _dp, _ip,
-                                   _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
+                                   _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p, _ip]),
 }
 
 LIB_NAME = "libtortoise_hip.so"

@@ -1274,6 +1274,7 @@ struct TvArgs {
   const real* P;      // [T][PSTRIDE]
   const real* BT;     // [n_btab][n_tab][4]
   const int* bidx;    // [T]
+  const int* nk;      // [T] per-trajectory knot counts or null (all N)
   const real* XUR;    // [T][N][10]   optimised (X,U) records
   const real* NZ;     // [T][N-1][4][9] noise or null
   real* KD;           // [T][N-1][24] gains (solver sign) + unused d
@@ -1363,10 +1364,11 @@ template <typename real, int DIAGJ>
 TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
-  const int N = a.N, n_tab = a.n_tab;
+  const int NS = a.N, n_tab = a.n_tab;            // slab stride; own horizon below (as solve_trajectory)
+  const int N = a.nk ? a.nk[traj] : a.N;
   TPtrs<real> p;
-  p.XU = (TSAT_GLOBAL real*)(a.XUR + (size_t)traj * N * XUW);
-  p.KD = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * (N - 1) * KDW);
+  p.XU = (TSAT_GLOBAL real*)(a.XUR + (size_t)traj * NS * XUW);
+  p.KD = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * (NS - 1) * KDW);
   p.LAM = nullptr; p.CAND = nullptr;
   p.bt = (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[traj] * n_tab * 4);
   stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)traj * PSTRIDE), a.us);
@@ -1395,8 +1397,8 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
   }
   // ---- tracking: x_sim(k+1) = rk4(plant)(x_sim(k), U(k) - K(k) dX(k))   (src/attitude_controller.jl:39-45) -----
   const Traj<real> tr = load_traj<real>(N, n_tab, p.bt);
-  TSAT_GLOBAL real* XSg = (TSAT_GLOBAL real*)(a.XS + (size_t)traj * N * XUW);
-  const TSAT_GLOBAL real* NZg = a.NZ ? (const TSAT_GLOBAL real*)(a.NZ + (size_t)traj * (N - 1) * 36) : nullptr;
+  TSAT_GLOBAL real* XSg = (TSAT_GLOBAL real*)(a.XS + (size_t)traj * NS * XUW);
+  const TSAT_GLOBAL real* NZg = a.NZ ? (const TSAT_GLOBAL real*)(a.NZ + (size_t)traj * (NS - 1) * 36) : nullptr;
   real x[7];
   for (int i = 0; i < 7; ++i) x[i] = lds[L_TR + P_X0 + i];
   for (int k = 0; k < N - 1; ++k) {

@@ -350,7 +350,7 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
                      const double* U, const double* xf, const double* Btab, const int32_t* btab_idx,
                      const double* tau0, const double* dtau, const double* dt, const double* Jmat, const double* Qd,
                      const double* Qfd, const double* Rd, const double* x0_sim, const double* noise, double* X_sim,
-                     double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats) {
+                     double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats, const int32_t* n_knots) {
   if (!h || !o) return -1;
   const std::string why = check_tv_options(*o);
   if (!why.empty()) return fail(h, -1, why);
@@ -366,6 +366,7 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
     const int64_t v = btab_idx ? btab_idx[t] : t;
     if (v < 0 || v >= n_btab) return fail(h, -1, "btab_idx out of range");
     if (!(dt[t] > 0.0)) return fail(h, -1, "dt must be positive");
+    if (n_knots && (n_knots[t] < 2 || n_knots[t] > N)) return fail(h, -1, "n_knots[t] must be in [2, N]");
     bi[(size_t)t] = (int)v;
   }
   std::vector<double> P(Tn * PSTRIDE), BT((size_t)n_btab * n_tab * 4), XUR(Tn * N * XUW);
@@ -373,7 +374,7 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
   pack_btab<double>(n_btab, n_tab, Btab, BT.data());
   pack_xu_records<double>(T, N, X, U, XUR.data());
   double *dP = nullptr, *dBT = nullptr, *dXUR = nullptr, *dNZ = nullptr, *dKD = nullptr, *dXS = nullptr;
-  int* dbi = nullptr;
+  int *dbi = nullptr, *dnk = nullptr;
   tsat_tvlqr_stats* dst = nullptr;
   const size_t nNZ = Tn * (size_t)(N - 1) * 36, nKD = Tn * (size_t)(N - 1) * KDW, nXS = Tn * N * XUW;
   int rc = 0;
@@ -385,11 +386,16 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
   C(dP, P.data(), P.size() * 8); C(dBT, BT.data(), BT.size() * 8); C(dXUR, XUR.data(), XUR.size() * 8);
   if (noise) C(dNZ, noise, nNZ * 8);
   C(dbi, bi.data(), Tn * sizeof(int));
+  if (n_knots) {   // ragged batch: the slabs beyond a trajectory's own horizon stay zero
+    A((void**)&dnk, Tn * sizeof(int));
+    C(dnk, n_knots, Tn * sizeof(int));
+    if (!rc && (hipMemset(dKD, 0, nKD * 8) != hipSuccess || hipMemset(dXS, 0, nXS * 8) != hipSuccess)) rc = -10;
+  }
   if (!rc) {
     TvArgs<double> a;
     a.T = (int)T; a.N = N; a.n_tab = n_tab; a.lin_sq = o->linearize_dt_sq; a.min_steps = o->min_steps;
     a.us = o->u_scale; a.w_tol = o->w_tol; a.ang_tol = o->angle_tol;
-    a.P = dP; a.BT = dBT; a.bidx = dbi; a.XUR = dXUR; a.NZ = dNZ; a.KD = dKD; a.XS = dXS; a.stats = dst;
+    a.P = dP; a.BT = dBT; a.bidx = dbi; a.nk = dnk; a.XUR = dXUR; a.NZ = dNZ; a.KD = dKD; a.XS = dXS; a.stats = dst;
     const int cls = inertia_class(T, Jmat);
     auto kern = cls == 2 ? tsat_tvlqr_kernel<double, 2> : (cls == 1 ? tsat_tvlqr_kernel<double, 1> : tsat_tvlqr_kernel<double, 0>);
     hipLaunchKernelGGL(kern, dim3((unsigned)T), dim3(64), 0, h->stream, a);
@@ -400,7 +406,7 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
   if (!rc && hipMemcpy(KD.data(), dKD, nKD * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && hipMemcpy(stats, dst, Tn * sizeof(tsat_tvlqr_stats), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc) unpack_tv<double>(T, N, XS.data(), KD.data(), X_sim, U_sim, K_lqr);
-  void* fr[] = {dP, dBT, dXUR, dNZ, dKD, dXS, dbi, dst};
+  void* fr[] = {dP, dBT, dXUR, dNZ, dKD, dXS, dbi, dnk, dst};
   for (void* q : fr)
     if (q) (void)hipFree(q);
   if (rc) h->err = "device allocation, copy or launch failed in tsat_tvlqr_batch";

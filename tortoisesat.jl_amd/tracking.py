@@ -60,10 +60,12 @@ def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noi
         if noise.shape != (T, N - 1, 4, 9):
             raise ValueError("noise must be (T, N-1, 4, 9)")
     Xs = np.empty((T, N, 7)); Us = np.empty((T, N - 1, 3)); K = np.empty((T, N - 1, 6, 3))
+    nk = None if batch.n_knots is None else np.ascontiguousarray(batch.n_knots, dtype=np.int32)
     st = np.zeros(T, dtype=_abi.TVLQR_STATS_DTYPE)
     d = _abi.as_dp
     rc = lib.tsat_tvlqr_batch(solver._h, C.byref(o), T, batch.Btab.shape[0], d(X), d(U), d(batch.xf), d(batch.Btab),
                               _abi.as_ip(batch.btab_idx), d(batch.tau0), d(batch.dtau), d(batch.dt), d(batch.Jmat),
-                              d(Qd), d(Qfd), d(Rd), d(x0_sim), d(noise), d(Xs), d(Us), d(K), st.ctypes.data_as(C.c_void_p))
+                              d(Qd), d(Qfd), d(Rd), d(x0_sim), d(noise), d(Xs), d(Us), d(K), st.ctypes.data_as(C.c_void_p),
+                              _abi.as_ip(nk))
     solver._check(rc, "tsat_tvlqr_batch")
     return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)
