@@ -1,9 +1,12 @@
 # TortoiseHIP.jl — thin `ccall` shim over libtortoise_hip.so (include/tortoise_hip.h).
 #
-# Drop-in for the ONE hot call of the reference: `TrajectoryOptimization.solve!(sat, solver)`
-# (src/TortoiseSat.jl:199) and the loop body `solve(solver,U)` of src/monte_carlo.jl:196, for a batch of slews.
-# The host keeps igrf / kep_ECI / magnetic_simulation / eigen_axis_slew / Bryson weights in Julia exactly as the
-# reference scripts do and hands plain column-major arrays across the ABI (Julia's native layout — no copies).
+# Drop-in for the hot call of the reference: `TrajectoryOptimization.solve!(sat, solver)`
+# (src/TortoiseSat.jl:199) and the loop body `solve(solver,U)` of src/monte_carlo.jl:196, for a batch of slews —
+# plus the batched forms of the calls on either side of it: `magnetic_simulation` (src/magnetic_toolbox.jl:33-106),
+# `magnetic_gramian` + `condition_based_time` (:1-31), `attitude_simulation` with the slew-time statistic
+# (src/attitude_controller.jl:1-48, src/monte_carlo.jl:242-262) and the result files (src/monte_carlo.jl:334-343).
+# eigen_axis_slew / Bryson weights stay in Julia exactly as the reference scripts have them; plain column-major arrays
+# cross the ABI (Julia's native layout — no copies).
 #
 # NOTE: no Julia toolchain exists in the authoring image; this file is syntax-reviewed only (DESIGN.md §1).
 module TortoiseHIP
@@ -77,6 +80,7 @@ Base.@kwdef mutable struct BatchProblem
     Q::Matrix{Float64}; Qf::Matrix{Float64}; R::Matrix{Float64}
     u_min::Matrix{Float64}; u_max::Matrix{Float64}
     U0::Array{Float64,3}
+    n_knots::Vector{Int32} = Int32[]         # optional per-slew horizons length(t_total[i]) (src/monte_carlo.jl:145); empty = all N
     X::Array{Float64,3} = zeros(0, 0, 0)     # 7×N×T after solve!
     U::Array{Float64,3} = zeros(0, 0, 0)     # 3×(N-1)×T
     K::Array{Float64,4} = zeros(0, 0, 0, 0)  # 3×7×(N-1)×T
@@ -89,18 +93,129 @@ function solve!(p::BatchProblem, s::HIPSolver)
     o = s.opts; o.n_knots = N; o.n_tab = size(p.B_ECI, 2)
     p.X = zeros(7, N, T); p.U = zeros(3, N - 1, T); p.K = zeros(3, 7, N - 1, T)
     p.stats = Vector{Stats}(undef, T)
-    rc = ccall((:tsat_solve_batch, LIB), Cint,
-        (Ptr{Cvoid}, Ref{Options}, Int64, Int64,
-         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
-         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
-         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Stats}),
-        s.handle, o, T, size(p.B_ECI, 3),
-        p.x0, p.xf, p.B_ECI, p.btab_idx, p.tau0, p.dtau, p.dt, p.J,
-        p.Q, p.Qf, p.R, p.u_min, p.u_max, p.U0,
-        p.X, p.U, p.K, p.stats)
-    rc == 0 || error("tsat_solve_batch failed ($rc): " *
-                     unsafe_string(ccall((:tsat_last_error, LIB), Cstring, (Ptr{Cvoid},), s.handle)))
+    if isempty(p.n_knots)
+        rc = ccall((:tsat_solve_batch, LIB), Cint,
+            (Ptr{Cvoid}, Ref{Options}, Int64, Int64,
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Stats}),
+            s.handle, o, T, size(p.B_ECI, 3),
+            p.x0, p.xf, p.B_ECI, p.btab_idx, p.tau0, p.dtau, p.dt, p.J,
+            p.Q, p.Qf, p.R, p.u_min, p.u_max, p.U0,
+            p.X, p.U, p.K, p.stats)
+        check(s, rc, "tsat_solve_batch")
+    else   # variable horizons: the resident-batch calls, with tsat_batch_knots between upload and run
+        check(s, ccall((:tsat_batch_reserve, LIB), Cint, (Ptr{Cvoid}, Int64, Int32, Int32, Int64, Int32),
+                       s.handle, T, N, o.n_tab, size(p.B_ECI, 3), o.max_linesearch), "tsat_batch_reserve")
+        check(s, ccall((:tsat_batch_upload, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+            s.handle, p.x0, p.xf, p.B_ECI, p.btab_idx, p.tau0, p.dtau, p.dt, p.J, p.Q, p.Qf, p.R, p.u_min, p.u_max, p.U0),
+            "tsat_batch_upload")
+        check(s, ccall((:tsat_batch_knots, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}), s.handle, p.n_knots), "tsat_batch_knots")
+        check(s, ccall((:tsat_batch_run, LIB), Cint, (Ptr{Cvoid}, Ref{Options}, Ptr{Cfloat}), s.handle, o, C_NULL), "tsat_batch_run")
+        check(s, ccall((:tsat_batch_download, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Stats}),
+                       s.handle, p.X, p.U, p.K, p.stats), "tsat_batch_download")
+    end
     return p
+end
+
+check(s::HIPSolver, rc, what) = rc == 0 ? nothing :
+    error("$what failed ($rc): " * unsafe_string(ccall((:tsat_last_error, LIB), Cstring, (Ptr{Cvoid},), s.handle)))
+
+# ---------------------------------------------------------------------------------------------------------------
+# the callers on either side of the solve
+# ---------------------------------------------------------------------------------------------------------------
+# struct tsat_btable_options
+Base.@kwdef mutable struct BtableOptions
+    n_half::Int32 = 5000             # N, src/TortoiseSat.jl:61
+    reserved::Int32 = 0
+    mjd::Float64 = 58155.0           # MJD_0, src/TortoiseSat.jl:44
+    gm::Float64 = 3.986004418e5      # km^3/s^2, src/input_parameters.jl:26
+    r_igrf_km::Float64 = 6771.0      # alt + R_E, src/magnetic_toolbox.jl:44,81
+    date::Float64 = 2019.0           # src/magnetic_toolbox.jl:81
+end
+
+"""
+magnetic_simulation(s, A, t0, tf, N) — batched `magnetic_simulation(A[i,:], t0, tf[i], N, mag_field, GM, MJD_0)[1]`
+(src/magnetic_toolbox.jl:33-106). A :: 6×T Keplerian elements (the rows of the reference's `A`), t0, tf :: T.
+Returns B_ECI :: 3×2N×T (Tesla; last row zero as in the reference) and pos :: 3×(2N+1)×T (km).
+"""
+function magnetic_simulation(s::HIPSolver, A::Matrix{Float64}, t0::Vector{Float64}, tf::Vector{Float64}, N::Integer;
+                             opts::BtableOptions = BtableOptions())
+    T = size(A, 2); opts.n_half = N
+    B = zeros(3, 2N, T); pos = zeros(3, 2N + 1, T)
+    check(s, ccall((:tsat_btable_batch, LIB), Cint,
+        (Ptr{Cvoid}, Ref{BtableOptions}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        s.handle, opts, T, A, t0, tf, B, pos), "tsat_btable_batch")
+    return B, pos
+end
+
+"""
+condition_based_time(s, B, dt, cutoff) — batched `condition_based_time(magnetic_gramian(B_N, dt), cutoff)`
+(src/magnetic_toolbox.jl:1-31; call sites src/TortoiseSat.jl:73-82, src/monte_carlo.jl:137-140).
+B :: 3×n_rows×T. Returns the 1-based row index per orbit (0 = never below the cutoff) and the condition number there.
+"""
+function condition_based_time(s::HIPSolver, B::Array{Float64,3}, dt::Vector{Float64}, cutoff::Vector{Float64})
+    T = size(B, 3); idx = zeros(Int32, T); cnd = zeros(T)
+    check(s, ccall((:tsat_horizon_batch, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}),
+        s.handle, T, size(B, 2), B, dt, cutoff, idx, cnd), "tsat_horizon_batch")
+    return idx, cnd
+end
+
+# struct tsat_tvlqr_options / tsat_tvlqr_stats
+Base.@kwdef mutable struct TvlqrOptions
+    n_knots::Int32 = 0
+    n_tab::Int32 = 0
+    linearize_dt_sq::Int32 = 1       # `dt = S[end]^2`, src/attitude_controller.jl:137
+    min_steps::Int32 = 10            # src/monte_carlo.jl:251
+    u_scale::Float64 = 1e-2          # src/gain_simulator.jl:42
+    w_tol::Float64 = 0.05            # slew_limits, src/monte_carlo.jl:70-71
+    angle_tol::Float64 = 0.08727
+end
+struct TvlqrStats
+    slew_index::Int32; failed::Int32; slew_time::Float64; final_w_norm::Float64; final_angle::Float64
+end
+
+"""
+attitude_simulation(s, p, x0_lqr, Q_lqr, Qf_lqr, R_lqr; noise) — batched
+`attitude_simulation(f!, f_gains!, :rk4, X, U, dt, x0_lqr, t0, tf, Q_lqr, R_lqr, Qf_lqr)` (src/attitude_controller.jl:1-48)
+around the solved `p.X`, `p.U`, plus the slew-time / failure statistic of src/monte_carlo.jl:242-262.
+x0_lqr :: 7×T; Q_lqr, Qf_lqr :: 6×T and R_lqr :: 3×T diagonals; noise :: 9×4×(N-1)×T draws of `simulator`
+(gyro noise, attitude-noise rotation vector, field noise per RK4 stage; src/simulator.jl:5,10,22) or `nothing`.
+Returns X_sim 7×N×T, U_sim 3×(N-1)×T, K 3×6×(N-1)×T, stats.
+"""
+function attitude_simulation(s::HIPSolver, p::BatchProblem, x0_lqr::Matrix{Float64}, Q_lqr::Matrix{Float64},
+                             Qf_lqr::Matrix{Float64}, R_lqr::Matrix{Float64};
+                             noise::Union{Nothing,Array{Float64,4}} = nothing, opts::TvlqrOptions = TvlqrOptions())
+    T = size(p.x0, 2); N = p.N
+    opts.n_knots = N; opts.n_tab = size(p.B_ECI, 2)
+    Xs = zeros(7, N, T); Us = zeros(3, N - 1, T); K = zeros(3, 6, N - 1, T); st = Vector{TvlqrStats}(undef, T)
+    check(s, ccall((:tsat_tvlqr_batch, LIB), Cint,
+        (Ptr{Cvoid}, Ref{TvlqrOptions}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{TvlqrStats}, Ptr{Int32}),
+        s.handle, opts, T, size(p.B_ECI, 3), p.X, p.U, p.xf, p.B_ECI, p.btab_idx, p.tau0, p.dtau, p.dt, p.J,
+        Q_lqr, Qf_lqr, R_lqr, x0_lqr, noise === nothing ? C_NULL : noise, Xs, Us, K, st,
+        isempty(p.n_knots) ? C_NULL : p.n_knots), "tsat_tvlqr_batch")
+    return Xs, Us, K, st
+end
+
+"""
+write_results(dir, n, A, sim_states, sim_control_inputs, B_ECI_total, t_total) — the files of src/monte_carlo.jl:334-343
+(`{n}_A.h5` "A"; per trial `{n}_states_{i}.h5` "states", `{n}_control_{i}.h5` "control", `{n}_B_N_{i}.h5` "B_ECI",
+`{n}_t_total_{i}.h5` "t_total"). Needs HDF5.jl, as the reference does.
+"""
+function write_results(dir, n, A, sim_states, sim_control_inputs, B_ECI_total, t_total)
+    HDF5 = Base.require(Base.PkgId(Base.UUID("f67ccb44-e63f-5c2f-98bd-6dc0ccc4ba2f"), "HDF5"))
+    HDF5.h5write(joinpath(dir, "$(n)_A.h5"), "A", A)
+    for i in eachindex(sim_states)
+        HDF5.h5write(joinpath(dir, "$(n)_states_$(i).h5"), "states", sim_states[i])
+        HDF5.h5write(joinpath(dir, "$(n)_control_$(i).h5"), "control", sim_control_inputs[i])
+        HDF5.h5write(joinpath(dir, "$(n)_B_N_$(i).h5"), "B_ECI", B_ECI_total[i])
+        HDF5.h5write(joinpath(dir, "$(n)_t_total_$(i).h5"), "t_total", collect(t_total[i]))
+    end
 end
 
 end # module
