@@ -1,0 +1,24 @@
+#!/bin/bash
+# Developer tool, run on the GPU box from the repo root:  bash tools/collect_profiles.sh gpurun_out/final
+# Final-round measurement set: bench line, rocprofv3 kernel statistics of the same command, three separate PMC passes
+# (FETCH_SIZE, WRITE_SIZE, SQ counters; --kernel-trace only, as MI355X_MICROARCH.md prescribes), phase clocks of the
+# stamped build, the whole pipeline and the Monte-Carlo experiment. Summarise with tools/summarize_profiles.py.
+set -e -o pipefail
+OUT=$(realpath -m "${1:-gpurun_out/final}")
+ROOT=$(pwd)
+mkdir -p "$OUT"
+python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+cd /tmp && export TMPDIR=/tmp
+B="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $B > "$OUT/stats.json" 2> "$OUT/stats.err"
+B2="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --gather none"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- $B2 > /dev/null 2> "$OUT/pmc_fetch.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o run -- $B2 > /dev/null 2> "$OUT/pmc_write.err"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
+  --output-format csv -d "$OUT/pmc_sq" -o run -- $B2 > /dev/null 2> "$OUT/pmc_sq.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pipeline" -o run -- python3 $ROOT/tools/pipeline_timing.py > "$OUT/pipeline.log" 2> "$OUT/pipeline.err"
+cd "$ROOT"
+python3 tools/phase_profile.py > "$OUT/phase_clocks.txt" 2> "$OUT/phase_clocks.err"
+python3 tools/monte_carlo_timing.py 1024 1024 > "$OUT/monte_carlo.txt" 2> "$OUT/monte_carlo.err"
+python3 tools/large_batch.py > "$OUT/large_batch.txt" 2> "$OUT/large_batch.err"
+echo done

@@ -1,0 +1,59 @@
+"""Developer tool: turn what tools/collect_profiles.sh wrote into the committed summaries under profiles/.
+
+  python tools/summarize_profiles.py gpurun_out/final profiles/r01
+writes <dst>/bench_n1_final.json, kernel_stats_*.csv, phase/pipeline/Monte-Carlo text files and profiles/pmc_summary.json
+(per launch of the solve kernel; FETCH_SIZE / WRITE_SIZE are reported in KB by rocprofv3; the read figure is bracketed
+by the raw value and its double, see MI355X_MICROARCH.md on wide streaming reads)."""
+import csv, glob, json, os, shutil, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern), recursive=True)
+    if not g:
+        raise SystemExit(f"missing {pattern}")
+    return g[0]
+
+
+def counters(d):
+    acc, n = {}, {}
+    with open(one(f"{d}/**/*counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if "tsat_solve_kernel" not in r["Kernel_Name"]:
+                continue
+            k = r["Counter_Name"]
+            acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
+            n[k] = n.get(k, 0) + 1
+            kern = r["Kernel_Name"]
+    return {k: acc[k] / n[k] for k in acc}, kern
+
+
+shutil.copy(os.path.join(src, "bench_n1.json"), os.path.join(dst, "bench_n1_final.json"))
+shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(dst, "kernel_stats_bench_steps5_final.csv"))
+shutil.copy(one("pipeline/**/*kernel_stats.csv"), os.path.join(dst, "kernel_stats_pipeline.csv"))
+for a, b in (("phase_clocks.txt", "phase_clocks_final.txt"), ("pipeline.log", "pipeline_wall.txt"),
+             ("monte_carlo.txt", "monte_carlo_wall.txt"), ("large_batch.txt", "large_batch.txt"), ("stats.json", "bench_under_rocprof.json")):
+    with open(os.path.join(src, a)) as f:
+        keep = [ln for ln in f if not ln.startswith(("W20", "E20", "I20"))]
+    with open(os.path.join(dst, b), "w") as f:
+        f.writelines(keep)
+bench = json.loads(open(os.path.join(src, "bench_n1.json")).read().strip().splitlines()[-1])
+fe, kern = counters("pmc_fetch")
+wr, _ = counters("pmc_write")
+sq, _ = counters("pmc_sq")
+rd_raw, wr_b = fe["FETCH_SIZE"] * 1024.0, wr["WRITE_SIZE"] * 1024.0
+out = {
+    "kernel": kern, "workload": bench["config"]["workload"],
+    "FETCH_SIZE_KB": fe["FETCH_SIZE"], "WRITE_SIZE_KB": wr["WRITE_SIZE"],
+    "read_bytes_raw": rd_raw, "read_bytes_x2": 2 * rd_raw, "write_bytes": wr_b,
+    "hbm_bytes_per_launch": 2 * rd_raw + wr_b, "hbm_bytes_per_launch_lower": rd_raw + wr_b,
+    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+    "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE), mean per launch of the solve kernel; FETCH_SIZE doubled per "
+            "MI355X_MICROARCH.md (upper bracket; 8-byte accesses are uncalibrated, lower bracket = raw).",
+    "sq": sq,
+}
+with open(os.path.join(root, "profiles", "pmc_summary.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print(json.dumps(out, indent=1))
