@@ -38,6 +38,20 @@ def test_struct_layouts_and_defaults(pkg, ol):
     assert (o.integrator, o.max_outer, o.max_inner) == (3, 20, 50)     # src/TortoiseSat.jl:146,195-196
     assert o.u_scale == 1e-2                                           # src/DerivFunction.jl:37
     assert C.sizeof(abi.Stats) == 64 and abi.STATS_DTYPE.itemsize == 64
+    # the widened entry points: defaults are the reference's script constants, oracle and library agree field by field
+    t, tr = abi.TvlqrOptions(), ol.tvlqr_default_options()
+    lib.tsat_tvlqr_default_options(C.byref(t))
+    for name, _ in abi.TvlqrOptions._fields_:
+        assert getattr(t, name) == getattr(tr, name), name
+    assert (t.linearize_dt_sq, t.min_steps, t.w_tol, t.angle_tol) == (1, 10, 0.05, 0.08727)   # src/monte_carlo.jl:70-71,251
+    assert C.sizeof(abi.TvlqrOptions) == 40 and abi.TVLQR_STATS_DTYPE.itemsize == 32
+    bt, br = abi.BtableOptions(), ol.BtableOptions()
+    lib.tsat_btable_default_options(C.byref(bt))
+    ol.load().orc_btable_default_options(C.byref(br))
+    for name, _ in abi.BtableOptions._fields_:
+        assert getattr(bt, name) == getattr(br, name), name
+    assert (bt.n_half, bt.mjd, bt.r_igrf_km, bt.date) == (5000, 58155.0, 6771.0, 2019.0)      # src/TortoiseSat.jl:44,61
+    assert bt.gm == 3.986004418e14 * 1e-9 and C.sizeof(abi.BtableOptions) == 40
 
 
 def test_no_gpu_means_error_not_fallback(pkg):

@@ -188,6 +188,31 @@ def test_gpu_api_errors_are_codes_not_crashes(pkg, ol, solver):
         assert rc < 0 and lib.tsat_last_error(solver._h)
     assert lib.tsat_batch_reserve(solver._h, 0, 30, 30, 1, 20) < 0
     assert lib.tsat_batch_run(solver._h, C.byref(o), None) == 0      # the handle is still usable
+    # widened entry points: bad arguments come back as codes with a message, never as a launch
+    d, ip = abi.as_dp, abi.as_ip
+    bo = abi.BtableOptions()
+    lib.tsat_btable_default_options(C.byref(bo))
+    kep = np.array([[0.0, 6771.0, 96.6, 10.0, 0.0, 20.0]]); t0 = np.zeros(1); tf = np.full(1, 60.0)
+    B = np.zeros((1, 2 * 8, 3))
+    for field, bad in (("date", 2020.0), ("date", 2014.9), ("n_half", 0)):
+        b2 = abi.BtableOptions.from_buffer_copy(bo)
+        b2.n_half = 8
+        setattr(b2, field, bad)
+        assert lib.tsat_btable_batch(solver._h, C.byref(b2), 1, d(kep), d(t0), d(tf), d(B), None) < 0
+        assert lib.tsat_last_error(solver._h)
+    bo.n_half = 8
+    for bad_kep, bad_tf in ((np.array([[1.0, 6771.0, 96.6, 0, 0, 0]]), tf), (np.array([[0.0, -1.0, 96.6, 0, 0, 0]]), tf), (kep, np.zeros(1))):
+        assert lib.tsat_btable_batch(solver._h, C.byref(bo), 1, d(np.ascontiguousarray(bad_kep, dtype=np.float64)), d(t0), d(bad_tf), d(B), None) < 0
+    assert lib.tsat_btable_batch(solver._h, C.byref(bo), 1, d(kep), d(t0), d(tf), d(B), None) == 0
+    assert lib.tsat_horizon_batch(solver._h, 1, 0, d(B), d(t0), d(tf), ip(np.zeros(1, np.int32)), None) < 0
+    res = solver.download(want_K=False)
+    Qd, Qfd, Rd = pkg.tracking.tvlqr_weights(b.T)
+    b.n_knots = np.array([30, 31], dtype=np.int32)                    # beyond the batch stride
+    with pytest.raises(RuntimeError):
+        pkg.tracking.attitude_simulation(solver, b, res["X"], res["U"], b.x0, Qd, Qfd, Rd)
+    b.n_knots = np.array([30, 1], dtype=np.int32)
+    with pytest.raises(RuntimeError):
+        pkg.tracking.attitude_simulation(solver, b, res["X"], res["U"], b.x0, Qd, Qfd, Rd)
 
 
 def test_gpu_one_call_abi_entry(pkg, ol, solver):

@@ -97,8 +97,13 @@ class ResultGather:
     def gather(self):
         if self.mode == "none":
             return None
+        import torch
         import torch.distributed as dist
 
+        if self.collective:
+            # the previous step's all-gather (asynchronous, it overlaps the solve that ran since) must have drained
+            # before its source buffers are overwritten by this export
+            torch.cuda.current_stream().synchronize()
         self.solver.export_device(self.X.data_ptr() if self.X is not None else None,
                                   self.U.data_ptr() if self.U is not None else None,
                                   None, self.stats.data_ptr())
