@@ -214,6 +214,25 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
                       const int32_t* n_knots);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Receding-horizon re-solve on the RESIDENT batch (BASELINE.json configs[4]). NOT in the reference —
+ * it tracks its plan with TVLQR (src/attitude_controller.jl:1-48); defined here as: n_steps times
+ *   1. solve the horizon from the current x0 with the current initial controls, budget and options of `o`
+ *      (exactly tsat_batch_run);
+ *   2. record x_t = x0 and u_t = U[0];
+ *   3. advance the noise-free plant one step with u_t: rk3 or rk4 (plant_integrator 3 | 4) of the model dynamics
+ *      (src/DerivFunction.jl:1-48) over dt, table rows at the current table time;
+ *   4. warm start of the next solve = the plan shifted by one knot, last control repeated; tau0 += dtau.
+ * Nothing returns to the host between steps. Afterwards the resident batch holds the advanced x0 / tau0 / warm start
+ * and the last plan (tsat_batch_download); a further call continues the simulation.
+ *   X_hist 7 x (n_steps+1) x T   states x_0 .. x_{n_steps}
+ *   U_hist 3 x n_steps x T       applied controls
+ *   stats_last T (may be NULL)   statistics of the last solve
+ *   solve_ms (may be NULL)       device time of the whole loop
+ * ------------------------------------------------------------------------------------------------------------ */
+int  tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t plant_integrator,
+                  double* X_hist, double* U_hist, tsat_stats* stats_last, float* solve_ms);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Horizon selection (the caller right before the solve): cumulative magnetic Gramian of a field table and the first
  * row at which its condition number drops below `cutoff`.
  *   magnetic_gramian(B_N, dt)          src/magnetic_toolbox.jl:1-12   G_1 = hat(B_1)hat(B_1)', G_i = G_{i-1} + hat(B_i)hat(B_i)' dt

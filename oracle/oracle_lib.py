@@ -152,6 +152,29 @@ def solve_batch(batch, opts, nthreads=1, want_K=True, trace_rows=0):
     return dict(X=X, U=U, K=K, stats=stats, trace=trace)
 
 
+def mpc_batch(batch, opts, n_steps, plant_integrator=4, nthreads=1):
+    """Oracle receding-horizon loop (see tsat_mpc_run). Returns dict(X_hist (T,n_steps+1,7), U_hist (T,n_steps,3),
+    stats (last solve), X, U (last plan))."""
+    lib = load()
+    T, N = batch.T, batch.N
+    o = opts.copy()
+    o.n_knots, o.n_tab = N, batch.n_tab
+    Xh = np.zeros((T, n_steps + 1, 7)); Uh = np.zeros((T, n_steps, 3))
+    X = np.zeros((T, N, 7)); U = np.zeros((T, N - 1, 3))
+    stats = np.zeros(T, dtype=STATS_DTYPE)
+    d = lambda a: a.ctypes.data_as(_dp)
+    rc = lib.orc_mpc_batch(
+        C.byref(o), C.c_int64(T), C.c_int64(batch.Btab.shape[0]), d(batch.x0), d(batch.xf), d(batch.Btab),
+        batch.btab_idx.ctypes.data_as(C.POINTER(C.c_int32)), d(batch.tau0), d(batch.dtau), d(batch.dt),
+        d(batch.Jmat), d(batch.Qd), d(batch.Qfd), d(batch.Rd), d(batch.ulo), d(batch.uhi), d(batch.U0),
+        C.c_int32(n_steps), C.c_int32(plant_integrator), d(Xh), d(Uh), stats.ctypes.data_as(C.c_void_p), d(X), d(U),
+        C.c_int(nthreads),
+        None if batch.n_knots is None else np.ascontiguousarray(batch.n_knots, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise RuntimeError(f"orc_mpc_batch failed rc={rc}")
+    return dict(X_hist=Xh, U_hist=Uh, stats=stats, X=X, U=U)
+
+
 TvlqrOptions, TVLQR_STATS_DTYPE = _abi.TvlqrOptions, _abi.TVLQR_STATS_DTYPE
 
 

@@ -810,6 +810,60 @@ int orc_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab, const doub
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Receding-horizon re-solve (BASELINE.json configs[4]; not in the reference — see tsat_mpc_run in the header): per
+// trajectory, n_steps times { solve from the current state with the current warm start; record x_t, u_t = U[0];
+// plant step with rk3/rk4 of the model dynamics; shift the plan by one knot (last control repeated); tau0 += dtau }.
+// X_last / U_last (may be NULL) receive the plan of the last solve, laid out as orc_solve_batch's X / U.
+// ------------------------------------------------------------------------------------------------------------
+int orc_mpc_batch(const tsat_options* o, int64_t T, int64_t n_btab, const double* x0, const double* xf,
+                  const double* Btab, const int32_t* btab_idx, const double* tau0, const double* dtau,
+                  const double* dt, const double* Jmat, const double* Qd, const double* Qfd, const double* Rd,
+                  const double* ulo, const double* uhi, const double* U0, int32_t n_steps, int32_t plant_integrator,
+                  double* X_hist, double* U_hist, tsat_stats* stats_last, double* X_last, double* U_last, int nthreads,
+                  const int32_t* n_knots) {
+  if (!o || o->n_knots < 2 || o->n_tab < 1 || (o->integrator != 3 && o->integrator != 4)) return -1;
+  if (n_steps < 1 || (plant_integrator != 3 && plant_integrator != 4)) return -1;
+  if (!btab_idx && n_btab != T) return -1;
+  const int NS = o->n_knots;
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int64_t t = 0; t < T; ++t) {
+    Traj tr = make_traj(o, t, x0, xf, Btab, btab_idx, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi);
+    if (n_knots) tr.N = n_knots[t];
+    const int N = tr.N;
+    double xc[7];
+    std::vector<double> Uw(U0 + (size_t)3 * (NS - 1) * t, U0 + (size_t)3 * (NS - 1) * (t + 1)), X((size_t)7 * NS, 0.0),
+        U((size_t)3 * (NS - 1), 0.0);
+    for (int i = 0; i < 7; ++i) xc[i] = x0[7 * t + i];
+    tsat_stats st;
+    for (int s = 0; s < n_steps; ++s) {
+      tr.x0 = xc;
+      solve_one(tr, *o, Uw.data(), X.data(), U.data(), nullptr, &st, nullptr, 0);
+      double* hx = X_hist + ((size_t)t * (n_steps + 1) + s) * 7;
+      double* hu = U_hist + ((size_t)t * n_steps + s) * 3;
+      for (int i = 0; i < 7; ++i) hx[i] = xc[i];
+      for (int c = 0; c < 3; ++c) hu[c] = U[c];
+      double xn[7];
+      rk_step<double>(plant_integrator, xc, U.data(), brow(tr, 0, 0.0), brow(tr, 0, 0.5), brow(tr, 0, 1.0), tr.dt, tr.ph, xn);
+      for (int k = 0; k < N - 1; ++k) {
+        const int src = (k + 1 < N - 1) ? k + 1 : N - 2;
+        for (int c = 0; c < 3; ++c) Uw[(size_t)3 * k + c] = U[(size_t)3 * src + c];
+      }
+      for (int i = 0; i < 7; ++i) xc[i] = xn[i];
+      if (s == n_steps - 1)
+        for (int i = 0; i < 7; ++i) hx[7 + i] = xn[i];
+      tr.tau0 = tr.tau0 + tr.dtau;
+    }
+    if (stats_last) stats_last[t] = st;
+    if (X_last) std::memcpy(X_last + (size_t)7 * NS * t, X.data(), sizeof(double) * 7 * NS);
+    if (U_last) std::memcpy(U_last + (size_t)3 * (NS - 1) * t, U.data(), sizeof(double) * 3 * (NS - 1));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Closed-loop TVLQR tracking: literal restatement of attitude_simulation / attitude_lqr
 // (src/attitude_controller.jl:1-119), the plants (src/simulator.jl, src/gain_simulator.jl) and the slew-time statistic
 // (src/monte_carlo.jl:242-262). Randomness is an input: `noise` carries the values `simulator` would draw.

@@ -81,6 +81,23 @@ class Emu:
         return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)
 
 
+    def mpc(self, batch, opts, n_steps, plant_integrator=4):
+        T, N = batch.T, batch.N
+        o = opts.copy()
+        o.n_knots, o.n_tab = N, batch.n_tab
+        Xh = np.zeros((T, n_steps + 1, 7)); Uh = np.zeros((T, n_steps, 3))
+        X = np.zeros((T, N, 7)); U = np.zeros((T, N - 1, 3))
+        st = np.zeros(T, dtype=self.abi.STATS_DTYPE)
+        d = self.abi.as_dp
+        rc = self.lib.emu_mpc_batch(C.byref(o), C.c_int64(T), C.c_int64(batch.Btab.shape[0]), d(batch.x0), d(batch.xf), d(batch.Btab),
+                                    self.abi.as_ip(batch.btab_idx), d(batch.tau0), d(batch.dtau), d(batch.dt), d(batch.Jmat),
+                                    d(batch.Qd), d(batch.Qfd), d(batch.Rd), d(batch.ulo), d(batch.uhi), d(batch.U0),
+                                    C.c_int32(n_steps), C.c_int32(plant_integrator), d(Xh), d(Uh), st.ctypes.data_as(C.c_void_p),
+                                    d(X), d(U), None if batch.n_knots is None else self.abi.as_ip(np.ascontiguousarray(batch.n_knots, dtype=np.int32)))
+        if rc != 0:
+            raise RuntimeError(f"emu_mpc_batch rc={rc}")
+        return dict(X_hist=Xh, U_hist=Uh, stats=st, X=X, U=U)
+
     def btable(self, kep, t0, tf, N, mjd=58155.0, gm=3.986004418e5, r_igrf_km=6771.0, date=2019.0):
         kep = np.ascontiguousarray(kep, dtype=np.float64)
         T = kep.shape[0]

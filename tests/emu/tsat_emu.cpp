@@ -73,6 +73,64 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
 }
 
 template <int DIAGJ>
+static void run_mpc_block(const MpcArgs<double>& a, int traj) {
+  std::vector<double> lds(LDS_REALS, 0.0);
+  std::barrier<> bar(WAVE);
+  tsat_emu::g_bar = &bar;
+  tsat_emu::g_lds = lds.data();
+  std::vector<std::thread> th;
+  for (int l = 0; l < WAVE; ++l)
+    th.emplace_back([&, l]() {
+      tsat_emu::g_lane = l;
+      mpc_advance_trajectory<double, DIAGJ>(a, traj);
+    });
+  for (auto& t : th) t.join();
+}
+
+// the loop of tsat_mpc_run: solve blocks, then advance blocks, n_steps times, on emulated device buffers
+extern "C" int emu_mpc_batch(const tsat_options* o, int64_t T, int64_t n_btab, const double* x0, const double* xf,
+                             const double* Btab, const int32_t* btab_idx, const double* tau0, const double* dtau,
+                             const double* dt, const double* Jmat, const double* Qd, const double* Qfd,
+                             const double* Rd, const double* ulo, const double* uhi, const double* U0, int32_t n_steps,
+                             int32_t plant_integrator, double* X_hist, double* U_hist, tsat_stats* stats_last, double* X_last,
+                             double* U_last, const int32_t* n_knots) {
+  const int N = o->n_knots, n_tab = o->n_tab;
+  if (!check_options(*o, N, n_tab, o->max_linesearch).empty()) return -1;
+  const int max_ls = o->max_linesearch < NSTORE ? o->max_linesearch : NSTORE;
+  std::vector<double> P((size_t)T * PSTRIDE), BT((size_t)n_btab * n_tab * 4), U0w(U0, U0 + (size_t)T * (N - 1) * 3);
+  std::vector<int> bidx(T);
+  pack_params<double>(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, P.data());
+  pack_btab<double>(n_btab, n_tab, Btab, BT.data());
+  for (int64_t t = 0; t < T; ++t) bidx[t] = btab_idx ? btab_idx[t] : (int)t;
+  std::vector<double> XU((size_t)T * N * XUW, 0.0), KD((size_t)T * (N - 1) * KDW, 0.0),
+      LAM((size_t)T * (N - 1) * LMW, 0.0), CAND((size_t)T * max_ls * N * XUW, 0.0);
+  KArgs<double> a;
+  a.T = (int)T; a.N = N; a.n_tab = n_tab; a.max_ls = max_ls; a.opt = *o;
+  a.P = P.data(); a.BT = BT.data(); a.bidx = bidx.data(); a.nk = n_knots; a.U0 = U0w.data();
+  a.XU = XU.data(); a.KD = KD.data(); a.LAM = LAM.data(); a.CAND = CAND.data();
+  a.stats = stats_last; a.trace = nullptr; a.trace_rows = 0;
+  MpcArgs<double> m;
+  m.T = (int)T; m.N = N; m.n_tab = n_tab; m.plant_integ = plant_integrator; m.n_steps = n_steps; m.us = o->u_scale;
+  m.P = P.data(); m.BT = BT.data(); m.bidx = bidx.data(); m.nk = n_knots; m.XU = XU.data(); m.U0 = U0w.data();
+  m.HX = X_hist; m.HU = U_hist;
+  const int cls = inertia_class(T, Jmat);
+  using blk_t = void (*)(const KArgs<double>&, int);
+  static const blk_t variants[2][3][2] = {
+      {{run_block<3, 0, 0>, run_block<3, 0, 1>}, {run_block<3, 1, 0>, run_block<3, 1, 1>}, {run_block<3, 2, 0>, run_block<3, 2, 1>}},
+      {{run_block<4, 0, 0>, run_block<4, 0, 1>}, {run_block<4, 1, 0>, run_block<4, 1, 1>}, {run_block<4, 2, 0>, run_block<4, 2, 1>}}};
+  const blk_t blk = variants[o->integrator == 4 ? 1 : 0][cls][o->error_state ? 1 : 0];
+  for (int s = 0; s < n_steps; ++s) {
+    for (int t = 0; t < (int)T; ++t) blk(a, t);
+    m.step = s;
+    for (int t = 0; t < (int)T; ++t) {
+      if (cls == 2) run_mpc_block<2>(m, t); else if (cls == 1) run_mpc_block<1>(m, t); else run_mpc_block<0>(m, t);
+    }
+  }
+  for (int64_t e = 0; e < T * (int64_t)N; ++e) export_record<double>(e, N, n_knots, XU.data(), KD.data(), X_last, U_last, nullptr);
+  return 0;
+}
+
+template <int DIAGJ>
 static void run_tv_block(const TvArgs<double>& a, int traj) {
   std::vector<double> lds(LDS_REALS, 0.0);
   std::barrier<> bar(WAVE);

@@ -1471,6 +1471,62 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
 }
 
 // ==================================================================================================
+// Receding-horizon step (BASELINE.json configs[4]; NOT in the reference, which tracks its plan with
+// TVLQR): after a solve of the resident batch, record (x_t, u_t = U[0]), advance the noise-free plant one step with
+// the applied control (rk3 / rk4 of the model dynamics), make the plan shifted by one knot (last control repeated)
+// the next warm start and move the table clock on by one knot. Lanes = knots for the shift; lane 0 steps the plant.
+// ==================================================================================================
+template <typename real>
+struct MpcArgs {
+  int T, N, n_tab, plant_integ, step, n_steps;
+  real us;
+  real* P;            // [T][PSTRIDE]   x0 and tau0 are advanced in place
+  const real* BT;     // [n_btab][n_tab][4]
+  const int* bidx;    // [T]
+  const int* nk;      // [T] or null
+  const real* XU;     // [T][N][10]     the plan just solved
+  real* U0;           // [T][N-1][3]    next warm start
+  real* HX;           // [T][n_steps+1][7]
+  real* HU;           // [T][n_steps][3]
+};
+
+template <typename real, int DIAGJ>
+TSAT_DEV void mpc_advance_trajectory(const MpcArgs<real>& a, int traj) {
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE();
+  const int NS = a.N;
+  const int N = a.nk ? a.nk[traj] : a.N;
+  TSAT_GLOBAL real* Pg = (TSAT_GLOBAL real*)(a.P + (size_t)traj * PSTRIDE);
+  stage_traj<real>(Pg, a.us);
+  TSAT_SYNC();
+  const Traj<real> tr = load_traj<real>(N, a.n_tab, (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[traj] * a.n_tab * 4));
+  const TSAT_GLOBAL real* XUg = (const TSAT_GLOBAL real*)(a.XU + (size_t)traj * NS * XUW);
+  TSAT_GLOBAL real* U0g = (TSAT_GLOBAL real*)(a.U0 + (size_t)traj * (NS - 1) * 3);
+  for (int k = lane; k < N - 1; k += WAVE) {
+    const int src = (k + 1 < N - 1) ? k + 1 : N - 2;
+    for (int c = 0; c < 3; ++c) U0g[(size_t)k * 3 + c] = XUg[(size_t)src * XUW + 7 + c];
+  }
+  if (lane == 0) {
+    real x[7], u[3], xn[7], b0[3], b1[3], b2[3];
+    for (int i = 0; i < 7; ++i) x[i] = lds[L_TR + P_X0 + i];
+    for (int c = 0; c < 3; ++c) u[c] = XUg[7 + c];
+    const TSAT_GLOBAL real* p0 = tr.bt + (size_t)brow_index(tr, 0, 0.0) * 4;
+    const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, 0, 0.5) * 4;
+    const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, 0, 1.0) * 4;
+    for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
+    if (a.plant_integ == 4) rk_step<real, 4, DIAGJ, 0>(tr, x, u, b0, b1, b2, xn);
+    else rk_step<real, 3, DIAGJ, 0>(tr, x, u, b0, b1, b2, xn);
+    real* hx = a.HX + ((size_t)traj * (a.n_steps + 1) + a.step) * 7;
+    real* hu = a.HU + ((size_t)traj * a.n_steps + a.step) * 3;
+    for (int i = 0; i < 7; ++i) { hx[i] = x[i]; Pg[P_X0 + i] = xn[i]; }
+    for (int c = 0; c < 3; ++c) hu[c] = u[c];
+    if (a.step == a.n_steps - 1)
+      for (int i = 0; i < 7; ++i) hx[7 + i] = xn[i];
+    Pg[P_TAU0] = (real)(tr.tau0 + tr.dtau);
+  }
+}
+
+// ==================================================================================================
 // Horizon selection: magnetic_gramian + condition_based_time (src/magnetic_toolbox.jl:1-31) for a
 // batch. One trajectory per wavefront, lanes = table rows: each 64-row block is an inclusive wave scan of the six
 // unique Gramian entries plus the carry of the previous blocks; every lane then has ITS prefix Gramian and evaluates

@@ -29,6 +29,13 @@ __global__ __launch_bounds__(64) void tsat_tvlqr_kernel(TvArgs<real> a) {
   tvlqr_trajectory<real, DIAGJ>(a, traj);
 }
 
+template <typename real, int DIAGJ>
+__global__ __launch_bounds__(64) void tsat_mpc_advance_kernel(MpcArgs<real> a) {
+  const int traj = blockIdx.x;
+  if (traj >= a.T) return;
+  mpc_advance_trajectory<real, DIAGJ>(a, traj);
+}
+
 template <typename real>
 __global__ __launch_bounds__(64) void tsat_btable_kernel(BtArgs<real> a) {
   const int traj = blockIdx.x;
@@ -244,28 +251,39 @@ int tsat_batch_knots(tsat_handle* h, const int32_t* n_knots) {
   return 0;
 }
 
-int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
-  if (!h || !o) return -1;
-  if (!h->uploaded) return fail(h, -1, "tsat_batch_upload has not been called");
-  const std::string why = check_options(*o, h->N, h->n_tab, h->max_ls);
-  if (!why.empty()) return fail(h, -1, why);
-  TSAT_HIP(h, hipSetDevice(h->dev));
-  KArgs<double> a;
-  a.T = (int)h->T; a.N = h->N; a.n_tab = h->n_tab; a.max_ls = h->max_ls < NSTORE ? h->max_ls : NSTORE; a.opt = *o;
-  a.P = h->P; a.BT = h->BT; a.bidx = h->bidx; a.nk = h->ragged ? h->nk : nullptr; a.U0 = h->U0;
-  a.XU = h->XU; a.KD = h->KD; a.LAM = h->LAM; a.CAND = h->CAND;
-  a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
-  // LDS is a static module-level array (tsat_device.hpp): nothing dynamic to request at launch
-  // kernel variant: integrator x inertia class (full / diagonal / isotropic) x error-state mode
-  using kern_t = void (*)(KArgs<double>);
-  static const kern_t variants[2][3][2] = {
+namespace {
+using solve_kern_t = void (*)(KArgs<double>);
+// kernel variant: integrator x inertia class (full / diagonal / isotropic) x error-state mode. LDS is a static
+// module-level array (tsat_device.hpp): nothing dynamic to request at launch.
+solve_kern_t solve_variant(const tsat_handle* h, const tsat_options* o) {
+  static const solve_kern_t variants[2][3][2] = {
       {{tsat_solve_kernel<double, 3, 0, 0>, tsat_solve_kernel<double, 3, 0, 1>},
        {tsat_solve_kernel<double, 3, 1, 0>, tsat_solve_kernel<double, 3, 1, 1>},
        {tsat_solve_kernel<double, 3, 2, 0>, tsat_solve_kernel<double, 3, 2, 1>}},
       {{tsat_solve_kernel<double, 4, 0, 0>, tsat_solve_kernel<double, 4, 0, 1>},
        {tsat_solve_kernel<double, 4, 1, 0>, tsat_solve_kernel<double, 4, 1, 1>},
        {tsat_solve_kernel<double, 4, 2, 0>, tsat_solve_kernel<double, 4, 2, 1>}}};
-  const kern_t kern = variants[o->integrator == 4 ? 1 : 0][h->inertia_class][o->error_state ? 1 : 0];
+  return variants[o->integrator == 4 ? 1 : 0][h->inertia_class][o->error_state ? 1 : 0];
+}
+
+KArgs<double> solve_args(const tsat_handle* h, const tsat_options* o) {
+  KArgs<double> a;
+  a.T = (int)h->T; a.N = h->N; a.n_tab = h->n_tab; a.max_ls = h->max_ls < NSTORE ? h->max_ls : NSTORE; a.opt = *o;
+  a.P = h->P; a.BT = h->BT; a.bidx = h->bidx; a.nk = h->ragged ? h->nk : nullptr; a.U0 = h->U0;
+  a.XU = h->XU; a.KD = h->KD; a.LAM = h->LAM; a.CAND = h->CAND;
+  a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
+  return a;
+}
+}  // namespace
+
+int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
+  if (!h || !o) return -1;
+  if (!h->uploaded) return fail(h, -1, "tsat_batch_upload has not been called");
+  const std::string why = check_options(*o, h->N, h->n_tab, h->max_ls);
+  if (!why.empty()) return fail(h, -1, why);
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  const KArgs<double> a = solve_args(h, o);
+  const solve_kern_t kern = solve_variant(h, o);
   if (h->trace) TSAT_HIP(h, hipMemsetAsync(h->trace, 0, (size_t)h->T * h->trace_rows * 8 * sizeof(double), h->stream));
   TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(kern, dim3((unsigned)h->T), dim3(64), 0, h->stream, a);
@@ -273,6 +291,50 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
   TSAT_HIP(h, hipEventRecord(h->ev1, h->stream));
   TSAT_HIP(h, hipStreamSynchronize(h->stream));
   if (kernel_ms) TSAT_HIP(h, hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
+  h->solved = true;
+  return 0;
+}
+
+int tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t plant_integrator, double* X_hist,
+                 double* U_hist, tsat_stats* stats_last, float* solve_ms) {
+  if (!h || !o) return -1;
+  if (!h->uploaded) return fail(h, -1, "tsat_batch_upload has not been called");
+  const std::string why = check_options(*o, h->N, h->n_tab, h->max_ls);
+  if (!why.empty()) return fail(h, -1, why);
+  if (n_steps < 1) return fail(h, -1, "n_steps must be >= 1");
+  if (plant_integrator != 3 && plant_integrator != 4) return fail(h, -1, "plant_integrator must be 3 (rk3) or 4 (rk4)");
+  if (!X_hist || !U_hist) return fail(h, -1, "null array");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  const size_t T = (size_t)h->T, nX = T * ((size_t)n_steps + 1) * 7, nU = T * (size_t)n_steps * 3;
+  double *dHX = nullptr, *dHU = nullptr;
+  if (hipMalloc((void**)&dHX, nX * 8) != hipSuccess || hipMalloc((void**)&dHU, nU * 8) != hipSuccess) {
+    if (dHX) (void)hipFree(dHX);
+    return fail(h, -10, "device allocation failed in tsat_mpc_run");
+  }
+  const KArgs<double> a = solve_args(h, o);
+  const solve_kern_t kern = solve_variant(h, o);
+  MpcArgs<double> m;
+  m.T = (int)h->T; m.N = h->N; m.n_tab = h->n_tab; m.plant_integ = plant_integrator; m.n_steps = n_steps; m.us = o->u_scale;
+  m.P = h->P; m.BT = h->BT; m.bidx = h->bidx; m.nk = h->ragged ? h->nk : nullptr; m.XU = h->XU; m.U0 = h->U0;
+  m.HX = dHX; m.HU = dHU;
+  auto adv = h->inertia_class == 2 ? tsat_mpc_advance_kernel<double, 2>
+                                   : (h->inertia_class == 1 ? tsat_mpc_advance_kernel<double, 1> : tsat_mpc_advance_kernel<double, 0>);
+  int rc = 0;
+  if (hipEventRecord(h->ev0, h->stream) != hipSuccess) rc = -10;
+  for (int s = 0; s < n_steps && !rc; ++s) {   // 2 n_steps launches queued back to back; the stream orders them
+    hipLaunchKernelGGL(kern, dim3((unsigned)h->T), dim3(64), 0, h->stream, a);
+    m.step = s;
+    hipLaunchKernelGGL(adv, dim3((unsigned)h->T), dim3(64), 0, h->stream, m);
+    if (hipGetLastError() != hipSuccess) rc = -10;
+  }
+  if (!rc && (hipEventRecord(h->ev1, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)) rc = -10;
+  if (!rc && solve_ms && hipEventElapsedTime(solve_ms, h->ev0, h->ev1) != hipSuccess) rc = -10;
+  if (!rc && hipMemcpy(X_hist, dHX, nX * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && hipMemcpy(U_hist, dHU, nU * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && stats_last && hipMemcpy(stats_last, h->stats, T * sizeof(tsat_stats), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  (void)hipFree(dHX);
+  (void)hipFree(dHU);
+  if (rc) return fail(h, rc, "launch or copy failed in tsat_mpc_run");
   h->solved = true;
   return 0;
 }
