@@ -203,6 +203,28 @@ function attitude_simulation(s::HIPSolver, p::BatchProblem, x0_lqr::Matrix{Float
 end
 
 """
+receding_horizon!(s, p, n_steps; plant_integrator = 4) — `tsat_mpc_run` on the batch `p` (uploaded here): re-solve the
+horizon every control step with the budget of `s.opts`, apply U[:,1] to the noise-free plant, shift the plan.
+No reference equivalent (BASELINE.json configs[4]). Returns X_hist 7×(n_steps+1)×T, U_hist 3×n_steps×T.
+"""
+function receding_horizon!(s::HIPSolver, p::BatchProblem, n_steps::Integer; plant_integrator::Integer = 4)
+    T = size(p.x0, 2); N = p.N
+    o = s.opts; o.n_knots = N; o.n_tab = size(p.B_ECI, 2)
+    check(s, ccall((:tsat_batch_reserve, LIB), Cint, (Ptr{Cvoid}, Int64, Int32, Int32, Int64, Int32),
+                   s.handle, T, N, o.n_tab, size(p.B_ECI, 3), o.max_linesearch), "tsat_batch_reserve")
+    check(s, ccall((:tsat_batch_upload, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        s.handle, p.x0, p.xf, p.B_ECI, p.btab_idx, p.tau0, p.dtau, p.dt, p.J, p.Q, p.Qf, p.R, p.u_min, p.u_max, p.U0),
+        "tsat_batch_upload")
+    isempty(p.n_knots) || check(s, ccall((:tsat_batch_knots, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}), s.handle, p.n_knots), "tsat_batch_knots")
+    Xh = zeros(7, n_steps + 1, T); Uh = zeros(3, n_steps, T)
+    check(s, ccall((:tsat_mpc_run, LIB), Cint, (Ptr{Cvoid}, Ref{Options}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Stats}, Ptr{Cfloat}),
+                   s.handle, o, n_steps, plant_integrator, Xh, Uh, C_NULL, C_NULL), "tsat_mpc_run")
+    return Xh, Uh
+end
+
+"""
 write_results(dir, n, A, sim_states, sim_control_inputs, B_ECI_total, t_total) — the files of src/monte_carlo.jl:334-343
 (`{n}_A.h5` "A"; per trial `{n}_states_{i}.h5` "states", `{n}_control_{i}.h5` "control", `{n}_B_N_{i}.h5` "B_ECI",
 `{n}_t_total_{i}.h5` "t_total"). Needs HDF5.jl, as the reference does.

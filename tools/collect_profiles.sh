@@ -21,4 +21,5 @@ cd "$ROOT"
 python3 tools/phase_profile.py > "$OUT/phase_clocks.txt" 2> "$OUT/phase_clocks.err"
 python3 tools/monte_carlo_timing.py 1024 1024 > "$OUT/monte_carlo.txt" 2> "$OUT/monte_carlo.err"
 python3 tools/large_batch.py > "$OUT/large_batch.txt" 2> "$OUT/large_batch.err"
+{ python3 tools/mpc_timing.py 512 500; python3 tools/mpc_timing.py 4096 200; } > "$OUT/mpc_timing.txt" 2> "$OUT/mpc_timing.err"
 echo done

@@ -34,7 +34,7 @@ shutil.copy(os.path.join(src, "bench_n1.json"), os.path.join(dst, "bench_n1_fina
 shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(dst, "kernel_stats_bench_steps5_final.csv"))
 shutil.copy(one("pipeline/**/*kernel_stats.csv"), os.path.join(dst, "kernel_stats_pipeline.csv"))
 for a, b in (("phase_clocks.txt", "phase_clocks_final.txt"), ("pipeline.log", "pipeline_wall.txt"),
-             ("monte_carlo.txt", "monte_carlo_wall.txt"), ("large_batch.txt", "large_batch.txt"), ("stats.json", "bench_under_rocprof.json")):
+             ("monte_carlo.txt", "monte_carlo_wall.txt"), ("large_batch.txt", "large_batch.txt"), ("mpc_timing.txt", "mpc_timing.txt"), ("stats.json", "bench_under_rocprof.json")):
     with open(os.path.join(src, a)) as f:
         keep = [ln for ln in f if not ln.startswith(("W20", "E20", "I20"))]
     with open(os.path.join(dst, b), "w") as f:
