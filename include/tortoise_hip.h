@@ -178,7 +178,22 @@ typedef struct tsat_tvlqr_options {
   double  u_scale;          /* 1e-2: `u/100` (src/gain_simulator.jl:42)                                       */
   double  w_tol;            /* 0.05 rad/s   (src/monte_carlo.jl:70)                                           */
   double  angle_tol;        /* 0.08727 rad  (src/monte_carlo.jl:71)                                           */
+  int32_t noise_mode;       /* 0: the `noise` array (NULL = noise-free plant); 1: drawn inside the kernel, below */
+  int32_t reserved;
+  uint64_t noise_seed;      /* key of the counter-based generator                                             */
+  double  sigma_gyro;       /* (0.38 deg)^2: `randn(3,1)*(.38*pi/180)^2`, src/simulator.jl:5                  */
+  double  sigma_att;        /* (1 deg)^2:    `randn(3,1)*(1*pi/180)^2`,   src/simulator.jl:10                 */
+  double  field_amp;        /* (1e-5)^2:     `rand(3)*1e-5^2`,            src/simulator.jl:22                 */
 } tsat_tvlqr_options;
+
+/* noise_mode = 1: the nine draws of plant evaluation (trajectory id, knot k, RK4 stage s) come from Philox4x32-10 with
+ * key (noise_seed lo, hi) and counters (id lo, id hi, k, 4 s + j), j = 0, 1, 2 -> words w[j][0..3]:
+ *   U(w) = (w + 0.5) 2^-32;  (z, z') = sqrt(-2 ln U(a)) (cos, sin)(2 pi U(b))          (Box-Muller)
+ *   gyro   = sigma_gyro (z(w00,w01), z'(w00,w01), z(w02,w03))
+ *   att    = sigma_att  (z'(w02,w03), z(w10,w11), z'(w10,w11))
+ *   field  = field_amp  (U(w12), U(w13), U(w20))
+ * id = noise_id[t] (NULL: t), so a sweep draws the same noise however it is sharded or chunked. The reference draws
+ * from Julia's global generator inside `simulator`; any generator is as faithful, this one is reproducible. */
 
 typedef struct tsat_tvlqr_stats {
   int32_t slew_index;       /* first 1-based sample j > min_steps with |w| < w_tol and error angle < angle_tol; 0 = none */
@@ -204,6 +219,7 @@ void tsat_tvlqr_default_options(tsat_tvlqr_options* o);
  *   n_knots T or NULL            per-trajectory horizons as for tsat_batch_knots (`t_total[i]`, src/monte_carlo.jl:145):
  *                                trajectory t is tracked over its first n_knots[t] samples, the rest of its slabs is
  *                                zero and its statistic counts n_knots[t] samples; NULL = all N
+ *   noise_id T or NULL           generator ids of the trajectories when options.noise_mode = 1
  */
 int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int64_t n_btab,
                       const double* X, const double* U, const double* xf,
@@ -211,7 +227,7 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
                       const double* dt, const double* Jmat, const double* Qd, const double* Qfd, const double* Rd,
                       const double* x0_sim, const double* noise,
                       double* X_sim, double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats,
-                      const int32_t* n_knots);
+                      const int32_t* n_knots, const int64_t* noise_id);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Receding-horizon re-solve on the RESIDENT batch (BASELINE.json configs[4]). NOT in the reference —

@@ -173,6 +173,12 @@ Base.@kwdef mutable struct TvlqrOptions
     u_scale::Float64 = 1e-2          # src/gain_simulator.jl:42
     w_tol::Float64 = 0.05            # slew_limits, src/monte_carlo.jl:70-71
     angle_tol::Float64 = 0.08727
+    noise_mode::Int32 = 0            # 1: the kernel draws the plant noise itself (Philox4x32-10 keyed by noise_seed)
+    reserved::Int32 = 0
+    noise_seed::UInt64 = 0
+    sigma_gyro::Float64 = (0.38 * pi / 180)^2    # src/simulator.jl:5
+    sigma_att::Float64 = (pi / 180)^2            # src/simulator.jl:10
+    field_amp::Float64 = 1e-10                   # src/simulator.jl:22
 end
 struct TvlqrStats
     slew_index::Int32; failed::Int32; slew_time::Float64; final_w_norm::Float64; final_angle::Float64
@@ -188,17 +194,18 @@ Returns X_sim 7×N×T, U_sim 3×(N-1)×T, K 3×6×(N-1)×T, stats.
 """
 function attitude_simulation(s::HIPSolver, p::BatchProblem, x0_lqr::Matrix{Float64}, Q_lqr::Matrix{Float64},
                              Qf_lqr::Matrix{Float64}, R_lqr::Matrix{Float64};
-                             noise::Union{Nothing,Array{Float64,4}} = nothing, opts::TvlqrOptions = TvlqrOptions())
+                             noise::Union{Nothing,Array{Float64,4}} = nothing, noise_id::Vector{Int64} = Int64[],
+                             opts::TvlqrOptions = TvlqrOptions())
     T = size(p.x0, 2); N = p.N
     opts.n_knots = N; opts.n_tab = size(p.B_ECI, 2)
     Xs = zeros(7, N, T); Us = zeros(3, N - 1, T); K = zeros(3, 6, N - 1, T); st = Vector{TvlqrStats}(undef, T)
     check(s, ccall((:tsat_tvlqr_batch, LIB), Cint,
         (Ptr{Cvoid}, Ref{TvlqrOptions}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32},
          Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
-         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{TvlqrStats}, Ptr{Int32}),
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{TvlqrStats}, Ptr{Int32}, Ptr{Int64}),
         s.handle, opts, T, size(p.B_ECI, 3), p.X, p.U, p.xf, p.B_ECI, p.btab_idx, p.tau0, p.dtau, p.dt, p.J,
         Q_lqr, Qf_lqr, R_lqr, x0_lqr, noise === nothing ? C_NULL : noise, Xs, Us, K, st,
-        isempty(p.n_knots) ? C_NULL : p.n_knots), "tsat_tvlqr_batch")
+        isempty(p.n_knots) ? C_NULL : p.n_knots, isempty(noise_id) ? C_NULL : noise_id), "tsat_tvlqr_batch")
     return Xs, Us, K, st
 end
 

@@ -184,7 +184,20 @@ def tvlqr_default_options():
     return o
 
 
-def tvlqr_batch(batch, X, U, Qd, Qfd, Rd, x0_sim, noise=None, opts=None, nthreads=1):
+def philox4x32_10(key, ctr):
+    out = (C.c_uint32 * 4)()
+    load().orc_philox4x32_10((C.c_uint32 * 2)(*key), (C.c_uint32 * 4)(*ctr), out)
+    return [int(v) for v in out]
+
+
+def plant_noise(seed, tid, knot, stage, sg, sa, fa):
+    nz = np.zeros(9)
+    load().orc_plant_noise(C.c_uint64(seed), C.c_int64(tid), C.c_int32(knot), C.c_int32(stage), C.c_double(sg), C.c_double(sa),
+                           C.c_double(fa), nz.ctypes.data_as(_dp))
+    return nz
+
+
+def tvlqr_batch(batch, X, U, Qd, Qfd, Rd, x0_sim, noise=None, opts=None, nthreads=1, noise_ids=None):
     """Oracle closed-loop tracking of solved trajectories (see tsat_tvlqr_batch). Returns X_sim, U_sim, K_lqr, stats."""
     lib = load()
     T, N = batch.T, batch.N
@@ -200,7 +213,8 @@ def tvlqr_batch(batch, X, U, Qd, Qfd, Rd, x0_sim, noise=None, opts=None, nthread
                              batch.btab_idx.ctypes.data_as(C.POINTER(C.c_int32)), d(batch.tau0), d(batch.dtau), d(batch.dt),
                              d(batch.Jmat), d(Qd), d(Qfd), d(Rd), d(x0_sim), d(noise) if noise is not None else None,
                              d(Xs), d(Us), d(K), st.ctypes.data_as(C.c_void_p), C.c_int(nthreads),
-                             None if batch.n_knots is None else np.ascontiguousarray(batch.n_knots, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32)))
+                             None if batch.n_knots is None else np.ascontiguousarray(batch.n_knots, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32)),
+                             None if noise_ids is None else np.ascontiguousarray(noise_ids, dtype=np.int64).ctypes.data_as(C.POINTER(C.c_int64)))
     if rc != 0:
         raise RuntimeError(f"orc_tvlqr_batch failed rc={rc}")
     return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)

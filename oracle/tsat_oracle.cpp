@@ -871,6 +871,41 @@ int orc_mpc_batch(const tsat_options* o, int64_t T, int64_t n_btab, const double
 void orc_tvlqr_default_options(tsat_tvlqr_options* o) {
   std::memset(o, 0, sizeof(*o));
   o->linearize_dt_sq = 1; o->min_steps = 10; o->u_scale = 1e-2; o->w_tol = 0.05; o->angle_tol = 0.08727;
+  const double deg = M_PI / 180.0;
+  o->noise_mode = 0; o->noise_seed = 0;
+  o->sigma_gyro = (0.38 * deg) * (0.38 * deg);   // src/simulator.jl:5
+  o->sigma_att = deg * deg;                       // src/simulator.jl:10
+  o->field_amp = 1e-5 * 1e-5;                     // src/simulator.jl:22
+}
+
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11) and the draws of
+// one plant evaluation as include/tortoise_hip.h defines them for noise_mode = 1
+void orc_philox4x32_10(const uint32_t key[2], const uint32_t ctr[4], uint32_t out[4]) {
+  uint32_t k0 = key[0], k1 = key[1], c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  for (int r = 0; r < 10; ++r) {
+    if (r > 0) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static inline double unit_open(uint32_t w) { return ((double)w + 0.5) / 4294967296.0; }
+void orc_plant_noise(uint64_t seed, int64_t id, int32_t knot, int32_t stage, double sg, double sa, double fa, double* nz) {
+  const uint32_t key[2] = {(uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32)};
+  uint32_t w[3][4];
+  for (uint32_t j = 0; j < 3; ++j) {
+    const uint32_t ctr[4] = {(uint32_t)((uint64_t)id & 0xFFFFFFFFull), (uint32_t)((uint64_t)id >> 32), (uint32_t)knot, (uint32_t)(4 * stage) + j};
+    orc_philox4x32_10(key, ctr, w[j]);
+  }
+  auto bm = [](uint32_t a, uint32_t b, double& z0, double& z1) {
+    const double r = std::sqrt(-2.0 * std::log(unit_open(a))), th = 2.0 * M_PI * unit_open(b);
+    z0 = r * std::cos(th); z1 = r * std::sin(th);
+  };
+  double z[6];
+  bm(w[0][0], w[0][1], z[0], z[1]); bm(w[0][2], w[0][3], z[2], z[3]); bm(w[1][0], w[1][1], z[4], z[5]);
+  for (int i = 0; i < 3; ++i) { nz[i] = sg * z[i]; nz[3 + i] = sa * z[3 + i]; }
+  nz[6] = fa * unit_open(w[1][2]); nz[7] = fa * unit_open(w[1][3]); nz[8] = fa * unit_open(w[2][0]);
 }
 
 // src/simulator.jl:1-42 with the three random draws passed in (nz: gyro(3), attitude rotation vector(3), field(3));
@@ -907,8 +942,9 @@ int orc_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, cons
                     const double* xf, const double* Btab, const int32_t* btab_idx, const double* tau0,
                     const double* dtau, const double* dt, const double* Jmat, const double* Qd, const double* Qfd,
                     const double* Rd, const double* x0_sim, const double* noise, double* X_sim, double* U_sim,
-                    double* K_lqr, tsat_tvlqr_stats* stats, int nthreads, const int32_t* n_knots) {
+                    double* K_lqr, tsat_tvlqr_stats* stats, int nthreads, const int32_t* n_knots, const int64_t* noise_id) {
   if (!o || o->n_knots < 2 || o->n_tab < 1) return -1;
+  if (o->noise_mode == 1 && noise) return -1;
   if (!btab_idx && n_btab != T) return -1;
   const int NS = o->n_knots;   // slab stride; a ragged trajectory uses its first n_knots[t] samples (zero beyond)
   (void)nthreads;
@@ -960,7 +996,11 @@ int orc_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, cons
         us[a] = v;
         Us[3 * k + a] = v;
       }
-      const double* nz = noise ? noise + ((size_t)t * (NS - 1) + k) * 36 : nullptr;
+      double drawn[36];
+      if (o->noise_mode == 1)
+        for (int st = 0; st < 4; ++st)
+          orc_plant_noise(o->noise_seed, noise_id ? noise_id[t] : t, k, st, o->sigma_gyro, o->sigma_att, o->field_amp, drawn + 9 * st);
+      const double* nz = o->noise_mode == 1 ? drawn : (noise ? noise + ((size_t)t * (NS - 1) + k) * 36 : nullptr);
       const double *b0 = brow(tr, k, 0.0), *b1 = brow(tr, k, 0.5), *b2 = brow(tr, k, 1.0);
       double k1[7], k2[7], k3[7], k4[7], tmp[7];
       sim_dyn(xs, us, b0, nz, tr.ph, k1);

@@ -61,9 +61,11 @@ class Emu:
         return dict(X=X, U=U, K=K, stats=stats, trace=trace)
 
 
-    def tvlqr(self, batch, X, U, Qd, Qfd, Rd, x0_sim, noise=None, opts=None):
+    def tvlqr(self, batch, X, U, Qd, Qfd, Rd, x0_sim, noise=None, opts=None, noise_ids=None):
         T, N = batch.T, batch.N
-        o = opts or self.abi.TvlqrOptions(0, 0, 1, 10, 1e-2, 0.05, 0.08727)
+        if opts is None:
+            opts = self.abi.TvlqrOptions(0, 0, 1, 10, 1e-2, 0.05, 0.08727, 0, 0, 0, (0.38 * np.pi / 180) ** 2, (np.pi / 180) ** 2, 1e-10)
+        o = opts
         o.n_knots, o.n_tab = N, batch.n_tab
         c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         X, U, Qd, Qfd, Rd, x0_sim = c(X), c(U), c(Qd), c(Qfd), c(Rd), c(x0_sim)
@@ -75,7 +77,8 @@ class Emu:
                                       d(batch.Btab), self.abi.as_ip(batch.btab_idx), d(batch.tau0), d(batch.dtau), d(batch.dt),
                                       d(batch.Jmat), d(Qd), d(Qfd), d(Rd), d(x0_sim), d(noise), d(Xs), d(Us), d(K),
                                       st.ctypes.data_as(C.c_void_p),
-                                      None if batch.n_knots is None else self.abi.as_ip(np.ascontiguousarray(batch.n_knots, dtype=np.int32)))
+                                      None if batch.n_knots is None else self.abi.as_ip(np.ascontiguousarray(batch.n_knots, dtype=np.int32)),
+                                      None if noise_ids is None else np.ascontiguousarray(noise_ids, dtype=np.int64).ctypes.data_as(C.POINTER(C.c_int64)))
         if rc != 0:
             raise RuntimeError(f"emu_tvlqr_batch rc={rc}")
         return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)

@@ -150,7 +150,7 @@ extern "C" int emu_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n
                                const double* dtau, const double* dt, const double* Jmat, const double* Qd,
                                const double* Qfd, const double* Rd, const double* x0_sim, const double* noise,
                                double* X_sim, double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats,
-                               const int32_t* n_knots) {
+                               const int32_t* n_knots, const int64_t* noise_id) {
   if (!check_tv_options(*o).empty()) return -1;
   const int N = o->n_knots, n_tab = o->n_tab;
   std::vector<double> P((size_t)T * PSTRIDE), BT((size_t)n_btab * n_tab * 4), XUR((size_t)T * N * XUW),
@@ -163,6 +163,7 @@ extern "C" int emu_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n
   TvArgs<double> a;
   a.T = (int)T; a.N = N; a.n_tab = n_tab; a.lin_sq = o->linearize_dt_sq; a.min_steps = o->min_steps;
   a.us = o->u_scale; a.w_tol = o->w_tol; a.ang_tol = o->angle_tol;
+  fill_tv_noise<double>(*o, (const long long*)noise_id, a);
   a.P = P.data(); a.BT = BT.data(); a.bidx = bidx.data(); a.nk = n_knots; a.XUR = XUR.data(); a.NZ = noise; a.KD = KD.data(); a.XS = XS.data();
   a.stats = stats;
   const int cls = inertia_class(T, Jmat);

@@ -19,7 +19,8 @@ class OracleStages:
         o.error_state = 1
         return self.ol.solve_batch(batch, o, nthreads=self.nthreads, want_K=False)
 
-    def attitude_simulation(self, batch, X, U, x0_sim, Qd, Qfd, Rd, noise, s):
+    def attitude_simulation(self, batch, X, U, x0_sim, Qd, Qfd, Rd, noise_seed, noise_ids, s):
         o = self.ol.tvlqr_default_options()
         o.w_tol, o.angle_tol = s.w_tol, s.angle_tol
-        return self.ol.tvlqr_batch(batch, X, U, Qd, Qfd, Rd, x0_sim, noise=noise, opts=o, nthreads=self.nthreads)
+        o.noise_mode, o.noise_seed = 1, noise_seed
+        return self.ol.tvlqr_batch(batch, X, U, Qd, Qfd, Rd, x0_sim, opts=o, nthreads=self.nthreads, noise_ids=noise_ids)

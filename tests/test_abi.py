@@ -44,7 +44,7 @@ def test_struct_layouts_and_defaults(pkg, ol):
     for name, _ in abi.TvlqrOptions._fields_:
         assert getattr(t, name) == getattr(tr, name), name
     assert (t.linearize_dt_sq, t.min_steps, t.w_tol, t.angle_tol) == (1, 10, 0.05, 0.08727)   # src/monte_carlo.jl:70-71,251
-    assert C.sizeof(abi.TvlqrOptions) == 40 and abi.TVLQR_STATS_DTYPE.itemsize == 32
+    assert C.sizeof(abi.TvlqrOptions) == 80 and abi.TVLQR_STATS_DTYPE.itemsize == 32
     bt, br = abi.BtableOptions(), ol.BtableOptions()
     lib.tsat_btable_default_options(C.byref(bt))
     ol.load().orc_btable_default_options(C.byref(br))

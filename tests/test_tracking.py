@@ -120,6 +120,51 @@ def test_ragged_tracking_equals_separate_runs(pkg, ol, emu):
         assert alone["stats"]["slew_time"][0] == ref["stats"]["slew_time"][t]
 
 
+def test_philox_known_answers_and_draw_layout(pkg, ol):
+    """Philox4x32-10 known-answer vectors of the Random123 distribution (kat_vectors), on the oracle's C++ and on the
+    NumPy generator of the host module; then the draw layout of include/tortoise_hip.h on both"""
+    tr = pkg.tracking
+    kats = [((0, 0), (0, 0, 0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff, 0xffffffff), (0xffffffff,) * 4, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0xa4093822, 0x299f31d0), (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for key, ctr, out in kats:
+        assert tuple(ol.philox4x32_10(key, ctr)) == out
+        got = tr.philox4x32_10(np.array(key, dtype=np.uint64), np.array([ctr], dtype=np.uint64))[0]
+        assert tuple(int(v) for v in got) == out
+    seed, ids = 0x1234567890abcdef, np.array([0, 7, 2 ** 40 + 3])
+    nz = tr.generated_noise(seed, ids, 6)
+    assert nz.shape == (3, 5, 4, 9)
+    for t, k, st in ((0, 0, 0), (1, 4, 3), (2, 2, 1)):
+        np.testing.assert_allclose(nz[t, k, st], ol.plant_noise(seed, int(ids[t]), k, st, (0.38 * np.pi / 180) ** 2, (np.pi / 180) ** 2, 1e-10),
+                                   rtol=1e-13, atol=0)
+    big = tr.generated_noise(99, np.arange(64), 200)                       # 460k normals, 154k uniforms
+    g = big[..., :6] / np.r_[[(0.38 * np.pi / 180) ** 2] * 3, [(np.pi / 180) ** 2] * 3]
+    assert abs(g.mean()) < 5e-3 and abs(g.std() - 1) < 5e-3 and abs(np.mean(g ** 4) - 3) < 0.05
+    f = big[..., 6:] / 1e-10
+    assert f.min() > 0 and f.max() < 1 and abs(f.mean() - 0.5) < 3e-3
+    assert abs(np.corrcoef(g[..., 0].ravel(), g[..., 1].ravel())[0, 1]) < 5e-3
+
+
+def test_seeded_noise_equals_the_same_noise_as_an_array(pkg, ol, emu):
+    """noise_mode = 1 (drawn where it is used) against array mode fed with the host-side generator: same run"""
+    b, r = _ragged(pkg, ol)
+    Qd, Qfd, Rd, x0s, _ = _setup(pkg, b)
+    ids = np.array([5, 900, 2 ** 33], dtype=np.int64)
+    nz = pkg.tracking.generated_noise(2019, ids, b.N)
+    arr = ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz)
+    o = ol.tvlqr_default_options(); o.noise_mode, o.noise_seed = 1, 2019
+    ref = ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, opts=o, noise_ids=ids)
+    assert np.max(np.abs(arr["X_sim"] - ref["X_sim"])) < 1e-13
+    assert np.array_equal(arr["stats"]["slew_index"], ref["stats"]["slew_index"])
+    o2 = pkg._abi.TvlqrOptions.from_buffer_copy(o)
+    got = emu.tvlqr(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, opts=o2, noise_ids=ids)
+    _same_tracking(ref, got)
+    # ids default to the trajectory index; another seed is another run
+    o.noise_seed = 2020
+    other = ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, opts=o)
+    assert np.max(np.abs(other["X_sim"] - ref["X_sim"])) > 1e-9
+
+
 def _same_tracking(ref, got):
     kscale = max(float(np.max(np.abs(ref["K"]))), 1.0)
     assert np.max(np.abs(ref["K"] - got["K"])) < 1e-8 * kscale
@@ -156,4 +201,13 @@ def test_gpu_tracking_matches_oracle(pkg, ol):
     _same_tracking(ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz, nthreads=5), got)
     for t, n in enumerate(b.n_knots):
         assert np.all(got["X_sim"][t, n:] == 0) and np.all(got["U_sim"][t, n - 1:] == 0)
+    # noise drawn inside the kernel (Philox) = the same noise handed over as an array = the oracle's
+    ids = np.array([3, 1, 2 ** 35, 0, 77], dtype=np.int64)
+    gen = tr.attitude_simulation(s, b, r["X"], r["U"], x0s, Qd, Qfd, Rd, noise_seed=424242, noise_ids=ids)
+    arr = tr.attitude_simulation(s, b, r["X"], r["U"], x0s, Qd, Qfd, Rd, noise=tr.generated_noise(424242, ids, b.N))
+    assert np.max(np.abs(gen["X_sim"] - arr["X_sim"])) < 1e-12 and np.array_equal(gen["stats"]["slew_index"], arr["stats"]["slew_index"])
+    o = ol.tvlqr_default_options(); o.noise_mode, o.noise_seed = 1, 424242
+    _same_tracking(ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, opts=o, noise_ids=ids, nthreads=5), gen)
+    with pytest.raises(RuntimeError):
+        tr.attitude_simulation(s, b, r["X"], r["U"], x0s, Qd, Qfd, Rd, noise=nz, noise_seed=None if False else None, min_steps=-1)
     s.close()

@@ -56,7 +56,9 @@ class TvlqrOptions(C.Structure):
     """``tsat_tvlqr_options`` — closed-loop tracking of a solved slew (src/attitude_controller.jl:1-119)."""
 
     _fields_ = [("n_knots", C.c_int32), ("n_tab", C.c_int32), ("linearize_dt_sq", C.c_int32), ("min_steps", C.c_int32),
-                ("u_scale", C.c_double), ("w_tol", C.c_double), ("angle_tol", C.c_double)]
+                ("u_scale", C.c_double), ("w_tol", C.c_double), ("angle_tol", C.c_double),
+                ("noise_mode", C.c_int32), ("reserved", C.c_int32), ("noise_seed", C.c_uint64),
+                ("sigma_gyro", C.c_double), ("sigma_att", C.c_double), ("field_amp", C.c_double)]
 
 
 class BtableOptions(C.Structure):
@@ -98,7 +100,7 @@ PROTOTYPES = {
     "tsat_horizon_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, _ip, _dp]),
     "tsat_tvlqr_default_options": (None, [C.POINTER(TvlqrOptions)]),
     "tsat_tvlqr_batch": (C.c_int, [C.c_void_p, C.POINTER(TvlqrOptions), C.c_int64, C.c_int64, _dp, _dp, _dp, _dp, _ip,
-                                   _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p, _ip]),
+                                   _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p, _ip, C.POINTER(C.c_int64)]),
 }
 
 LIB_NAME = "libtortoise_hip.so"

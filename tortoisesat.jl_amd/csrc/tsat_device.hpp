@@ -181,6 +181,7 @@ TSAT_DEV double acos_(double a) { return std::acos(a); }
 TSAT_DEV double asin_(double a) { return std::asin(a); }
 TSAT_DEV double atan2_(double a, double b) { return std::atan2(a, b); }
 TSAT_DEV double fmod_(double a, double b) { return std::fmod(a, b); }
+TSAT_DEV double log_(double a) { return std::log(a); }
 #else
 // v_rsq_f64 seed (rel. error <= 5.3e-8, profiles/r01/rsq_rcp_accuracy.txt) + ONE third-order step:
 // y (1 + e/2 + 3e^2/8), e = 1 - s y^2  ->  error O(e^3) ~ 1e-22, i.e. rounding only; 5 instructions instead of the 8
@@ -213,6 +214,7 @@ TSAT_DEV double acos_(double a) { return ::acos(a); }
 TSAT_DEV double asin_(double a) { return ::asin(a); }
 TSAT_DEV double atan2_(double a, double b) { return ::atan2(a, b); }
 TSAT_DEV double fmod_(double a, double b) { return ::fmod(a, b); }
+TSAT_DEV double log_(double a) { return ::log(a); }
 #endif
 
 // phase timing for the diagnostic build (-DTSAT_PROFILE): shader-clock stamps accumulated per phase and written to
@@ -1277,19 +1279,55 @@ struct TvArgs {
   const int* nk;      // [T] per-trajectory knot counts or null (all N)
   const real* XUR;    // [T][N][10]   optimised (X,U) records
   const real* NZ;     // [T][N-1][4][9] noise or null
+  int noise_mode;     // 1: draw the noise in the kernel (Philox4x32-10, see include/tortoise_hip.h)
+  unsigned k0, k1;    // generator key
+  const long long* nid;   // [T] generator ids or null (id = trajectory index)
+  real sg, sa, fa;    // sigma_gyro, sigma_att, field_amp
   real* KD;           // [T][N-1][24] gains (solver sign) + unused d
   real* XS;           // [T][N][10]   simulated (x,u) records
   tsat_tvlqr_stats* stats;
 };
 
-// plant with the reference's three noise sources injected (src/simulator.jl:5-23); nz == null: src/gain_simulator.jl
+// Philox4x32-10 (Salmon et al., SC'11): ten rounds of two 32x32->64 multiplies on the counter, key bumped by the Weyl
+// constants between rounds
+TSAT_DEV void philox4x32_10(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+template <typename real> TSAT_DEV real unit_open(unsigned w) { return ((real)w + (real)0.5) * (real)(1.0 / 4294967296.0); }
+template <typename real> TSAT_DEV void box_muller(unsigned a, unsigned b, real& z0, real& z1) {
+  const real r = sqrt_(-2 * log_(unit_open<real>(a))), th = (real)6.283185307179586476925 * unit_open<real>(b);
+  z0 = r * cos_(th); z1 = r * sin_(th);
+}
+// the nine draws of one plant evaluation (include/tortoise_hip.h, noise_mode = 1)
+template <typename real>
+TSAT_DEV void plant_noise(unsigned k0, unsigned k1, long long id, int knot, int stage, real sg, real sa, real fa, real nz[9]) {
+  unsigned w0[4], w1[4], w2[4];
+  const unsigned ilo = (unsigned)((unsigned long long)id & 0xFFFFFFFFull), ihi = (unsigned)((unsigned long long)id >> 32);
+  philox4x32_10(k0, k1, ilo, ihi, (unsigned)knot, (unsigned)(4 * stage + 0), w0);
+  philox4x32_10(k0, k1, ilo, ihi, (unsigned)knot, (unsigned)(4 * stage + 1), w1);
+  philox4x32_10(k0, k1, ilo, ihi, (unsigned)knot, (unsigned)(4 * stage + 2), w2);
+  real z[6];
+  box_muller<real>(w0[0], w0[1], z[0], z[1]);
+  box_muller<real>(w0[2], w0[3], z[2], z[3]);
+  box_muller<real>(w1[0], w1[1], z[4], z[5]);
+  for (int i = 0; i < 3; ++i) { nz[i] = sg * z[i]; nz[3 + i] = sa * z[3 + i]; }
+  nz[6] = fa * unit_open<real>(w1[2]); nz[7] = fa * unit_open<real>(w1[3]); nz[8] = fa * unit_open<real>(w2[0]);
+}
+
+// plant with the reference's three noise sources injected (src/simulator.jl:5-23); noisy == false: src/gain_simulator.jl
 template <typename real, int DIAGJ>
 TSAT_DEV void dyn_sim_h(const Traj<real>& tr, const real x[7], const real us[3], const real b[3],
-                        const TSAT_GLOBAL real* nz, real k[7]) {
+                        bool noisy, const real nz[9], real k[7]) {
   real xx[7], bb[3];
   for (int i = 0; i < 7; ++i) xx[i] = x[i];
   for (int i = 0; i < 3; ++i) bb[i] = b[i];
-  if (nz) {
+  if (noisy) {
     const real rn = rsqrt_<real>(x[3] * x[3] + x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
     const real q0 = x[3] * rn, q1 = x[4] * rn, q2 = x[5] * rn, q3 = x[6] * rn;
     const real n0 = nz[3], n1 = nz[4], n2 = nz[5];
@@ -1399,9 +1437,19 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
   const Traj<real> tr = load_traj<real>(N, n_tab, p.bt);
   TSAT_GLOBAL real* XSg = (TSAT_GLOBAL real*)(a.XS + (size_t)traj * NS * XUW);
   const TSAT_GLOBAL real* NZg = a.NZ ? (const TSAT_GLOBAL real*)(a.NZ + (size_t)traj * (NS - 1) * 36) : nullptr;
+  const bool gen = a.noise_mode == 1, noisy = gen || NZg != nullptr;
+  const long long gid = a.nid ? a.nid[traj] : (long long)traj;
+  constexpr int NZK = WAVE / 4;            // knots per generated chunk: lanes = (knot, RK4 stage) pairs
+  real* nzl = lds + L_UNION;               // [NZK][4][9]; the Jacobian records that lived here are spent
   real x[7];
   for (int i = 0; i < 7; ++i) x[i] = lds[L_TR + P_X0 + i];
   for (int k = 0; k < N - 1; ++k) {
+    if (gen && (k % NZK) == 0) {
+      TSAT_SYNC();
+      const int kk = k + (lane >> 2);
+      if (kk < N - 1) plant_noise<real>(a.k0, a.k1, gid, kk, lane & 3, a.sg, a.sa, a.fa, nzl + lane * 9);
+      TSAT_SYNC();
+    }
     const TSAT_GLOBAL real* xr = p.XU + (size_t)k * XUW;
     const TSAT_GLOBAL real* kd = p.KD + (size_t)k * KDW;
     real dX[6];
@@ -1427,16 +1475,23 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
     const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
     const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
     for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
-    const TSAT_GLOBAL real* nz = NZg ? NZg + (size_t)k * 36 : nullptr;
+    real nz[36];
+    if (gen) {
+      for (int i = 0; i < 36; ++i) nz[i] = nzl[(k % NZK) * 36 + i];
+    } else if (NZg) {
+      for (int i = 0; i < 36; ++i) nz[i] = NZg[(size_t)k * 36 + i];
+    } else {
+      for (int i = 0; i < 36; ++i) nz[i] = 0;
+    }
     const real us[3] = {u[0] * tr.us, u[1] * tr.us, u[2] * tr.us};
     real k1[7], k2[7], k3[7], k4[7], t[7];
-    dyn_sim_h<real, DIAGJ>(tr, x, us, b0, nz, k1);
+    dyn_sim_h<real, DIAGJ>(tr, x, us, b0, noisy, nz, k1);
     for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k1[i];
-    dyn_sim_h<real, DIAGJ>(tr, t, us, b1, nz ? nz + 9 : nullptr, k2);
+    dyn_sim_h<real, DIAGJ>(tr, t, us, b1, noisy, nz + 9, k2);
     for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k2[i];
-    dyn_sim_h<real, DIAGJ>(tr, t, us, b1, nz ? nz + 18 : nullptr, k3);
+    dyn_sim_h<real, DIAGJ>(tr, t, us, b1, noisy, nz + 18, k3);
     for (int i = 0; i < 7; ++i) t[i] = x[i] + k3[i];
-    dyn_sim_h<real, DIAGJ>(tr, t, us, b2, nz ? nz + 27 : nullptr, k4);
+    dyn_sim_h<real, DIAGJ>(tr, t, us, b2, noisy, nz + 27, k4);
     for (int i = 0; i < 7; ++i) x[i] = x[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) * (real)(1.0 / 6.0);
   }
   if (lane == 0) {

@@ -183,7 +183,25 @@ inline std::string check_tv_options(const tsat_tvlqr_options& o) {
   if (o.n_knots < 2) return "n_knots must be >= 2";
   if (o.n_tab < 1) return "n_tab must be >= 1";
   if (o.min_steps < 0) return "min_steps must be >= 0";
+  if (o.noise_mode != 0 && o.noise_mode != 1) return "noise_mode must be 0 (array / none) or 1 (generated)";
   return "";
+}
+
+// scales of the three draws of `simulator` (src/simulator.jl:5,10,22)
+inline void tv_noise_defaults(tsat_tvlqr_options& o) {
+  const double deg = 3.14159265358979323846 / 180.0;
+  o.noise_mode = 0; o.reserved = 0; o.noise_seed = 0;
+  o.sigma_gyro = (0.38 * deg) * (0.38 * deg);
+  o.sigma_att = deg * deg;
+  o.field_amp = 1e-5 * 1e-5;
+}
+
+template <typename real>
+inline void fill_tv_noise(const tsat_tvlqr_options& o, const long long* ids, TvArgs<real>& a) {
+  a.noise_mode = o.noise_mode;
+  a.k0 = (unsigned)(o.noise_seed & 0xFFFFFFFFull); a.k1 = (unsigned)(o.noise_seed >> 32);
+  a.nid = ids;
+  a.sg = (real)o.sigma_gyro; a.sa = (real)o.sigma_att; a.fa = (real)o.field_amp;
 }
 
 // Records of the field-table kernel (tsat_device.hpp, igrf12_eval): per (n, m) the Gauss coefficients advanced to

@@ -406,13 +406,14 @@ void tsat_tvlqr_default_options(tsat_tvlqr_options* o) {
   std::memset(o, 0, sizeof(*o));
   o->linearize_dt_sq = 1;   // `dt = S[end]^2`, src/attitude_controller.jl:137
   o->min_steps = 10; o->u_scale = 1e-2; o->w_tol = 0.05; o->angle_tol = 0.08727;   // src/monte_carlo.jl:70-71,251
+  tv_noise_defaults(*o);
 }
 
 int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, const double* X,
                      const double* U, const double* xf, const double* Btab, const int32_t* btab_idx,
                      const double* tau0, const double* dtau, const double* dt, const double* Jmat, const double* Qd,
                      const double* Qfd, const double* Rd, const double* x0_sim, const double* noise, double* X_sim,
-                     double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats, const int32_t* n_knots) {
+                     double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats, const int32_t* n_knots, const int64_t* noise_id) {
   if (!h || !o) return -1;
   const std::string why = check_tv_options(*o);
   if (!why.empty()) return fail(h, -1, why);
@@ -420,6 +421,7 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
   if (!X || !U || !xf || !Btab || !tau0 || !dtau || !dt || !Jmat || !Qd || !Qfd || !Rd || !x0_sim || !X_sim || !U_sim || !stats)
     return fail(h, -1, "null array");
   if (!btab_idx && n_btab != T) return fail(h, -1, "btab_idx is NULL but n_btab != T");
+  if (o->noise_mode == 1 && noise) return fail(h, -1, "noise_mode = 1 draws the noise in the kernel: pass noise = NULL");
   TSAT_HIP(h, hipSetDevice(h->dev));
   const int N = o->n_knots, n_tab = o->n_tab;
   const size_t Tn = (size_t)T;
@@ -437,6 +439,7 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
   pack_xu_records<double>(T, N, X, U, XUR.data());
   double *dP = nullptr, *dBT = nullptr, *dXUR = nullptr, *dNZ = nullptr, *dKD = nullptr, *dXS = nullptr;
   int *dbi = nullptr, *dnk = nullptr;
+  long long* dnid = nullptr;
   tsat_tvlqr_stats* dst = nullptr;
   const size_t nNZ = Tn * (size_t)(N - 1) * 36, nKD = Tn * (size_t)(N - 1) * KDW, nXS = Tn * N * XUW;
   int rc = 0;
@@ -453,10 +456,15 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
     C(dnk, n_knots, Tn * sizeof(int));
     if (!rc && (hipMemset(dKD, 0, nKD * 8) != hipSuccess || hipMemset(dXS, 0, nXS * 8) != hipSuccess)) rc = -10;
   }
+  if (o->noise_mode == 1 && noise_id) {
+    A((void**)&dnid, Tn * sizeof(long long));
+    C(dnid, noise_id, Tn * sizeof(long long));
+  }
   if (!rc) {
     TvArgs<double> a;
     a.T = (int)T; a.N = N; a.n_tab = n_tab; a.lin_sq = o->linearize_dt_sq; a.min_steps = o->min_steps;
     a.us = o->u_scale; a.w_tol = o->w_tol; a.ang_tol = o->angle_tol;
+    fill_tv_noise<double>(*o, dnid, a);
     a.P = dP; a.BT = dBT; a.bidx = dbi; a.nk = dnk; a.XUR = dXUR; a.NZ = dNZ; a.KD = dKD; a.XS = dXS; a.stats = dst;
     const int cls = inertia_class(T, Jmat);
     auto kern = cls == 2 ? tsat_tvlqr_kernel<double, 2> : (cls == 1 ? tsat_tvlqr_kernel<double, 1> : tsat_tvlqr_kernel<double, 0>);
@@ -468,7 +476,7 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
   if (!rc && hipMemcpy(KD.data(), dKD, nKD * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && hipMemcpy(stats, dst, Tn * sizeof(tsat_tvlqr_stats), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc) unpack_tv<double>(T, N, XS.data(), KD.data(), X_sim, U_sim, K_lqr);
-  void* fr[] = {dP, dBT, dXUR, dNZ, dKD, dXS, dbi, dnk, dst};
+  void* fr[] = {dP, dBT, dXUR, dNZ, dKD, dXS, dbi, dnk, dnid, dst};
   for (void* q : fr)
     if (q) (void)hipFree(q);
   if (rc) h->err = "device allocation, copy or launch failed in tsat_tvlqr_batch";

@@ -11,8 +11,9 @@ Deliberate differences, all visible as arguments:
   * ``field_rate``: "physical" replays the resampled table at its own rate, "reference" at the script's
     ``1/(tf - t0)`` with tf = 2400 s (src/DerivFunction.jl:44 with the script globals; SURVEY quirk 1);
   * the state box ``x_bnd = 10`` (:180) never binds (|w| << 10, |q| <= 1) and is not modelled;
-  * randomness comes from ``numpy`` generators seeded per trial index, so a sweep gives the same trials whatever the
-    number of ranks or the chunking.
+  * randomness comes from generators keyed per trial index (``numpy`` PCG64 for the script's draws, Philox4x32-10
+    inside the tracking kernel for the plant noise), so a sweep gives the same trials whatever the number of ranks or
+    the chunking.
 """
 from dataclasses import dataclass
 
@@ -74,9 +75,9 @@ class GpuStages:
         self.solver.opts = opts
         return to.solve_(to.BatchProblem.from_arrays(batch, error_state=1), self.solver, want_K=False)
 
-    def attitude_simulation(self, batch, X, U, x0_sim, Qd, Qfd, Rd, noise, s):
-        return tr.attitude_simulation(self.solver, batch, X, U, x0_sim, Qd, Qfd, Rd, noise=noise, w_tol=s.w_tol,
-                                      angle_tol=s.angle_tol)
+    def attitude_simulation(self, batch, X, U, x0_sim, Qd, Qfd, Rd, noise_seed, noise_ids, s):
+        return tr.attitude_simulation(self.solver, batch, X, U, x0_sim, Qd, Qfd, Rd, noise_seed=noise_seed, noise_ids=noise_ids,
+                                      w_tol=s.w_tol, angle_tol=s.angle_tol)
 
 
 def trial_rng(seed, i):
@@ -122,17 +123,14 @@ def build_batch(ids, t_final, B_fine, seed, s):
     return b, n_knots
 
 
-def draw_tracking_inputs(batch, n_knots, ids, seed):
-    """x0_lqr (src/monte_carlo.jl:203-211) and the draws `simulator` makes (src/simulator.jl:5,10,22), per trial."""
-    T, N = batch.T, batch.N
-    x0s = np.empty((T, 7))
-    nz = np.zeros((T, N - 1, 4, 9))
+def draw_tracking_inputs(batch, ids, seed):
+    """x0_lqr (src/monte_carlo.jl:203-211) per trial. The draws `simulator` makes inside the dynamics
+    (src/simulator.jl:5,10,22) are generated by the tracking kernel itself, keyed by (seed, trial index)."""
+    x0s = np.empty((batch.T, 7))
     for j, i in enumerate(ids):
         r = np.random.Generator(np.random.PCG64([int(seed), int(i), 1]))
         x0s[j] = tr.perturbed_initial_state(batch.x0[j:j + 1], r)[0]
-        n = int(n_knots[j])
-        nz[j, : n - 1] = tr.simulator_noise(1, n, r)[0]
-    return x0s, nz
+    return x0s
 
 
 def run_trials(stages, seed, lo, hi, setup=None, keep_trajectories=True):
@@ -156,8 +154,8 @@ def run_trials(stages, seed, lo, hi, setup=None, keep_trajectories=True):
     batch, n_knots = build_batch(ids, t_final[sel], B_fine, seed, s)
     res = stages.solve(batch, s)
     Qd, Qfd, Rd = tr.tvlqr_weights(batch.T, s.lqr_alpha, s.lqr_beta, s.lqr_r)
-    x0s, nz = draw_tracking_inputs(batch, n_knots, ids, seed)
-    tv = stages.attitude_simulation(batch, res["X"], res["U"], x0s, Qd, Qfd, Rd, nz, s)
+    x0s = draw_tracking_inputs(batch, ids, seed)
+    tv = stages.attitude_simulation(batch, res["X"], res["U"], x0s, Qd, Qfd, Rd, int(seed), ids.astype(np.int64), s)
     out["n_knots"][sel] = n_knots
     out["slew_time"][sel] = tv["stats"]["slew_time"]
     out["fails"][sel] = tv["stats"]["failed"]

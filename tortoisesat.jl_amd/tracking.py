@@ -41,14 +41,62 @@ def simulator_noise(T, N, rng):
     return np.ascontiguousarray(np.concatenate([g, a, b], axis=3))
 
 
+_M0, _M1, _W0, _W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+_LO = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(key, ctr):
+    """Philox4x32-10 on arrays: key (2,) or (..., 2), ctr (..., 4) of 32-bit words held in uint64. Returns (..., 4)."""
+    k0, k1 = np.uint64(key[..., 0]) + np.zeros(ctr.shape[:-1], np.uint64), np.uint64(key[..., 1]) + np.zeros(ctr.shape[:-1], np.uint64)
+    c0, c1, c2, c3 = (ctr[..., i].astype(np.uint64) for i in range(4))
+    for r in range(10):
+        if r:
+            k0, k1 = (k0 + _W0) & _LO, (k1 + _W1) & _LO
+        p0, p1 = _M0 * c0, _M1 * c2
+        c0, c1, c2, c3 = (p1 >> np.uint64(32)) ^ c1 ^ k0, p1 & _LO, (p0 >> np.uint64(32)) ^ c3 ^ k1, p0 & _LO
+    return np.stack([c0, c1, c2, c3], axis=-1)
+
+
+def generated_noise(seed, ids, N, sigma_gyro=(0.38 * np.pi / 180.0) ** 2, sigma_att=(np.pi / 180.0) ** 2, field_amp=1e-10):
+    """What ``noise_mode = 1`` draws inside the kernel (include/tortoise_hip.h), as an array (T, N-1, 4, 9) — the same
+    run can then be repeated in array mode, or inspected."""
+    ids = np.asarray(ids, dtype=np.int64).astype(np.uint64)
+    T = ids.shape[0]
+    key = np.array([np.uint64(seed) & _LO, np.uint64(seed) >> np.uint64(32)], dtype=np.uint64)
+    ctr = np.zeros((T, N - 1, 4, 3, 4), dtype=np.uint64)
+    ctr[..., 0] = (ids & _LO)[:, None, None, None]
+    ctr[..., 1] = (ids >> np.uint64(32))[:, None, None, None]
+    ctr[..., 2] = np.arange(N - 1, dtype=np.uint64)[None, :, None, None]
+    ctr[..., 3] = (4 * np.arange(4, dtype=np.uint64))[None, None, :, None] + np.arange(3, dtype=np.uint64)[None, None, None, :]
+    w = philox4x32_10(key, ctr).astype(np.float64)                       # (T, N-1, 4, 3, 4)
+    u = (w + 0.5) / 4294967296.0
+
+    def bm(a, b):
+        r, th = np.sqrt(-2.0 * np.log(a)), 2.0 * np.pi * b
+        return r * np.cos(th), r * np.sin(th)
+
+    z0, z1 = bm(u[..., 0, 0], u[..., 0, 1]); z2, z3 = bm(u[..., 0, 2], u[..., 0, 3]); z4, z5 = bm(u[..., 1, 0], u[..., 1, 1])
+    out = np.stack([sigma_gyro * z0, sigma_gyro * z1, sigma_gyro * z2, sigma_att * z3, sigma_att * z4, sigma_att * z5,
+                    field_amp * u[..., 1, 2], field_amp * u[..., 1, 3], field_amp * u[..., 2, 0]], axis=-1)
+    return np.ascontiguousarray(out)
+
+
 def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noise=None, linearize_dt_sq=True,
-                        u_scale=1e-2, min_steps=10, w_tol=0.05, angle_tol=0.08727):
+                        u_scale=1e-2, min_steps=10, w_tol=0.05, angle_tol=0.08727, noise_seed=None, noise_ids=None):
     """Batched ``attitude_simulation`` + slew-time statistic. ``solver`` is an AugmentedLagrangianSolver (owns the GPU
-    handle); X (T,N,7), U (T,N-1,3) are the solved trajectories. Returns dict(X_sim, U_sim, K (T,N-1,6,3), stats)."""
+    handle); X (T,N,7), U (T,N-1,3) are the solved trajectories. Plant noise: ``noise`` array (T,N-1,4,9), or
+    ``noise_seed`` (+ optional per-trajectory ``noise_ids``) to have the kernel draw it, or neither for the noise-free
+    plant. Returns dict(X_sim, U_sim, K (T,N-1,6,3), stats)."""
     lib = _abi.load()
     T, N = batch.T, batch.N
     o = _abi.TvlqrOptions()
     lib.tsat_tvlqr_default_options(C.byref(o))
+    ids = None
+    if noise_seed is not None:
+        if noise is not None:
+            raise ValueError("give either a noise array or a noise seed")
+        o.noise_mode, o.noise_seed = 1, int(noise_seed)
+        ids = None if noise_ids is None else np.ascontiguousarray(noise_ids, dtype=np.int64)
     o.n_knots, o.n_tab, o.linearize_dt_sq, o.min_steps = N, batch.n_tab, int(bool(linearize_dt_sq)), int(min_steps)
     o.u_scale, o.w_tol, o.angle_tol = float(u_scale), float(w_tol), float(angle_tol)
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
@@ -66,6 +114,6 @@ def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noi
     rc = lib.tsat_tvlqr_batch(solver._h, C.byref(o), T, batch.Btab.shape[0], d(X), d(U), d(batch.xf), d(batch.Btab),
                               _abi.as_ip(batch.btab_idx), d(batch.tau0), d(batch.dtau), d(batch.dt), d(batch.Jmat),
                               d(Qd), d(Qfd), d(Rd), d(x0_sim), d(noise), d(Xs), d(Us), d(K), st.ctypes.data_as(C.c_void_p),
-                              _abi.as_ip(nk))
+                              _abi.as_ip(nk), None if ids is None else ids.ctypes.data_as(C.POINTER(C.c_int64)))
     solver._check(rc, "tsat_tvlqr_batch")
     return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)
