@@ -471,9 +471,9 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
     hipLaunchKernelGGL(kern, dim3((unsigned)T), dim3(64), 0, h->stream, a);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) rc = -10;
   }
-  std::vector<double> XS(nXS), KD(nKD);
+  std::vector<double> XS(nXS), KD(K_lqr ? nKD : 0);     // the gains travel only when asked for
   if (!rc && hipMemcpy(XS.data(), dXS, nXS * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
-  if (!rc && hipMemcpy(KD.data(), dKD, nKD * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && K_lqr && hipMemcpy(KD.data(), dKD, nKD * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && hipMemcpy(stats, dst, Tn * sizeof(tsat_tvlqr_stats), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc) unpack_tv<double>(T, N, XS.data(), KD.data(), X_sim, U_sim, K_lqr);
   void* fr[] = {dP, dBT, dXUR, dNZ, dKD, dXS, dbi, dnk, dnid, dst};

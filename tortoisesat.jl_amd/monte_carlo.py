@@ -77,7 +77,7 @@ class GpuStages:
 
     def attitude_simulation(self, batch, X, U, x0_sim, Qd, Qfd, Rd, noise_seed, noise_ids, s):
         return tr.attitude_simulation(self.solver, batch, X, U, x0_sim, Qd, Qfd, Rd, noise_seed=noise_seed, noise_ids=noise_ids,
-                                      w_tol=s.w_tol, angle_tol=s.angle_tol)
+                                      w_tol=s.w_tol, angle_tol=s.angle_tol, want_K=False)
 
 
 def trial_rng(seed, i):

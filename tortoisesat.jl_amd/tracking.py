@@ -82,7 +82,8 @@ def generated_noise(seed, ids, N, sigma_gyro=(0.38 * np.pi / 180.0) ** 2, sigma_
 
 
 def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noise=None, linearize_dt_sq=True,
-                        u_scale=1e-2, min_steps=10, w_tol=0.05, angle_tol=0.08727, noise_seed=None, noise_ids=None):
+                        u_scale=1e-2, min_steps=10, w_tol=0.05, angle_tol=0.08727, noise_seed=None, noise_ids=None,
+                        want_K=True):
     """Batched ``attitude_simulation`` + slew-time statistic. ``solver`` is an AugmentedLagrangianSolver (owns the GPU
     handle); X (T,N,7), U (T,N-1,3) are the solved trajectories. Plant noise: ``noise`` array (T,N-1,4,9), or
     ``noise_seed`` (+ optional per-trajectory ``noise_ids``) to have the kernel draw it, or neither for the noise-free
@@ -107,7 +108,7 @@ def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noi
         noise = c(noise)
         if noise.shape != (T, N - 1, 4, 9):
             raise ValueError("noise must be (T, N-1, 4, 9)")
-    Xs = np.empty((T, N, 7)); Us = np.empty((T, N - 1, 3)); K = np.empty((T, N - 1, 6, 3))
+    Xs = np.empty((T, N, 7)); Us = np.empty((T, N - 1, 3)); K = np.empty((T, N - 1, 6, 3)) if want_K else None
     nk = None if batch.n_knots is None else np.ascontiguousarray(batch.n_knots, dtype=np.int32)
     st = np.zeros(T, dtype=_abi.TVLQR_STATS_DTYPE)
     d = _abi.as_dp
