@@ -25,6 +25,14 @@
  *       orc_quaternion_expansion                        src/attitude_controller.jl:50-81, src/quaternion_toolbox.jl:15-75
  *   A7  orc_tvlqr_riccati                               src/attitude_controller.jl:83-92
  *   A8/A9/A10 orc_solve_batch                           src/TortoiseSat.jl:157-199 + SURVEY.md Appendix A
+ *             (its RESULT is pinned against SciPy's SLSQP on an independent NumPy rollout, tests/test_golden_and_emu.py)
+ *   §8f-1 orc_kep_eci, orc_igrf12, orc_btable_batch     src/kep_ECI.jl:1-35, src/OrbitPlotter.jl:1-52, src/igrf.jl:70-274,
+ *                                                       src/legendre.jl:254-292, src/dlegendre.jl:221-309, src/magnetic_toolbox.jl:33-106
+ *   §8f-2 orc_horizon_batch                             src/magnetic_toolbox.jl:1-31
+ *   §8f-3 orc_tvlqr_batch (+ orc_philox4x32_10,
+ *         orc_plant_noise for noise_mode = 1)           src/attitude_controller.jl:1-119, src/simulator.jl, src/gain_simulator.jl,
+ *                                                       src/monte_carlo.jl:242-262
+ *   orc_mpc_batch                                       no reference text (BASELINE.json configs[4]; see tsat_mpc_run in the header)
  */
 #include <cmath>
 #include <cstdint>
