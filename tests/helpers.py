@@ -35,7 +35,11 @@ def load_case(name, pkg, ol):
 
 
 def golden_cases():
-    return sorted(f for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    return sorted(f for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("stages_"))
+
+
+def stage_golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name))
 
 
 def abi_options_like(o, pkg, N, n_tab):
