@@ -5,6 +5,7 @@ binds the same classes so that checker and product agree on the layout.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -118,6 +119,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64, and a process keeps whichever HIP runtime it loaded first: if
+    # this library came first, a later `import torch` finds no GPU. bench.py and sweep.py hand torch device buffers to
+    # this library, so torch — when installed — is imported before the dlopen (TSAT_NO_TORCH_PRELOAD=1 skips it).
+    if "torch" not in sys.modules and os.environ.get("TSAT_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     path = lib_path()
     if not os.path.exists(path):
         raise RuntimeError(
