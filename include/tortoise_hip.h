@@ -229,6 +229,13 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
                       double* X_sim, double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats,
                       const int32_t* n_knots, const int64_t* noise_id);
 
+/* The same tracking for the RESIDENT batch right after tsat_batch_run: reference trajectories, field tables, table
+ * clocks, inertias, goal states and per-trajectory horizons are the ones already on the device — nothing of the solve
+ * travels back and forth between the two calls (src/monte_carlo.jl:196 -> :230). n_knots / n_tab of `o` are ignored. */
+int  tsat_tvlqr_resident(tsat_handle* h, const tsat_tvlqr_options* o, const double* Qd, const double* Qfd,
+                         const double* Rd, const double* x0_sim, const double* noise,
+                         double* X_sim, double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats, const int64_t* noise_id);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Receding-horizon re-solve on the RESIDENT batch (BASELINE.json configs[4]). NOT in the reference —
  * it tracks its plan with TVLQR (src/attitude_controller.jl:1-48); defined here as: n_steps times

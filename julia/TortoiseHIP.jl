@@ -209,6 +209,21 @@ function attitude_simulation(s::HIPSolver, p::BatchProblem, x0_lqr::Matrix{Float
     return Xs, Us, K, st
 end
 
+"attitude_simulation_resident(s, p, ...) — as above for the batch still resident after solve!(p, s): nothing is re-uploaded"
+function attitude_simulation_resident(s::HIPSolver, p::BatchProblem, x0_lqr::Matrix{Float64}, Q_lqr::Matrix{Float64},
+                                      Qf_lqr::Matrix{Float64}, R_lqr::Matrix{Float64};
+                                      noise::Union{Nothing,Array{Float64,4}} = nothing, noise_id::Vector{Int64} = Int64[],
+                                      opts::TvlqrOptions = TvlqrOptions())
+    T = size(p.x0, 2); N = p.N
+    Xs = zeros(7, N, T); Us = zeros(3, N - 1, T); K = zeros(3, 6, N - 1, T); st = Vector{TvlqrStats}(undef, T)
+    check(s, ccall((:tsat_tvlqr_resident, LIB), Cint,
+        (Ptr{Cvoid}, Ref{TvlqrOptions}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{TvlqrStats}, Ptr{Int64}),
+        s.handle, opts, Q_lqr, Qf_lqr, R_lqr, x0_lqr, noise === nothing ? C_NULL : noise, Xs, Us, K, st,
+        isempty(noise_id) ? C_NULL : noise_id), "tsat_tvlqr_resident")
+    return Xs, Us, K, st
+end
+
 """
 receding_horizon!(s, p, n_steps; plant_integrator = 4) — `tsat_mpc_run` on the batch `p` (uploaded here): re-solve the
 horizon every control step with the budget of `s.opts`, apply U[:,1] to the noise-free plant, shift the plan.

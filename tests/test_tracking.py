@@ -190,6 +190,10 @@ def test_gpu_tracking_matches_oracle(pkg, ol):
         got = tr.attitude_simulation(s, b, res["X"], res["U"], x0s, Qd, Qfd, Rd, noise=nz)
         ref = ol.tvlqr_batch(b, res["X"], res["U"], Qd, Qfd, Rd, x0s, noise=nz, nthreads=min(12, ol.num_procs()))
         _same_tracking(ref, got)
+    res_dev = tr.attitude_simulation(s, b, None, None, x0s, Qd, Qfd, Rd, noise=nz)      # the resident batch, nothing re-uploaded
+    for k in ("X_sim", "U_sim", "K"):
+        assert np.array_equal(res_dev[k], got[k]), k
+    assert np.array_equal(res_dev["stats"], got["stats"])
     got2 = tr.attitude_simulation(s, b, res["X"], res["U"], x0s, Qd, Qfd, Rd, noise=nz, linearize_dt_sq=False)
     o = ol.tvlqr_default_options(); o.linearize_dt_sq = 0
     _same_tracking(ol.tvlqr_batch(b, res["X"], res["U"], Qd, Qfd, Rd, x0s, noise=nz, opts=o, nthreads=8), got2)

@@ -77,6 +77,8 @@ struct tsat_handle {
   tsat_stats* stats = nullptr;
   double* trace = nullptr;
   int64_t bytes = 0;
+  // host copies of the small per-trajectory inputs of the last upload (26 doubles each), for tsat_tvlqr_resident
+  std::vector<double> hx0, hxf, htau0, hdtau, hdt, hJ;
 };
 
 namespace {
@@ -232,6 +234,8 @@ int tsat_batch_upload(tsat_handle* h, const double* x0, const double* xf, const 
   TSAT_HIP(h, hipMemcpy(h->BT, BT.data(), BT.size() * sizeof(double), hipMemcpyHostToDevice));
   TSAT_HIP(h, hipMemcpy(h->bidx, bi.data(), bi.size() * sizeof(int), hipMemcpyHostToDevice));
   TSAT_HIP(h, hipMemcpy(h->U0, U0, (size_t)T * (h->N - 1) * 3 * sizeof(double), hipMemcpyHostToDevice));
+  h->hx0.assign(x0, x0 + 7 * T); h->hxf.assign(xf, xf + 7 * T); h->htau0.assign(tau0, tau0 + T);
+  h->hdtau.assign(dtau, dtau + T); h->hdt.assign(dt, dt + T); h->hJ.assign(Jmat, Jmat + 9 * T);
   h->uploaded = true;
   h->solved = false;
   h->ragged = false;   // a fresh upload is a uniform batch until tsat_batch_knots says otherwise
@@ -409,6 +413,47 @@ void tsat_tvlqr_default_options(tsat_tvlqr_options* o) {
   tv_noise_defaults(*o);
 }
 
+namespace {
+// launch + read-back shared by tsat_tvlqr_batch (everything uploaded for the call) and tsat_tvlqr_resident (reference
+// records, tables and knot counts are the resident solved batch)
+int run_tvlqr(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int N, int n_tab, int cls, const double* dP,
+              const double* dBT, const int* dbi, const int* dnk, const double* dXUR, const double* noise,
+              const int64_t* noise_id, double* X_sim, double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats) {
+  const size_t Tn = (size_t)T;
+  const size_t nNZ = Tn * (size_t)(N - 1) * 36, nKD = Tn * (size_t)(N - 1) * KDW, nXS = Tn * N * XUW;
+  double *dNZ = nullptr, *dKD = nullptr, *dXS = nullptr;
+  long long* dnid = nullptr;
+  tsat_tvlqr_stats* dst = nullptr;
+  int rc = 0;
+  auto A = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 16) != hipSuccess) rc = -10; };
+  auto C = [&](void* d, const void* s, size_t bytes) { if (!rc && hipMemcpy(d, s, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -10; };
+  if (noise) { A((void**)&dNZ, nNZ * 8); C(dNZ, noise, nNZ * 8); }
+  A((void**)&dKD, nKD * 8); A((void**)&dXS, nXS * 8); A((void**)&dst, Tn * sizeof(tsat_tvlqr_stats));
+  if (o->noise_mode == 1 && noise_id) { A((void**)&dnid, Tn * sizeof(long long)); C(dnid, noise_id, Tn * sizeof(long long)); }
+  // ragged batch: the slabs beyond a trajectory's own horizon stay zero
+  if (dnk && !rc && (hipMemset(dKD, 0, nKD * 8) != hipSuccess || hipMemset(dXS, 0, nXS * 8) != hipSuccess)) rc = -10;
+  if (!rc) {
+    TvArgs<double> a;
+    a.T = (int)T; a.N = N; a.n_tab = n_tab; a.lin_sq = o->linearize_dt_sq; a.min_steps = o->min_steps;
+    a.us = o->u_scale; a.w_tol = o->w_tol; a.ang_tol = o->angle_tol;
+    fill_tv_noise<double>(*o, dnid, a);
+    a.P = dP; a.BT = dBT; a.bidx = dbi; a.nk = dnk; a.XUR = dXUR; a.NZ = dNZ; a.KD = dKD; a.XS = dXS; a.stats = dst;
+    auto kern = cls == 2 ? tsat_tvlqr_kernel<double, 2> : (cls == 1 ? tsat_tvlqr_kernel<double, 1> : tsat_tvlqr_kernel<double, 0>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)T), dim3(64), 0, h->stream, a);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) rc = -10;
+  }
+  std::vector<double> XS(nXS), KD(K_lqr ? nKD : 0);     // the gains travel only when asked for
+  if (!rc && hipMemcpy(XS.data(), dXS, nXS * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && K_lqr && hipMemcpy(KD.data(), dKD, nKD * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && hipMemcpy(stats, dst, Tn * sizeof(tsat_tvlqr_stats), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc) unpack_tv<double>(T, N, XS.data(), KD.data(), X_sim, U_sim, K_lqr);
+  void* fr[] = {dNZ, dKD, dXS, dnid, dst};
+  for (void* q : fr)
+    if (q) (void)hipFree(q);
+  return rc;
+}
+}  // namespace
+
 int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, const double* X,
                      const double* U, const double* xf, const double* Btab, const int32_t* btab_idx,
                      const double* tau0, const double* dtau, const double* dt, const double* Jmat, const double* Qd,
@@ -437,49 +482,44 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
   pack_tv_params<double>(T, x0_sim, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, P.data());
   pack_btab<double>(n_btab, n_tab, Btab, BT.data());
   pack_xu_records<double>(T, N, X, U, XUR.data());
-  double *dP = nullptr, *dBT = nullptr, *dXUR = nullptr, *dNZ = nullptr, *dKD = nullptr, *dXS = nullptr;
+  double *dP = nullptr, *dBT = nullptr, *dXUR = nullptr;
   int *dbi = nullptr, *dnk = nullptr;
-  long long* dnid = nullptr;
-  tsat_tvlqr_stats* dst = nullptr;
-  const size_t nNZ = Tn * (size_t)(N - 1) * 36, nKD = Tn * (size_t)(N - 1) * KDW, nXS = Tn * N * XUW;
   int rc = 0;
   auto A = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 16) != hipSuccess) rc = -10; };
-  A((void**)&dP, P.size() * 8); A((void**)&dBT, BT.size() * 8); A((void**)&dXUR, XUR.size() * 8);
-  if (noise) A((void**)&dNZ, nNZ * 8);
-  A((void**)&dKD, nKD * 8); A((void**)&dXS, nXS * 8); A((void**)&dbi, Tn * sizeof(int)); A((void**)&dst, Tn * sizeof(tsat_tvlqr_stats));
   auto C = [&](void* d, const void* s, size_t bytes) { if (!rc && hipMemcpy(d, s, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -10; };
-  C(dP, P.data(), P.size() * 8); C(dBT, BT.data(), BT.size() * 8); C(dXUR, XUR.data(), XUR.size() * 8);
-  if (noise) C(dNZ, noise, nNZ * 8);
-  C(dbi, bi.data(), Tn * sizeof(int));
-  if (n_knots) {   // ragged batch: the slabs beyond a trajectory's own horizon stay zero
-    A((void**)&dnk, Tn * sizeof(int));
-    C(dnk, n_knots, Tn * sizeof(int));
-    if (!rc && (hipMemset(dKD, 0, nKD * 8) != hipSuccess || hipMemset(dXS, 0, nXS * 8) != hipSuccess)) rc = -10;
-  }
-  if (o->noise_mode == 1 && noise_id) {
-    A((void**)&dnid, Tn * sizeof(long long));
-    C(dnid, noise_id, Tn * sizeof(long long));
-  }
-  if (!rc) {
-    TvArgs<double> a;
-    a.T = (int)T; a.N = N; a.n_tab = n_tab; a.lin_sq = o->linearize_dt_sq; a.min_steps = o->min_steps;
-    a.us = o->u_scale; a.w_tol = o->w_tol; a.ang_tol = o->angle_tol;
-    fill_tv_noise<double>(*o, dnid, a);
-    a.P = dP; a.BT = dBT; a.bidx = dbi; a.nk = dnk; a.XUR = dXUR; a.NZ = dNZ; a.KD = dKD; a.XS = dXS; a.stats = dst;
-    const int cls = inertia_class(T, Jmat);
-    auto kern = cls == 2 ? tsat_tvlqr_kernel<double, 2> : (cls == 1 ? tsat_tvlqr_kernel<double, 1> : tsat_tvlqr_kernel<double, 0>);
-    hipLaunchKernelGGL(kern, dim3((unsigned)T), dim3(64), 0, h->stream, a);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) rc = -10;
-  }
-  std::vector<double> XS(nXS), KD(K_lqr ? nKD : 0);     // the gains travel only when asked for
-  if (!rc && hipMemcpy(XS.data(), dXS, nXS * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
-  if (!rc && K_lqr && hipMemcpy(KD.data(), dKD, nKD * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
-  if (!rc && hipMemcpy(stats, dst, Tn * sizeof(tsat_tvlqr_stats), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
-  if (!rc) unpack_tv<double>(T, N, XS.data(), KD.data(), X_sim, U_sim, K_lqr);
-  void* fr[] = {dP, dBT, dXUR, dNZ, dKD, dXS, dbi, dnk, dnid, dst};
+  A((void**)&dP, P.size() * 8); A((void**)&dBT, BT.size() * 8); A((void**)&dXUR, XUR.size() * 8); A((void**)&dbi, Tn * sizeof(int));
+  C(dP, P.data(), P.size() * 8); C(dBT, BT.data(), BT.size() * 8); C(dXUR, XUR.data(), XUR.size() * 8); C(dbi, bi.data(), Tn * sizeof(int));
+  if (n_knots) { A((void**)&dnk, Tn * sizeof(int)); C(dnk, n_knots, Tn * sizeof(int)); }
+  if (!rc) rc = run_tvlqr(h, o, T, N, n_tab, inertia_class(T, Jmat), dP, dBT, dbi, dnk, dXUR, noise, noise_id, X_sim, U_sim, K_lqr, stats);
+  void* fr[] = {dP, dBT, dXUR, dbi, dnk};
   for (void* q : fr)
     if (q) (void)hipFree(q);
   if (rc) h->err = "device allocation, copy or launch failed in tsat_tvlqr_batch";
+  return rc;
+}
+
+int tsat_tvlqr_resident(tsat_handle* h, const tsat_tvlqr_options* o, const double* Qd, const double* Qfd, const double* Rd,
+                        const double* x0_sim, const double* noise, double* X_sim, double* U_sim, double* K_lqr,
+                        tsat_tvlqr_stats* stats, const int64_t* noise_id) {
+  if (!h || !o) return -1;
+  if (!h->solved) return fail(h, -1, "tsat_batch_run has not been called");
+  tsat_tvlqr_options oo = *o;
+  oo.n_knots = h->N; oo.n_tab = h->n_tab;
+  const std::string why = check_tv_options(oo);
+  if (!why.empty()) return fail(h, -1, why);
+  if (!Qd || !Qfd || !Rd || !x0_sim || !X_sim || !U_sim || !stats) return fail(h, -1, "null array");
+  if (oo.noise_mode == 1 && noise) return fail(h, -1, "noise_mode = 1 draws the noise in the kernel: pass noise = NULL");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  const int64_t T = h->T;
+  std::vector<double> P((size_t)T * PSTRIDE);
+  pack_tv_params<double>(T, x0_sim, h->hxf.data(), h->htau0.data(), h->hdtau.data(), h->hdt.data(), h->hJ.data(), Qd, Qfd, Rd, P.data());
+  double* dP = nullptr;
+  if (hipMalloc((void**)&dP, P.size() * 8) != hipSuccess) return fail(h, -10, "device allocation failed in tsat_tvlqr_resident");
+  int rc = hipMemcpy(dP, P.data(), P.size() * 8, hipMemcpyHostToDevice) == hipSuccess ? 0 : -10;
+  if (!rc) rc = run_tvlqr(h, &oo, T, h->N, h->n_tab, h->inertia_class, dP, h->BT, h->bidx, h->ragged ? h->nk : nullptr, h->XU,
+                          noise, noise_id, X_sim, U_sim, K_lqr, stats);
+  (void)hipFree(dP);
+  if (rc) h->err = "device allocation, copy or launch failed in tsat_tvlqr_resident";
   return rc;
 }
 

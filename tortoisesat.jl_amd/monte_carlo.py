@@ -76,7 +76,8 @@ class GpuStages:
         return to.solve_(to.BatchProblem.from_arrays(batch, error_state=1), self.solver, want_K=False)
 
     def attitude_simulation(self, batch, X, U, x0_sim, Qd, Qfd, Rd, noise_seed, noise_ids, s):
-        return tr.attitude_simulation(self.solver, batch, X, U, x0_sim, Qd, Qfd, Rd, noise_seed=noise_seed, noise_ids=noise_ids,
+        # the batch just solved is still resident: its trajectories and tables do not travel again
+        return tr.attitude_simulation(self.solver, batch, None, None, x0_sim, Qd, Qfd, Rd, noise_seed=noise_seed, noise_ids=noise_ids,
                                       w_tol=s.w_tol, angle_tol=s.angle_tol, want_K=False)
 
 

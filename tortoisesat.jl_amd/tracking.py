@@ -85,9 +85,10 @@ def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noi
                         u_scale=1e-2, min_steps=10, w_tol=0.05, angle_tol=0.08727, noise_seed=None, noise_ids=None,
                         want_K=True):
     """Batched ``attitude_simulation`` + slew-time statistic. ``solver`` is an AugmentedLagrangianSolver (owns the GPU
-    handle); X (T,N,7), U (T,N-1,3) are the solved trajectories. Plant noise: ``noise`` array (T,N-1,4,9), or
-    ``noise_seed`` (+ optional per-trajectory ``noise_ids``) to have the kernel draw it, or neither for the noise-free
-    plant. Returns dict(X_sim, U_sim, K (T,N-1,6,3), stats)."""
+    handle); X (T,N,7), U (T,N-1,3) are the solved trajectories — or both ``None`` to track the batch that is resident on
+    the device right after ``solve_`` (no re-upload of trajectories and tables; ``batch`` must be the one just solved).
+    Plant noise: ``noise`` array (T,N-1,4,9), or ``noise_seed`` (+ optional per-trajectory ``noise_ids``) to have the
+    kernel draw it, or neither for the noise-free plant. Returns dict(X_sim, U_sim, K (T,N-1,6,3), stats)."""
     lib = _abi.load()
     T, N = batch.T, batch.N
     o = _abi.TvlqrOptions()
@@ -101,8 +102,13 @@ def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noi
     o.n_knots, o.n_tab, o.linearize_dt_sq, o.min_steps = N, batch.n_tab, int(bool(linearize_dt_sq)), int(min_steps)
     o.u_scale, o.w_tol, o.angle_tol = float(u_scale), float(w_tol), float(angle_tol)
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
-    X, U, x0_sim, Qd, Qfd, Rd = c(X), c(U), c(x0_sim), c(Qd), c(Qfd), c(Rd)
-    if X.shape != (T, N, 7) or U.shape != (T, N - 1, 3) or Qd.shape != (T, 6) or Qfd.shape != (T, 6) or Rd.shape != (T, 3):
+    resident = X is None and U is None
+    x0_sim, Qd, Qfd, Rd = c(x0_sim), c(Qd), c(Qfd), c(Rd)
+    if not resident:
+        X, U = c(X), c(U)
+        if X.shape != (T, N, 7) or U.shape != (T, N - 1, 3):
+            raise ValueError("array shapes do not match the batch")
+    if x0_sim.shape != (T, 7) or Qd.shape != (T, 6) or Qfd.shape != (T, 6) or Rd.shape != (T, 3):
         raise ValueError("array shapes do not match the batch")
     if noise is not None:
         noise = c(noise)
@@ -112,9 +118,15 @@ def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noi
     nk = None if batch.n_knots is None else np.ascontiguousarray(batch.n_knots, dtype=np.int32)
     st = np.zeros(T, dtype=_abi.TVLQR_STATS_DTYPE)
     d = _abi.as_dp
+    idp = None if ids is None else ids.ctypes.data_as(C.POINTER(C.c_int64))
+    if resident:
+        rc = lib.tsat_tvlqr_resident(solver._h, C.byref(o), d(Qd), d(Qfd), d(Rd), d(x0_sim), d(noise), d(Xs), d(Us), d(K),
+                                     st.ctypes.data_as(C.c_void_p), idp)
+        solver._check(rc, "tsat_tvlqr_resident")
+        return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)
     rc = lib.tsat_tvlqr_batch(solver._h, C.byref(o), T, batch.Btab.shape[0], d(X), d(U), d(batch.xf), d(batch.Btab),
                               _abi.as_ip(batch.btab_idx), d(batch.tau0), d(batch.dtau), d(batch.dt), d(batch.Jmat),
                               d(Qd), d(Qfd), d(Rd), d(x0_sim), d(noise), d(Xs), d(Us), d(K), st.ctypes.data_as(C.c_void_p),
-                              _abi.as_ip(nk), None if ids is None else ids.ctypes.data_as(C.POINTER(C.c_int64)))
+                              _abi.as_ip(nk), idp)
     solver._check(rc, "tsat_tvlqr_batch")
     return dict(X_sim=Xs, U_sim=Us, K=K, stats=st)
