@@ -229,6 +229,12 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
                       double* X_sim, double* U_sim, double* K_lqr, tsat_tvlqr_stats* stats,
                       const int32_t* n_knots, const int64_t* noise_id);
 
+/* Build of the solve kernel used by tsat_batch_run / tsat_solve_batch / tsat_mpc_run: 0 = automatic (default), 1 = wide
+ * (one wavefront per SIMD: 40 KB of LDS, full register file — fastest while the batch fits the GPU that way, i.e. up to
+ * 1024 trajectories), 2 = dense (two wavefronts per SIMD: 20 KB, 256 registers — faster above that). The results are
+ * bit-identical; the switch exists for tuning and for the tests. */
+int  tsat_set_kernel_variant(tsat_handle* h, int32_t variant);
+
 /* The same tracking for the RESIDENT batch right after tsat_batch_run: reference trajectories, field tables, table
  * clocks, inertias, goal states and per-trajectory horizons are the ones already on the device — nothing of the solve
  * travels back and forth between the two calls (src/monte_carlo.jl:196 -> :230). n_knots / n_tab of `o` are ignored. */

@@ -36,10 +36,10 @@ def ol():
 class Emu:
     """ctypes binding of tests/emu/libtsat_emu.so (the HIP kernel source run by 64 host threads per wave)."""
 
-    def __init__(self, abi):
+    def __init__(self, abi, name="libtsat_emu.so"):
         d = os.path.join(ROOT, "tests", "emu")
-        subprocess.check_call(["make", "-C", d, "libtsat_emu.so"], stdout=subprocess.DEVNULL)
-        self.lib = C.CDLL(os.path.join(d, "libtsat_emu.so"))
+        subprocess.check_call(["make", "-C", d, name], stdout=subprocess.DEVNULL)
+        self.lib = C.CDLL(os.path.join(d, name))
         self.abi = abi
 
     def solve(self, batch, opts, trace_rows=0):
@@ -126,6 +126,12 @@ class Emu:
 @pytest.fixture(scope="session")
 def emu(pkg):
     return Emu(pkg._abi)
+
+
+@pytest.fixture(scope="session")
+def emu_dense(pkg):
+    """the dense build of the solve kernel (two wavefronts per SIMD on the GPU): same source, -DTSAT_DENSE"""
+    return Emu(pkg._abi, "libtsat_emu_dense.so")
 
 
 def oracle_options(ol, **kw):

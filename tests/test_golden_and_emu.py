@@ -241,3 +241,17 @@ def test_oracle_finds_the_optimum_an_independent_optimiser_finds(pkg, ol, mask, 
     assert np.max(np.abs(r["U"][0] - Us)) < 2e-3 * ub                   # finite-difference gradients limit SLSQP, not the oracle
     if mask:
         assert np.max(np.abs(r["X"][0][-1][:3] - b.xf[0][:3])) < ctol and np.max(np.abs(goal(best.x))) < 1e-9
+
+
+@pytest.mark.parametrize("N,es", [(26, 0), (27, 0), (52, 0), (24, 1), (25, 1), (70, 1)])
+def test_dense_build_of_the_kernel_is_the_same_solve(pkg, ol, emu, emu_dense, N, es):
+    """the dense build (25 / 23-knot Jacobian chunks, tsat_kernels_dense.hip) around its chunk boundaries: equal to the
+    oracle, and bit-identical to the wide build — the chunking does not touch the arithmetic"""
+    assert emu_dense.lib.emu_lds_bytes() <= 20480 < emu.lib.emu_lds_bytes()
+    b = pkg.slew_setup.workload_monte_carlo(T=2, N=N, seed=300 + N)
+    o = oracle_options(ol, max_outer=2, max_inner=4, dj_counter_limit=1, error_state=es)
+    wide, dense = emu.solve(b, o), emu_dense.solve(b, o)
+    assert_same_solution(ol.solve_batch(b, o), dense)
+    for k in ("X", "U", "K"):
+        assert np.array_equal(wide[k], dense[k]), k
+    assert np.array_equal(wide["stats"], dense["stats"])

@@ -215,6 +215,27 @@ def test_gpu_api_errors_are_codes_not_crashes(pkg, ol, solver):
         pkg.tracking.attitude_simulation(solver, b, res["X"], res["U"], b.x0, Qd, Qfd, Rd)
 
 
+def test_gpu_dense_and_wide_builds_agree(pkg, ol, solver):
+    """tsat_set_kernel_variant: the two builds of the solve kernel give bit-identical results; batches above 1024
+    trajectories take the dense one automatically"""
+    b = pkg.slew_setup.workload_monte_carlo(T=24, N=300, seed=12, random_orbit=True)
+    o = oracle_options(ol, max_outer=3, max_inner=6, dj_counter_limit=1)
+    out = {}
+    for name, v in (("wide", 1), ("dense", 2)):
+        solver.set_kernel_variant(v)
+        out[name] = gpu_solve(pkg, solver, b, o)
+    solver.set_kernel_variant(0)
+    for k in ("X", "U", "K"):
+        assert np.array_equal(out["wide"][k], out["dense"][k]), k
+    assert np.array_equal(out["wide"]["stats"], out["dense"]["stats"])
+    assert_same_solution(ol.solve_batch(b, o, nthreads=8), out["dense"])
+    big = pkg.slew_setup.workload_monte_carlo(T=1030, N=40, seed=13)                     # automatic: dense
+    o2 = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1)
+    assert_same_solution(ol.solve_batch(big, o2, nthreads=8), gpu_solve(pkg, solver, big, o2))
+    with pytest.raises(RuntimeError):
+        solver.set_kernel_variant(3)
+
+
 def test_gpu_one_call_abi_entry(pkg, ol, solver):
     """tsat_solve_batch: the single call a Julia `ccall` would make in place of solve!(prob, solver)"""
     lib, abi = pkg._abi.load(), pkg._abi

@@ -4,7 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from tsat_loader import load_package
-load_package()
+pkg = load_package()
+if os.environ.get("TSAT_LIB"):            # developer switch: another build of the same library (experiments)
+    pkg._abi.LIB_NAME = os.environ["TSAT_LIB"]
 from tortoisesat_jl_amd import trajopt as to, slew_setup as ss
 
 def run(name, b, outer, inner, es=0):

@@ -84,7 +84,14 @@ constexpr int R_F = 0, R_LX = 70, R_LU = 77, R_LUU = 80, R_QQ = 83;
 template <int ES> struct BwdCfg {
   static constexpr int NH = ES ? 6 : 7;        // dimension of the state difference the gains act on
   static constexpr int RECS = ES ? 89 : 83;    // reals per knot record
+#ifdef TSAT_DENSE
+  // "dense" build of the solve kernel (tsat_kernels_dense.hip) for batches of more than one wave per SIMD: 8 waves x
+  // <= 20 KB per CU and <= 256 registers, so that two trajectories share a SIMD (1.45x fp64 issue); the price is
+  // 25-knot Jacobian chunks and 88 spilled registers, 11 % per wave
+  static constexpr int CHB = ES ? 23 : 25;
+#else
   static constexpr int CHB = ES ? 52 : 56;     // knots per backward chunk: 4 waves x <= 40.6 KB fit one CU
+#endif
 };
 // forward-sweep chunk arrays
 constexpr int KDW = 24, XUW = 10, LMW = 6, BSW = 9;

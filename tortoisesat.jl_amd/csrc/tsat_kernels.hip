@@ -12,6 +12,9 @@
 
 using namespace tsat;
 
+// the dense build of the solve kernel lives in its own translation unit (tsat_kernels_dense.hip)
+hipError_t tsat_launch_solve_dense(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
@@ -77,6 +80,7 @@ struct tsat_handle {
   tsat_stats* stats = nullptr;
   double* trace = nullptr;
   int64_t bytes = 0;
+  int variant = 0;            // solve-kernel build: 0 automatic (dense above 1024 trajectories), 1 wide, 2 dense
   // host copies of the small per-trajectory inputs of the last upload (26 doubles each), for tsat_tvlqr_resident
   std::vector<double> hx0, hxf, htau0, hdtau, hdt, hJ;
 };
@@ -270,6 +274,15 @@ solve_kern_t solve_variant(const tsat_handle* h, const tsat_options* o) {
   return variants[o->integrator == 4 ? 1 : 0][h->inertia_class][o->error_state ? 1 : 0];
 }
 
+// One wave per SIMD (wide build) as long as the batch fits the GPU that way — 256 CUs x 4 SIMDs — else two (dense build)
+constexpr int64_t TSAT_WIDE_MAX_T = 1024;
+hipError_t launch_solve(const tsat_handle* h, const tsat_options* o, const KArgs<double>& a) {
+  const bool dense = h->variant == 2 || (h->variant == 0 && h->T > TSAT_WIDE_MAX_T);
+  if (dense) return tsat_launch_solve_dense(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream);
+  hipLaunchKernelGGL(solve_variant(h, o), dim3((unsigned)h->T), dim3(64), 0, h->stream, a);
+  return hipGetLastError();
+}
+
 KArgs<double> solve_args(const tsat_handle* h, const tsat_options* o) {
   KArgs<double> a;
   a.T = (int)h->T; a.N = h->N; a.n_tab = h->n_tab; a.max_ls = h->max_ls < NSTORE ? h->max_ls : NSTORE; a.opt = *o;
@@ -287,15 +300,20 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
   if (!why.empty()) return fail(h, -1, why);
   TSAT_HIP(h, hipSetDevice(h->dev));
   const KArgs<double> a = solve_args(h, o);
-  const solve_kern_t kern = solve_variant(h, o);
   if (h->trace) TSAT_HIP(h, hipMemsetAsync(h->trace, 0, (size_t)h->T * h->trace_rows * 8 * sizeof(double), h->stream));
   TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(kern, dim3((unsigned)h->T), dim3(64), 0, h->stream, a);
-  TSAT_HIP(h, hipGetLastError());
+  TSAT_HIP(h, launch_solve(h, o, a));
   TSAT_HIP(h, hipEventRecord(h->ev1, h->stream));
   TSAT_HIP(h, hipStreamSynchronize(h->stream));
   if (kernel_ms) TSAT_HIP(h, hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
   h->solved = true;
+  return 0;
+}
+
+int tsat_set_kernel_variant(tsat_handle* h, int32_t variant) {
+  if (!h) return -1;
+  if (variant < 0 || variant > 2) return fail(h, -1, "variant must be 0 (automatic), 1 (wide) or 2 (dense)");
+  h->variant = variant;
   return 0;
 }
 
@@ -316,7 +334,6 @@ int tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t
     return fail(h, -10, "device allocation failed in tsat_mpc_run");
   }
   const KArgs<double> a = solve_args(h, o);
-  const solve_kern_t kern = solve_variant(h, o);
   MpcArgs<double> m;
   m.T = (int)h->T; m.N = h->N; m.n_tab = h->n_tab; m.plant_integ = plant_integrator; m.n_steps = n_steps; m.us = o->u_scale;
   m.P = h->P; m.BT = h->BT; m.bidx = h->bidx; m.nk = h->ragged ? h->nk : nullptr; m.XU = h->XU; m.U0 = h->U0;
@@ -326,7 +343,7 @@ int tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t
   int rc = 0;
   if (hipEventRecord(h->ev0, h->stream) != hipSuccess) rc = -10;
   for (int s = 0; s < n_steps && !rc; ++s) {   // 2 n_steps launches queued back to back; the stream orders them
-    hipLaunchKernelGGL(kern, dim3((unsigned)h->T), dim3(64), 0, h->stream, a);
+    if (launch_solve(h, o, a) != hipSuccess) rc = -10;
     m.step = s;
     hipLaunchKernelGGL(adv, dim3((unsigned)h->T), dim3(64), 0, h->stream, m);
     if (hipGetLastError() != hipSuccess) rc = -10;

@@ -262,6 +262,11 @@ class AugmentedLagrangianSolver:
             msg = self._lib.tsat_last_error(self._h)
             raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
+    def set_kernel_variant(self, variant):
+        """0 automatic (dense above 1024 trajectories), 1 wide (one wavefront per SIMD), 2 dense (two): see
+        tsat_set_kernel_variant. Results do not depend on it."""
+        self._check(self._lib.tsat_set_kernel_variant(self._h, int(variant)), "tsat_set_kernel_variant")
+
     # ---- resident-batch API -------------------------------------------------------------------
     def upload(self, batch: SlewBatch, max_linesearch):
         self._check(self._lib.tsat_batch_reserve(self._h, batch.T, batch.N, batch.n_tab, batch.Btab.shape[0],
