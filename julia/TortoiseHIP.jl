@@ -63,6 +63,10 @@ mutable struct HIPSolver          # plays the role of AugmentedLagrangianSolver 
     end
 end
 
+"set_kernel_variant!(s, v) — 0 automatic, 1 wide (one wavefront per SIMD), 2 dense (two); results do not depend on it"
+set_kernel_variant!(s::HIPSolver, v::Integer) =
+    check(s, ccall((:tsat_set_kernel_variant, LIB), Cint, (Ptr{Cvoid}, Int32), s.handle, v), "tsat_set_kernel_variant")
+
 """
 BatchProblem: T independent slews, arrays in the reference's own shapes.
   x0, xf :: 7×T   (ω; q scalar-first — the 8th time state of src/TortoiseSat.jl:124 is dropped)
