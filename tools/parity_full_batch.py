@@ -11,14 +11,21 @@ from tortoisesat_jl_amd import trajopt as to, slew_setup as ss
 import oracle_lib as ol
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-b = ss.workload_monte_carlo(T=T, N=1000)
+what = sys.argv[2] if len(sys.argv) > 2 else "configs1"
+if what == "configs3":      # a slice of the inclination sweep (BASELINE.json configs[3]): own table per trajectory, 3 x 50 budget
+    b = ss.workload_inclination_sweep(T=T, N=1000, j0=20000)
+    budget = (3, 50)
+else:
+    b = ss.workload_monte_carlo(T=T, N=1000)
+    budget = (5, 10)
+print(f"workload {what}, budget {budget[0]} x {budget[1]}; batches above 1024 trajectories run the dense build of the kernel", flush=True)
 for es in (0, 1):
-    opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = 5
-    opts.opts_uncon.iterations = 10; opts.opts_uncon.dJ_counter_limit = 1
+    opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = budget[0]
+    opts.opts_uncon.iterations = budget[1]; opts.opts_uncon.dJ_counter_limit = 1
     s = to.AugmentedLagrangianSolver(None, opts)
     got = to.solve_(to.BatchProblem.from_arrays(b, error_state=es), s, want_K=False)
     s.close()
-    o = ol.default_options(); o.max_outer, o.max_inner, o.dj_counter_limit, o.error_state = 5, 10, 1, es
+    o = ol.default_options(); o.max_outer, o.max_inner, o.dj_counter_limit, o.error_state = budget[0], budget[1], 1, es
     t0 = time.time()
     ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False)
     dt = time.time() - t0
