@@ -148,14 +148,23 @@ def main():
         kernel_ms = float(np.mean(kms))
         bytes_launch = algorithmic_bytes(st, N)
         achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, issue = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                    pm = json.load(f)
+                traffic = pm.get("hbm_bytes_per_launch")
+                # what actually bounds this kernel: VALU instructions issued per launch (SQ_INSTS_VALU, a
+                # separate --pmc pass) against what 1024 SIMDs can issue in fp64 — one wave64 instruction per 4 cycles
+                # at 2.4 GHz — during the measured launch
+                n_valu = pm.get("sq", {}).get("SQ_INSTS_VALU")
+                if n_valu:
+                    cap = 1024 * 2.4e9 / 4.0 * kernel_ms * 1e-3
+                    issue = {"valu_insts_per_launch": n_valu, "fp64_issue_capacity": cap, "frac": n_valu / cap,
+                             "note": "one wavefront per SIMD can use about 45 % of it (profiles/r01/lane_mask_ubench.txt)"}
             except Exception:
-                traffic = None
+                traffic, issue = None, None
         out = {
             "metric": "AL-iLQR trajectory solves/sec (1000 knots)",
             "value": world * T * args.steps / elapsed,
@@ -171,7 +180,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "tsat_solve_kernel<double,3>", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": bytes_launch},
+                         "algorithmic_bytes_per_launch": bytes_launch, "fp64_issue": issue},
             "solve_stats": {"converged": int(np.sum(st["status"] == 0)), "max_outer": int(np.sum(st["status"] == 1)),
                             "reg_fail": int(np.sum(st["status"] == 2)), "diverged": int(np.sum(st["status"] == 3)),
                             "mean_inner_iters": float(st["inner_iters"].mean()),
