@@ -141,12 +141,24 @@ constexpr int L_SINK = L_ZERO + 1;       // write target of lanes without a role
 constexpr int L_UNION = L_SINK + 1;      // 424 (16-byte aligned)
 static_assert(L_UNION % 2 == 0, "phase buffers must stay 16-byte aligned");
 constexpr int L_REC = L_UNION;           // BwdCfg::CHB x BwdCfg::RECS
-constexpr int L_KDC = L_UNION;           // CK x 24
-constexpr int L_XUC = L_KDC + CK * KDW;
-constexpr int L_LMC = L_XUC + CK * XUW;
-constexpr int L_BSC = L_LMC + CK * LMW;
-constexpr int L_GTC = L_BSC + CK * BSW;   // CK x 6 activity gates of the control-box rows (see forward_sweep)
-constexpr int L_FWD_END = L_GTC + CK * LMW;
+// Forward-sweep chunk buffer (reals). The first five arrays are filled by global_load_lds_dwordx4 — 64 lanes x 16 bytes
+// = 128 reals per instruction, lane-linear — so each is padded to a whole number of instructions; FB_GT (activity gates
+// of the control-box rows, see forward_sweep) is derived from FB_LM once the copy has landed.
+constexpr int GLDS = 2 * WAVE;                                         // reals per copy instruction
+constexpr int FB_KD = 0;                                               // CK x 24 = 6 instructions
+constexpr int FB_XU = FB_KD + ((CK * KDW + GLDS - 1) / GLDS) * GLDS;   // CK x 10 -> 3 instructions
+constexpr int FB_LM = FB_XU + ((CK * XUW + GLDS - 1) / GLDS) * GLDS;   // CK x 6  -> 2 instructions
+constexpr int FB_BA = FB_LM + ((CK * LMW + GLDS - 1) / GLDS) * GLDS;   // 3 CK stage rows, (b0, b1) -> 2 instructions
+constexpr int FB_BB = FB_BA + ((CK * 3 * 2 + GLDS - 1) / GLDS) * GLDS; // 3 CK stage rows, (b2, pad) -> 2 instructions
+constexpr int FB_GT = FB_BB + ((CK * 3 * 2 + GLDS - 1) / GLDS) * GLDS; // CK x 6
+constexpr int FB_SIZE = FB_GT + CK * LMW;
+#ifdef TSAT_DENSE
+constexpr int FWD_NBUF = 1;   // 20 KB budget: one buffer; the second wavefront on the SIMD covers the copy latency
+#else
+constexpr int FWD_NBUF = 2;   // the next chunk is copied while this one is rolled out
+#endif
+constexpr int L_FWD = L_UNION;
+constexpr int L_FWD_END = L_FWD + FWD_NBUF * FB_SIZE;
 constexpr int L_BWD_END = L_REC + (BwdCfg<0>::CHB * BwdCfg<0>::RECS > BwdCfg<1>::CHB * BwdCfg<1>::RECS
                                     ? BwdCfg<0>::CHB * BwdCfg<0>::RECS : BwdCfg<1>::CHB * BwdCfg<1>::RECS);
 constexpr int LDS_REALS = (L_FWD_END > L_BWD_END ? L_FWD_END : L_BWD_END);
@@ -574,6 +586,55 @@ TSAT_DEV void coop_load(real* dst, const TSAT_GLOBAL real* src, int n) {
   for (int i = lane; i < (n >> 1); i += WAVE) d2[i] = s2[i];
 }
 
+// Issue the copy of one forward chunk (knots k0 .. k0 + nk - 1) into the chunk buffer `fb`: gains K,d (closed-loop sweeps),
+// nominal (x,u) records, control-box multipliers and the three field rows of every step. On the GPU these are
+// global_load_lds_dwordx4 instructions: no VGPR destination (the sweep is at the register cap) and no wait — the data is
+// guaranteed in LDS after the next vmcnt(0) (TSAT_SYNC). A lane past the end of a short last chunk copies the last element
+// again into the padding. The emulator copies synchronously.
+template <typename real>
+TSAT_DEV void fwd_chunk_issue(real* fb, const TSAT_GLOBAL real* KDg, const TSAT_GLOBAL real* XUg, const TSAT_GLOBAL real* LMg,
+                              const Traj<real>& tr, int k0, int nk, int closed) {
+  static_assert(sizeof(real) == 8, "16-byte copy units are two reals");
+  const int lane = TSAT_LANE();
+  const int n2k = (nk * KDW) >> 1, n2x = (nk * XUW) >> 1, n2l = (nk * LMW) >> 1, nb = nk * 3;   // in 16-byte units
+  const TSAT_GLOBAL real* kd = KDg + (size_t)k0 * KDW;
+  const TSAT_GLOBAL real* xu = XUg + (size_t)k0 * XUW;
+  const TSAT_GLOBAL real* lm = LMg + (size_t)k0 * LMW;
+#ifdef TSAT_EMU
+  auto put = [&](real* dst, const real* src) { dst[0] = src[0]; dst[1] = src[1]; };
+#else
+  typedef __attribute__((address_space(1))) const void* gp_t;
+  typedef __attribute__((address_space(3))) void* lp_t;
+  // dst: the instruction's (wave-uniform) LDS base; the hardware adds lane x 16 bytes
+  auto put = [&](real* dst, const TSAT_GLOBAL real* src) { __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)(dst - 2 * lane), 16, 0, 0); };
+#endif
+  if (closed)
+    for (int j = 0; j < (CK * KDW + GLDS - 1) / GLDS; ++j) {
+      const int i = lane + WAVE * j, ic = (i < n2k) ? i : n2k - 1;
+      put(fb + FB_KD + 2 * i, kd + 2 * ic);
+    }
+  for (int j = 0; j < (CK * XUW + GLDS - 1) / GLDS; ++j) {
+    const int i = lane + WAVE * j, ic = (i < n2x) ? i : n2x - 1;
+    put(fb + FB_XU + 2 * i, xu + 2 * ic);
+  }
+  for (int j = 0; j < (CK * LMW + GLDS - 1) / GLDS; ++j) {
+    const int i = lane + WAVE * j, ic = (i < n2l) ? i : n2l - 1;
+    put(fb + FB_LM + 2 * i, lm + 2 * ic);
+  }
+  for (int j = 0; j < (CK * 3 * 2 + GLDS - 1) / GLDS; ++j) {
+    const int e = lane + WAVE * j, ec = (e < nb) ? e : nb - 1;
+    const int kk = ec / 3, st = ec - 3 * kk;
+    const TSAT_GLOBAL real* br = tr.bt + (size_t)brow_index(tr, k0 + kk, 0.5 * (double)st) * 4;
+    put(fb + FB_BA + 2 * e, br);
+    put(fb + FB_BB + 2 * e, br + 2);
+  }
+}
+// once the copy has landed: gate = -inf where the multiplier is positive (row active whatever c is), else 0
+template <typename real>
+TSAT_DEV void fwd_chunk_gates(real* fb, int nk) {
+  for (int e = TSAT_LANE(); e < nk * LMW; e += WAVE) fb[FB_GT + e] = (fb[FB_LM + e] > 0) ? -inf_<real>() : (real)0;
+}
+
 template <typename real> struct FwdOut { real J; int ok; };
 template <typename real> struct BwdOut { real dV1, dV2; int pd_ok; };
 
@@ -596,33 +657,27 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
   const TSAT_GLOBAL real* KDg = p.KD;
   const TSAT_GLOBAL real* LMg = p.LAM;
   TSAT_GLOBAL real* Cg = p.CAND + (size_t)(lane < n_cand ? lane : 0) * (size_t)N * XUW;
-  real* KDc = lds + L_KDC;
-  real* XUc = lds + L_XUC;
-  real* LMc = lds + L_LMC;
-  real* BSc = lds + L_BSC;
-  real* GTc = lds + L_GTC;
   HalfWeights<real> hw;
   for (int i = 0; i < 7; ++i) hw.hQd[i] = (real)0.5 * tr.Qd[i];
   for (int i = 0; i < 3; ++i) hw.hRd[i] = (real)0.5 * tr.Rd[i];
   hw.hmu = (real)0.5 * mu;
+  // chunk pipeline: buffer `cur` holds the chunk being rolled out; with two buffers the copy of the next chunk is issued
+  // before the roll-out and has landed long before it ends (32 knots ~ 35 us against ~1 us of memory latency)
+  int cur = 0;
+  fwd_chunk_issue<real>(lds + L_FWD, KDg, XUg, LMg, tr, 0, (N - 1 < CK) ? N - 1 : CK, closed);
+  TSAT_SYNC();
+  fwd_chunk_gates<real>(lds + L_FWD, (N - 1 < CK) ? N - 1 : CK);
+  TSAT_SYNC_LDS();
   for (int k0 = 0; k0 < N - 1; k0 += CK) {
     const int nk = (N - 1 - k0 < CK) ? (N - 1 - k0) : CK;
-    if (closed) coop_load(KDc, KDg + (size_t)k0 * KDW, nk * KDW);
-    coop_load(XUc, XUg + (size_t)k0 * XUW, nk * XUW);
-    for (int e = lane; e < nk * LMW; e += WAVE) {
-      const real l = LMg[(size_t)k0 * LMW + e];
-      LMc[e] = l;
-      GTc[e] = (l > 0) ? -inf_<real>() : (real)0;
-    }
-    for (int e = lane; e < nk * 3; e += WAVE) {
-      const int kk = e / 3, st = e - 3 * kk;
-      const int row = brow_index(tr, k0 + kk, 0.5 * (double)st);
-      const TSAT_GLOBAL real* br = tr.bt + (size_t)row * 4;
-      BSc[kk * BSW + st * 3 + 0] = br[0];
-      BSc[kk * BSW + st * 3 + 1] = br[1];
-      BSc[kk * BSW + st * 3 + 2] = br[2];
-    }
-    TSAT_SYNC();
+    const int kn = k0 + CK, nkn = (N - 1 - kn < CK) ? (N - 1 - kn) : CK;     // next chunk (nkn <= 0: none)
+    real* fb = lds + L_FWD + cur * FB_SIZE;
+    real* fbn = lds + L_FWD + ((FWD_NBUF == 2) ? (1 - cur) : 0) * FB_SIZE;
+    if (FWD_NBUF == 2 && nkn > 0) fwd_chunk_issue<real>(fbn, KDg, XUg, LMg, tr, kn, nkn, closed);
+    const real* KDc = fb + FB_KD;
+    const real* XUc = fb + FB_XU;
+    const real* LMc = fb + FB_LM;
+    const real* GTc = fb + FB_GT;
     for (int kk = 0; kk < nk; ++kk) {
       const real* xu = XUc + kk * XUW;
       real u[3] = {xu[7], xu[8], xu[9]};
@@ -658,11 +713,22 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
         for (int c = 0; c < 3; ++c) cr[7 + c] = u[c];
       }
       real xn[7];
-      const real* bs = BSc + kk * BSW;
-      rk_step<real, INTEG, DIAGJ, ES>(tr, x, u, bs, bs + 3, bs + 6, xn);
+      const real* ba = fb + FB_BA + kk * 6;   // stage rows tau, tau + dtau/2, tau + dtau: (b0, b1) here, (b2, pad) in FB_BB
+      const real* bb = fb + FB_BB + kk * 6;
+      const real b0[3] = {ba[0], ba[1], bb[0]}, b1[3] = {ba[2], ba[3], bb[2]}, b2[3] = {ba[4], ba[5], bb[4]};
+      rk_step<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, xn);
       for (int i = 0; i < 7; ++i) x[i] = xn[i];
     }
-    TSAT_SYNC_LDS();  // the next chunk's staging writes must not overtake this chunk's LDS reads
+    if (nkn > 0) {
+      if (FWD_NBUF == 1) {          // single buffer: copy the next chunk now that this one has been consumed
+        TSAT_SYNC_LDS();
+        fwd_chunk_issue<real>(fbn, KDg, XUg, LMg, tr, kn, nkn, closed);
+      }
+      TSAT_SYNC();                  // vmcnt(0): the copy issued before (or just after) the roll-out has landed
+      fwd_chunk_gates<real>(fbn, nkn);
+      TSAT_SYNC_LDS();
+      if (FWD_NBUF == 2) cur = 1 - cur;
+    }
   }
   for (int i = 0; i < 7; ++i) amax = fmaxabs_(amax, x[i]);
   real nu[7];
