@@ -576,16 +576,6 @@ TSAT_DEV real stage_cost_gated(const Traj<real>& tr, const HalfWeights<real>& hw
   return l;
 }
 
-// cooperative copy of `n` reals (n even, 16-byte aligned both sides) global -> LDS
-template <typename real>
-TSAT_DEV void coop_load(real* dst, const TSAT_GLOBAL real* src, int n) {
-  const int lane = TSAT_LANE();
-  struct alignas(2 * sizeof(real)) R2 { real a, b; };
-  const TSAT_GLOBAL R2* s2 = reinterpret_cast<const TSAT_GLOBAL R2*>(src);
-  R2* d2 = reinterpret_cast<R2*>(dst);
-  for (int i = lane; i < (n >> 1); i += WAVE) d2[i] = s2[i];
-}
-
 // Issue the copy of one forward chunk (knots k0 .. k0 + nk - 1) into the chunk buffer `fb`: gains K,d (closed-loop sweeps),
 // nominal (x,u) records, control-box multipliers and the three field rows of every step. On the GPU these are
 // global_load_lds_dwordx4 instructions: no VGPR destination (the sweep is at the register cap) and no wait — the data is
