@@ -72,6 +72,7 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
   return 0;
 }
 
+#ifndef TSAT_DENSE   // the dense build exists for the solve kernel only (tortoisesat.jl_amd/csrc/tsat_kernels_dense.hip)
 template <int DIAGJ>
 static void run_mpc_block(const MpcArgs<double>& a, int traj) {
   std::vector<double> lds(LDS_REALS, 0.0);
@@ -212,3 +213,4 @@ extern "C" int emu_btable_batch(const tsat_btable_options* o, int64_t T, const d
   if (pos) std::memcpy(pos, P.data(), P.size() * sizeof(double));
   return 0;
 }
+#endif  // TSAT_DENSE

@@ -576,6 +576,21 @@ TSAT_DEV real stage_cost_gated(const Traj<real>& tr, const HalfWeights<real>& hw
   return l;
 }
 
+// One 16-byte element per lane, global -> LDS, lane-linear: `dst` is THIS lane's destination (base + 2 lane reals; the
+// instruction takes the wave-uniform base and adds lane x 16 bytes itself). No VGPR destination, no wait: the data is
+// in LDS after the next vmcnt(0). The emulator copies synchronously.
+template <typename real>
+TSAT_DEV void glds_put(real* dst, const TSAT_GLOBAL real* src) {
+  static_assert(sizeof(real) == 8, "16-byte copy units are two reals");
+#ifdef TSAT_EMU
+  dst[0] = src[0]; dst[1] = src[1];
+#else
+  typedef __attribute__((address_space(1))) const void* gp_t;
+  typedef __attribute__((address_space(3))) void* lp_t;
+  __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)(dst - 2 * TSAT_LANE()), 16, 0, 0);
+#endif
+}
+
 // Issue the copy of one forward chunk (knots k0 .. k0 + nk - 1) into the chunk buffer `fb`: gains K,d (closed-loop sweeps),
 // nominal (x,u) records, control-box multipliers and the three field rows of every step. On the GPU these are
 // global_load_lds_dwordx4 instructions: no VGPR destination (the sweep is at the register cap) and no wait — the data is
@@ -590,14 +605,7 @@ TSAT_DEV void fwd_chunk_issue(real* fb, const TSAT_GLOBAL real* KDg, const TSAT_
   const TSAT_GLOBAL real* kd = KDg + (size_t)k0 * KDW;
   const TSAT_GLOBAL real* xu = XUg + (size_t)k0 * XUW;
   const TSAT_GLOBAL real* lm = LMg + (size_t)k0 * LMW;
-#ifdef TSAT_EMU
-  auto put = [&](real* dst, const real* src) { dst[0] = src[0]; dst[1] = src[1]; };
-#else
-  typedef __attribute__((address_space(1))) const void* gp_t;
-  typedef __attribute__((address_space(3))) void* lp_t;
-  // dst: the instruction's (wave-uniform) LDS base; the hardware adds lane x 16 bytes
-  auto put = [&](real* dst, const TSAT_GLOBAL real* src) { __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)(dst - 2 * lane), 16, 0, 0); };
-#endif
+  auto put = [&](real* dst, const TSAT_GLOBAL real* src) { glds_put<real>(dst, src); };
   if (closed)
     for (int j = 0; j < (CK * KDW + GLDS - 1) / GLDS; ++j) {
       const int i = lane + WAVE * j, ic = (i < n2k) ? i : n2k - 1;
@@ -1504,17 +1512,37 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
   const long long gid = a.nid ? a.nid[traj] : (long long)traj;
   constexpr int NZK = WAVE / 4;            // knots per generated chunk: lanes = (knot, RK4 stage) pairs
   real* nzl = lds + L_UNION;               // [NZK][4][9]; the Jacobian records that lived here are spent
+  // reference records, gains and field rows of CK knots at a time through the forward sweep's chunk buffer
+  // (global_load_lds, one exposed memory latency per chunk instead of one per knot); array-mode noise rides along
+  real* fb = nzl + NZK * 36;
+  real* nzc = fb + FB_SIZE;                // [CK][4][9] noise of the chunk (array mode)
+  static_assert(L_UNION + NZK * 36 + FB_SIZE + CK * 36 <= LDS_REALS + 0 * (int)sizeof(real),
+                "tracking buffers fit the wave's LDS block (wide build only; the dense build has the solve kernel alone)");
   real x[7];
   for (int i = 0; i < 7; ++i) x[i] = lds[L_TR + P_X0 + i];
   for (int k = 0; k < N - 1; ++k) {
+    if ((k % CK) == 0) {
+      const int nk = (N - 1 - k < CK) ? (N - 1 - k) : CK;
+      TSAT_SYNC_LDS();
+      fwd_chunk_issue<real>(fb, p.KD, p.XU, p.XU, tr, k, nk, 1);   // the multiplier slot is not used here: any valid source
+      if (NZg) {
+        const int n2 = (nk * 36) >> 1;
+        for (int j = 0; j < (CK * 36 + GLDS - 1) / GLDS; ++j) {
+          const int i = lane + WAVE * j, ic = (i < n2) ? i : n2 - 1;
+          glds_put<real>(nzc + 2 * i, NZg + (size_t)k * 36 + 2 * ic);
+        }
+      }
+      TSAT_SYNC();
+    }
     if (gen && (k % NZK) == 0) {
       TSAT_SYNC();
       const int kk = k + (lane >> 2);
       if (kk < N - 1) plant_noise<real>(a.k0, a.k1, gid, kk, lane & 3, a.sg, a.sa, a.fa, nzl + lane * 9);
       TSAT_SYNC();
     }
-    const TSAT_GLOBAL real* xr = p.XU + (size_t)k * XUW;
-    const TSAT_GLOBAL real* kd = p.KD + (size_t)k * KDW;
+    const int kc = k % CK;
+    const real* xr = fb + FB_XU + kc * XUW;
+    const real* kd = fb + FB_KD + kc * KDW;
     real dX[6];
     for (int i = 0; i < 3; ++i) dX[i] = x[i] - xr[i];
     {  // vector part of q_ref^-1 (x) q_sim  (:42)
@@ -1533,16 +1561,14 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
       for (int i = 0; i < 7; ++i) XSg[(size_t)k * XUW + i] = x[i];
       for (int c = 0; c < 3; ++c) XSg[(size_t)k * XUW + 7 + c] = u[c];
     }
-    real b0[3], b1[3], b2[3];
-    const TSAT_GLOBAL real* p0 = tr.bt + (size_t)brow_index(tr, k, 0.0) * 4;
-    const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
-    const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
-    for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
+    const real* ba = fb + FB_BA + kc * 6;
+    const real* bb = fb + FB_BB + kc * 6;
+    const real b0[3] = {ba[0], ba[1], bb[0]}, b1[3] = {ba[2], ba[3], bb[2]}, b2[3] = {ba[4], ba[5], bb[4]};
     real nz[36];
     if (gen) {
       for (int i = 0; i < 36; ++i) nz[i] = nzl[(k % NZK) * 36 + i];
     } else if (NZg) {
-      for (int i = 0; i < 36; ++i) nz[i] = NZg[(size_t)k * 36 + i];
+      for (int i = 0; i < 36; ++i) nz[i] = nzc[kc * 36 + i];
     } else {
       for (int i = 0; i < 36; ++i) nz[i] = 0;
     }
