@@ -348,3 +348,14 @@ def _rk3_numpy(x, u, b):
     k2 = f(x + k1 / 2, b0) * h
     k3 = f(x - k1 + 2 * k2, b2) * h
     return x + (k1 + 4 * k2 + k3) / 6
+
+
+def test_gpu_example_script_runs(pkg):
+    """examples/single_slew.py: the reference's single-slew script end to end (field table, horizon, solve, tracking)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("single_slew", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "single_slew.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(verbose=False)
+    assert out["N"] > 100 and out["stats"]["status"] in (0, 1) and np.all(np.isfinite(out["X"])) and np.all(np.abs(out["U"]) <= 1 + 1e-3)
