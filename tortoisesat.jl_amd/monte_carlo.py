@@ -108,7 +108,7 @@ def build_batch(ids, t_final, B_fine, seed, s):
     U0 = np.zeros((T, N - 1, 3))
     for j, i in enumerate(ids):
         n = int(n_knots[j])
-        wg, _ = eigen_axis_slew(x0, xf, s.t0 + s.dt * np.arange(n))
+        wg, _ = eigen_axis_slew(x0, xf, s.t0 + s.dt * np.arange(n), rates_only=True)
         Qd[j], Qfd[j], Rd[j] = bryson_weights(wg, J, s.dt, s.alpha, s.beta)
         r = trial_rng(seed, i)
         r.random(2)                                                                          # the orbit draws

@@ -61,8 +61,9 @@ def axis_angle_quat(axis, angle_rad):
 # --------------------------------------------------------------------------------------------------
 # eigen-axis guess + Bryson weights
 # --------------------------------------------------------------------------------------------------
-def eigen_axis_slew(x0, xf, t):
+def eigen_axis_slew(x0, xf, t, rates_only=False):
     """Versine eigen-axis guess (omega_guess (n,3), q_guess (n,4)), src/eigen_axis_slew.jl:1-38.
+    ``rates_only`` skips the quaternion history (the Bryson weights need the rates alone) and returns (omega_guess, None).
 
     Reproduces the reference's line 16 literally: ``qmult([q2;-q2[2:4]],q1)`` only reads the first four
     entries of its first argument, i.e. it multiplies by q2 itself, not by its conjugate.
@@ -79,6 +80,8 @@ def eigen_axis_slew(x0, xf, t):
     d_theta = np.diff(theta) / (t[1] - t[0])
     d_theta = np.append(d_theta, d_theta[-1])
     w_guess = d_theta[:, None] * axis[None, :]
+    if rates_only:
+        return w_guess, None
     dq = np.concatenate([np.cos(theta / 2.0)[:, None], axis[None, :] * np.sin(theta / 2.0)[:, None]], axis=1)
     q_guess = qmult(q1[None, :], dq)
     return w_guess, q_guess
