@@ -180,8 +180,9 @@ def summarize(out):
                 number_sims=int(st.shape[0]))
 
 
-def monte_carlo(stages, number_sims=100, seed=0, setup=None, rank=0, world=1, group=None, chunk=256, device=None):
-    """The whole experiment over `world` ranks: each rank runs a contiguous block of trials in chunks, then the
+def monte_carlo(stages, number_sims=100, seed=0, setup=None, rank=0, world=1, group=None, chunk=1024, device=None):
+    """The whole experiment over `world` ranks: each rank runs a contiguous block of trials in chunks (1024 = one
+    wavefront per SIMD of an MI355X), then the
     per-trial summaries (A, t_final, slew_time, fails) are all-gathered in trial order (the result lists the script
     appends to, src/monte_carlo.jl:60-66). Trajectories stay on the rank that produced them."""
     from .sweep import shard_range
