@@ -115,6 +115,11 @@ def build_batch(ids, t_final, B_fine, seed, s):
         U0[j, : n - 1] = r.random((n - 1, 3)) / 1000.0                                       # (:193)
     rows_per_s = s.N / (t_final - s.t0) if s.field_rate == "physical" else np.full(T, s.N / (s.tf - s.t0))
     c = np.ascontiguousarray
+    # the table has 2N rows over 2 t_final (src/magnetic_toolbox.jl:73); the solve reads rows 0 .. N (+ the stage rows of
+    # the last step), so only those travel to the solver
+    n_rows = min(B_fine.shape[1], s.N + 8)
+    assert np.all((n_knots.astype(np.float64) - 1.0) * s.dt * rows_per_s < n_rows - 1)     # last row any RK stage reads
+    B_fine = B_fine[:, :n_rows]
     b = SlewBatch(N=N, n_tab=B_fine.shape[1], x0=c(np.tile(x0, (T, 1))), xf=c(np.tile(xf, (T, 1))), Btab=c(B_fine),
                   btab_idx=np.arange(T, dtype=np.int32), tau0=np.zeros(T), dtau=c(s.dt * rows_per_s), dt=np.full(T, s.dt),
                   Jmat=c(np.tile(jmat_cm(J), (T, 1))), Qd=Qd, Qfd=Qfd, Rd=Rd, ulo=np.full((T, 3), -s.u_bnd),
