@@ -146,7 +146,8 @@ int  tsat_batch_upload(tsat_handle* h,
  * Arrays keep the common stride N; U0 entries beyond a trajectory's horizon are ignored and its X/U/K slabs are
  * returned zero-filled beyond it. Call after tsat_batch_upload. */
 int  tsat_batch_knots(tsat_handle* h, const int32_t* n_knots /* T */);
-/* run the solve on the resident batch (always restarts from the uploaded U0); blocks until done.
+/* run the solve on the resident batch; blocks until done. It starts from the RESIDENT x0 / tau0 / U0: those are the uploaded
+ * ones unless tsat_mpc_run has advanced them since (see there) — upload again to start over.
  * *kernel_ms (may be NULL) receives the HIP-event time of the solve kernel on the handle's stream. */
 int  tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms);
 /* unpack results to HOST buffers (any may be NULL) */
@@ -251,8 +252,10 @@ int  tsat_tvlqr_resident(tsat_handle* h, const tsat_tvlqr_options* o, const doub
  *   3. advance the noise-free plant one step with u_t: rk3 or rk4 (plant_integrator 3 | 4) of the model dynamics
  *      (src/DerivFunction.jl:1-48) over dt, table rows at the current table time;
  *   4. warm start of the next solve = the plan shifted by one knot, last control repeated; tau0 += dtau.
- * Nothing returns to the host between steps. Afterwards the resident batch holds the advanced x0 / tau0 / warm start
- * and the last plan (tsat_batch_download); a further call continues the simulation.
+ * Nothing returns to the host between steps. tsat_mpc_run MUTATES the resident batch: afterwards it holds the advanced
+ * x0 / tau0, the shifted warm start in place of the uploaded U0, and the last plan (tsat_batch_download); a further call
+ * continues the simulation, tsat_batch_run re-solves from the advanced state, and tsat_tvlqr_resident tracks the last plan
+ * from the advanced table clock (the handle's host copies of x0 / tau0 are refreshed from the device after the loop).
  *   X_hist 7 x (n_steps+1) x T   states x_0 .. x_{n_steps}
  *   U_hist 3 x n_steps x T       applied controls
  *   stats_last T (may be NULL)   statistics of the last solve

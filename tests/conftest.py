@@ -144,12 +144,26 @@ def oracle_options(ol, **kw):
 COUNT_FIELDS = ("status", "outer_iters", "inner_iters", "ls_trials", "n_backward", "bp_restarts", "fp_fails")
 
 
+def parity_errors(ref, got):
+    """per-trajectory (|dX|_inf, |dU|_inf / max(1, |U_ref|_inf)) — the two numbers the fp64 parity bar is stated on"""
+    ax = tuple(range(1, ref["X"].ndim))
+    dX = np.max(np.abs(ref["X"] - got["X"]), axis=ax)
+    scale = np.maximum(1.0, np.max(np.abs(ref["U"]), axis=ax)) if ref["U"].size else np.ones_like(dX)
+    dU = (np.max(np.abs(ref["U"] - got["U"]), axis=ax) if ref["U"].size else np.zeros_like(dX)) / scale
+    return dX, dU
+
+
 def assert_same_solution(ref, got, tol=1e-9, counts=True):
-    """fp64 parity bar: 1e-9 absolute on X and U at equal iteration counts."""
+    """fp64 parity bar: identical iteration / line-search / restart counts, and on EVERY
+    trajectory |dX|_inf < 1e-9 (states are O(1): unit quaternion, rates << 1 rad/s) and |dU|_inf < 1e-9 max(1, |U|_inf)
+    — the controls are stored in units of u_scale = 0.01 A m^2 and reach the box |u| <= 19 on the Monte-Carlo workloads
+    (|u| <= 1 on the single slew), so the bar on U is 1e-9 of the trajectory's own control scale, never looser than 1e-9
+    times the bound."""
     if counts:
         for f in COUNT_FIELDS:
             assert np.array_equal(ref["stats"][f], got["stats"][f]), f
-    assert np.max(np.abs(ref["X"] - got["X"])) < tol
-    assert np.max(np.abs(ref["U"] - got["U"])) < tol
+    dX, dU = parity_errors(ref, got)
+    assert np.max(dX) < tol, (float(np.max(dX)), int(np.argmax(dX)))
+    assert np.max(dU) < tol, (float(np.max(dU)), int(np.argmax(dU)))
     np.testing.assert_allclose(got["stats"]["cost"], ref["stats"]["cost"], rtol=1e-9)
     np.testing.assert_allclose(got["stats"]["c_max"], ref["stats"]["c_max"], rtol=1e-7, atol=1e-10)

@@ -35,8 +35,7 @@ def test_golden_covers_the_edge_paths(pkg, ol):
 @pytest.mark.parametrize("N", [2, 3, 33, 34, 49, 50])
 def test_emulated_kernel_ragged_knot_counts(pkg, ol, emu, N):
     """N-1 below / at / just above the forward (32) and backward (48) LDS chunk sizes; N = 2 is the minimum."""
-    b = pkg.slew_setup.workload_monte_carlo(T=1, N=N, seed=100 + N)
-    b.Rd[~np.isfinite(b.Rd)] = 0.03      # N = 2: the eigen-axis guess has no acceleration sample -> Bryson R undefined
+    b = pkg.slew_setup.workload_monte_carlo(T=1, N=N, seed=100 + N, degenerate_rd=0.03)   # N = 2: no acceleration sample in the guess -> Bryson R undefined
     o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1)
     assert_same_solution(ol.solve_batch(b, o), emu.solve(b, o))
 
@@ -114,8 +113,7 @@ def test_oracle_openmp_matches_serial(pkg, ol):
 @pytest.mark.parametrize("N", [2, 53, 54])
 def test_emulated_kernel_error_state_mode(pkg, ol, emu, N):
     """error_state = 1 (quaternion hooks, src/monte_carlo.jl:158): ragged sizes around the 52-knot backward chunk"""
-    b = pkg.slew_setup.workload_monte_carlo(T=1, N=N, seed=300 + N)
-    b.Rd[~np.isfinite(b.Rd)] = 0.03
+    b = pkg.slew_setup.workload_monte_carlo(T=1, N=N, seed=300 + N, degenerate_rd=0.03)   # N = 2: no acceleration sample in the guess -> Bryson R undefined
     o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1, error_state=1)
     assert_same_solution(ol.solve_batch(b, o), emu.solve(b, o))
 

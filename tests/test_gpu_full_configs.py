@@ -1,0 +1,119 @@
+"""GPU tier, full size: every BASELINE.json config at (shard) size against the CPU oracle on EVERY trajectory — the bar
+of conftest.assert_same_solution (identical counts; |dX| < 1e-9; |dU| < 1e-9 of the control scale) must hold for the worst
+trajectory of each batch, in every build of the solve kernel that the size selects.
+
+  configs[1]  1024 x 1000 knots, 5 x 10, one orbit      hooks off (registered API) and on (src/monte_carlo.jl:158)
+  configs[2]  random orbit per trajectory, 1000 knots   fp64 inputs here; the fp32 build is tested in test_gpu_fp32.py
+  configs[3]  inclination-sweep slice, 1000 knots, 3 x 50, own table per trajectory, the large-batch build
+  configs[4]  512 x 200-knot horizon x 1000 control steps: properties on all, oracle loop on a sub-sample
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_same_solution, oracle_options, parity_errors
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver(pkg):
+    s = pkg.trajopt.AugmentedLagrangianSolver(None, None, device=0)
+    yield s
+    s.close()
+
+
+def _gpu(pkg, solver, b, o, variant=0):
+    import helpers
+    a = helpers.abi_options_like(o, pkg, b.N, b.n_tab)
+    solver.set_kernel_variant(variant)
+    solver.upload(b, a.max_linesearch)
+    solver.run(a)
+    solver.set_kernel_variant(0)
+    return solver.download(want_K=False)
+
+
+def _report(name, ref, got):
+    dX, dU = parity_errors(ref, got)
+    print(f"[{name}] {len(dX)} trajectories: max|dX| {dX.max():.2e}, max|dU|/scale {dU.max():.2e}, "
+          f"max|dU| {np.max(np.abs(ref['U'] - got['U'])):.2e}")
+
+
+@pytest.mark.parametrize("es", [0, 1])
+def test_gpu_configs1_every_trajectory(pkg, ol, solver, es):
+    b = pkg.slew_setup.workload_monte_carlo(T=1024, N=1000)
+    o = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, error_state=es)
+    ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False)
+    got = _gpu(pkg, solver, b, o)
+    _report(f"configs[1] error_state={es}", ref, got)
+    assert_same_solution(ref, got)
+
+
+def test_gpu_configs2_inputs_fp64(pkg, ol, solver):
+    b = pkg.slew_setup.workload_monte_carlo(T=512, N=1000, seed=20190531, random_orbit=True)
+    o = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, error_state=1)
+    ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False)
+    for variant in (1, 2):
+        got = _gpu(pkg, solver, b, o, variant)
+        _report(f"configs[2] inputs fp64, build {variant}", ref, got)
+        assert_same_solution(ref, got)
+
+
+def test_gpu_configs3_slice_large_batch_build(pkg, ol, solver):
+    """1024 consecutive trajectories out of the middle of the 65536-trajectory inclination sweep, 3 x 50 budget"""
+    b = pkg.slew_setup.workload_inclination_sweep(T=1024, N=1000, j0=20000)
+    o = oracle_options(ol, max_outer=3, max_inner=50, dj_counter_limit=1)
+    ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False)
+    got = _gpu(pkg, solver, b, o, variant=2)
+    _report("configs[3] slice, dense build", ref, got)
+    assert_same_solution(ref, got)
+
+
+def test_gpu_configs4_shard(pkg, ol):
+    """512 trajectories x 200-knot horizon x 1000 control steps (1 x 3 budget, rk4 plant)"""
+    to, mpc, ss = pkg.trajopt, pkg.mpc, pkg.slew_setup
+    T, N, steps = 512, 200, 1000
+    b = ss.workload_monte_carlo(T=T, N=N, seed=77)
+    rows = N + steps + 8
+    b.Btab, b.n_tab = np.ascontiguousarray(ss.dipole_btable(rows, 0.2, 6771.0, 96.6)[None]), rows
+    b.dtau[:] = 1.0
+    s = to.AugmentedLagrangianSolver(None, to.AugmentedLagrangianSolverOptions())
+    s.opts.opts_uncon.dJ_counter_limit = 1
+    got = mpc.receding_horizon(to.BatchProblem.from_arrays(b), s, steps, plant_integrator=4)
+    again = mpc.receding_horizon(to.BatchProblem.from_arrays(b), s, steps, plant_integrator=4)
+    s.close()
+    Xh, Uh = got["X_hist"], got["U_hist"]
+    assert np.all(np.isfinite(Xh)) and np.all(np.isfinite(Uh))
+    assert np.array_equal(Xh, again["X_hist"]) and np.array_equal(Uh, again["U_hist"])                  # deterministic
+    assert np.array_equal(Xh[:, 0], b.x0)
+    assert np.max(np.abs(Uh)) <= 19.0 * (1 + 1e-2)              # the box is an AL constraint: small violations only
+    # the recorded history is the rk4 plant driven by the recorded controls (vectorised NumPy restatement)
+    Jd = 0.00125
+
+    def f(x, u, bb):
+        w, q = x[..., :3], x[..., 3:]
+        q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+        sq, v = q[..., :1], q[..., 1:]
+        qd = 0.5 * np.concatenate([-np.sum(v * w, -1, keepdims=True), sq * w + np.cross(v, w)], -1)
+        BB = bb + 2 * np.cross(v, np.cross(v, bb) + sq * bb)
+        return np.concatenate([np.cross(u * 1e-2, BB) / Jd, qd], -1)
+
+    B = b.Btab[0]
+    for t in (0, 1, 499, 998, 999):
+        x, u, r0, r1 = Xh[:, t], Uh[:, t], B[t], B[t + 1]
+        k1 = f(x, u, r0) * 0.2; k2 = f(x + k1 / 2, u, r0) * 0.2; k3 = f(x + k2 / 2, u, r0) * 0.2; k4 = f(x + k3, u, r1) * 0.2
+        assert np.max(np.abs(x + (k1 + 2 * k2 + 2 * k3 + k4) / 6 - Xh[:, t + 1])) < 1e-13
+    # closed loop does its job: the penalised attitude distance shrinks on the bulk of the batch
+    d0 = np.linalg.norm(Xh[:, 0, 3:7] - b.xf[:, 3:7], axis=1); d1 = np.linalg.norm(Xh[:, -1, 3:7] - b.xf[:, 3:7], axis=1)
+    assert np.median(d1) < 0.2 * np.median(d0)
+    # oracle loop on a sub-sample (the trajectories are independent: a shard alone equals its rows of the batch)
+    idx = [0, 137, 300, 511]
+    sub = b.slice(0, 1)
+    for f_ in ("x0", "xf", "btab_idx", "tau0", "dtau", "dt", "Jmat", "Qd", "Qfd", "Rd", "ulo", "uhi", "U0"):
+        setattr(sub, f_, np.ascontiguousarray(getattr(b, f_)[idx]))
+    o = oracle_options(ol, max_outer=1, max_inner=3, dj_counter_limit=1)
+    ref = ol.mpc_batch(sub, o, steps, plant_integrator=4, nthreads=4)
+    dX = np.max(np.abs(ref["X_hist"] - Xh[idx])); dU = np.max(np.abs(ref["U_hist"] - Uh[idx]))
+    print(f"[configs[4] shard] oracle sub-sample of {len(idx)}: max|dX_hist| {dX:.2e}, max|dU_hist| {dU:.2e}")
+    assert dX < 1e-9 and dU < 1e-9 * 19.0
+    for k in ("inner_iters", "ls_trials", "status"):
+        assert np.array_equal(ref["stats"][k], got["stats"][k][idx]), k

@@ -49,8 +49,7 @@ def test_gpu_reproduces_golden(pkg, ol, solver, name):
 # ----------------------------------------------------------------------------------------------- oracle parity
 @pytest.mark.parametrize("N", [2, 3, 33, 34, 49, 50, 97])
 def test_gpu_ragged_knot_counts(pkg, ol, solver, N):
-    b = pkg.slew_setup.workload_monte_carlo(T=5, N=N, seed=100 + N)
-    b.Rd[~np.isfinite(b.Rd)] = 0.03      # N = 2: the eigen-axis guess has no acceleration sample -> Bryson R undefined
+    b = pkg.slew_setup.workload_monte_carlo(T=5, N=N, seed=100 + N, degenerate_rd=0.03)   # N = 2: no acceleration sample in the guess -> Bryson R undefined
     o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1)
     assert_same_solution(ol.solve_batch(b, o), gpu_solve(pkg, solver, b, o))
 
@@ -82,8 +81,7 @@ def test_gpu_error_state_mode_1000_knots(pkg, ol, solver):
 
 @pytest.mark.parametrize("N", [2, 53, 54, 105])
 def test_gpu_error_state_ragged(pkg, ol, solver, N):
-    b = pkg.slew_setup.workload_monte_carlo(T=3, N=N, seed=300 + N)
-    b.Rd[~np.isfinite(b.Rd)] = 0.03
+    b = pkg.slew_setup.workload_monte_carlo(T=3, N=N, seed=300 + N, degenerate_rd=0.03)   # N = 2: no acceleration sample in the guess -> Bryson R undefined
     for integ in (3, 4):
         o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1, error_state=1, integrator=integ)
         assert_same_solution(ol.solve_batch(b, o), gpu_solve(pkg, solver, b, o))

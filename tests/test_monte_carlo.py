@@ -32,6 +32,17 @@ def test_script_arithmetic(pkg, ol):
     assert list(sm["fails"]) == list(np.nonzero(out["fails"])[0])
 
 
+def test_knot_counts_follow_julia_range_length(pkg):
+    """length(range(0, step=.2, stop=idx*0.48)) (src/monte_carlo.jl:140,145): Julia counts float ranges in twice precision,
+    so horizon indices that are multiples of 5 (2.4/0.2 = 11.999999999999998 in plain fp64) must not lose their last knot"""
+    mc = pkg.monte_carlo
+    idx = np.arange(1, 5001)
+    n = mc.knot_counts(idx * 2400.0 / 5000, 0.0, 0.2)
+    assert np.array_equal(n, (idx * 12) // 5 + 1)                      # exact rational count for the script's constants
+    assert list(mc.knot_counts(np.array([5, 10, 20]) * 0.48, 0.0, 0.2)) == [13, 25, 49]
+    assert list(mc.knot_counts(np.array([2.4, 2.39999, 2.5, 0.2]), 0.0, 0.2)) == [13, 12, 13, 2]
+
+
 def test_field_replay_rate_option(pkg, ol):
     """the script replays the resampled table at 1/(tf - t0) of the COARSE span; "physical" at its own"""
     mc = pkg.monte_carlo

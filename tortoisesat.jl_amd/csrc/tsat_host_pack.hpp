@@ -48,6 +48,35 @@ inline int inertia_class(int64_t T, const double* Jmat) {
   return cls;
 }
 
+// validate the per-trajectory inputs of an upload; returns "" or an error text. A non-finite weight or bound (e.g. the
+// reference's R = 1/m_max^2 with m_max = 0 for a two-knot guess) or a singular inertia would otherwise only show up as a
+// DIVERGED status or a nonsense cost.
+inline std::string check_inputs(int64_t T, const double* x0, const double* xf, const double* tau0, const double* dtau,
+                                const double* dt, const double* Jmat, const double* Qd, const double* Qfd,
+                                const double* Rd, const double* ulo, const double* uhi) {
+  auto finite = [](const double* a, int64_t n) {
+    for (int64_t i = 0; i < n; ++i)
+      if (!std::isfinite(a[i])) return false;
+    return true;
+  };
+  if (!finite(x0, 7 * T) || !finite(xf, 7 * T)) return "x0 / xf must be finite";
+  if (!finite(tau0, T) || !finite(dtau, T)) return "tau0 / dtau must be finite";
+  if (!finite(Qd, 7 * T) || !finite(Qfd, 7 * T) || !finite(Rd, 3 * T)) return "Qd / Qfd / Rd must be finite (Bryson weights of a degenerate guess?)";
+  if (!finite(ulo, 3 * T) || !finite(uhi, 3 * T)) return "ulo / uhi must be finite";
+  for (int64_t t = 0; t < T; ++t) {
+    if (!(dt[t] > 0.0) || !std::isfinite(dt[t])) return "dt must be positive";
+    for (int a = 0; a < 3; ++a)
+      if (!(ulo[3 * t + a] <= uhi[3 * t + a])) return "ulo must not exceed uhi";
+    const double* J = Jmat + 9 * t;
+    if (!finite(J, 9)) return "Jmat must be finite";
+    const double det = J[0] * (J[4] * J[8] - J[7] * J[5]) - J[3] * (J[1] * J[8] - J[7] * J[2]) + J[6] * (J[1] * J[5] - J[4] * J[2]);
+    double nrm = 0;
+    for (int i = 0; i < 9; ++i) nrm = std::fmax(nrm, std::fabs(J[i]));
+    if (!(std::fabs(det) > 1e-12 * nrm * nrm * nrm)) return "Jmat is singular";
+  }
+  return "";
+}
+
 // validate an options block against a reserved batch; returns "" or an error text
 inline std::string check_options(const tsat_options& o, int N, int n_tab, int max_ls_reserved) {
   if (o.n_knots != N) return "options.n_knots does not match the reserved batch";

@@ -228,8 +228,8 @@ int tsat_batch_upload(tsat_handle* h, const double* x0, const double* xf, const 
     if (v < 0 || v >= h->n_btab) return fail(h, -1, "btab_idx out of range");
     bi[(size_t)t] = (int)v;
   }
-  for (int64_t t = 0; t < T; ++t)
-    if (!(dt[t] > 0.0)) return fail(h, -1, "dt must be positive");
+  const std::string bad = check_inputs(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi);
+  if (!bad.empty()) return fail(h, -1, bad);
   h->inertia_class = inertia_class(T, Jmat);
   std::vector<double> P((size_t)T * PSTRIDE), BT((size_t)h->n_btab * h->n_tab * 4);
   pack_params<double>(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, P.data());
@@ -353,9 +353,17 @@ int tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t
   if (!rc && hipMemcpy(X_hist, dHX, nX * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && hipMemcpy(U_hist, dHU, nU * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && stats_last && hipMemcpy(stats_last, h->stats, T * sizeof(tsat_stats), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  // the loop advanced x0 and tau0 inside the device parameter records: refresh the host mirrors tsat_tvlqr_resident packs
+  // its own records from, so that tracking after an MPC run linearises against the field rows the last plan was solved on
+  std::vector<double> Pb(T * PSTRIDE);
+  if (!rc && hipMemcpy(Pb.data(), h->P, Pb.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   (void)hipFree(dHX);
   (void)hipFree(dHU);
-  if (rc) return fail(h, rc, "launch or copy failed in tsat_mpc_run");
+  if (rc) { h->solved = false; return fail(h, rc, "launch or copy failed in tsat_mpc_run"); }
+  for (size_t t = 0; t < T; ++t) {
+    for (int i = 0; i < 7; ++i) h->hx0[7 * t + i] = Pb[t * PSTRIDE + P_X0 + i];
+    h->htau0[t] = Pb[t * PSTRIDE + P_TAU0];
+  }
   h->solved = true;
   return 0;
 }
@@ -448,7 +456,7 @@ int run_tvlqr(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int N, int
   A((void**)&dKD, nKD * 8); A((void**)&dXS, nXS * 8); A((void**)&dst, Tn * sizeof(tsat_tvlqr_stats));
   if (o->noise_mode == 1 && noise_id) { A((void**)&dnid, Tn * sizeof(long long)); C(dnid, noise_id, Tn * sizeof(long long)); }
   // ragged batch: the slabs beyond a trajectory's own horizon stay zero
-  if (dnk && !rc && (hipMemset(dKD, 0, nKD * 8) != hipSuccess || hipMemset(dXS, 0, nXS * 8) != hipSuccess)) rc = -10;
+  if (dnk && !rc && (hipMemsetAsync(dKD, 0, nKD * 8, h->stream) != hipSuccess || hipMemsetAsync(dXS, 0, nXS * 8, h->stream) != hipSuccess)) rc = -10;
   if (!rc) {
     TvArgs<double> a;
     a.T = (int)T; a.N = N; a.n_tab = n_tab; a.lin_sq = o->linearize_dt_sq; a.min_steps = o->min_steps;

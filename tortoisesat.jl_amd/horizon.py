@@ -32,6 +32,8 @@ def condition_based_time(solver, Btab, dt_row, cutoff):
 
 
 def knots_from_index(tf_index, span, n_rows, dt=0.2, t0=0.0):
-    """t_final = index*(tf-t0)/N and N_knots = floor((t_final-t0)/dt) (src/TortoiseSat.jl:82-85)."""
+    """t_final = index*(tf-t0)/N and N_knots = floor((t_final-t0)/dt) (src/TortoiseSat.jl:82-85). This is the single-slew
+    script's `convert(Int64,floor((t_final-t0)/dt))`, a plain fp64 floor (2.4/0.2 -> 11), reproduced as written; the
+    Monte-Carlo script's `range(t0,step=.2,stop=t_final)` counts in twice precision — `monte_carlo.knot_counts`."""
     t_final = np.asarray(tf_index, dtype=np.float64) * float(span) / float(n_rows)
     return t_final, np.floor((t_final - t0) / dt).astype(np.int32)

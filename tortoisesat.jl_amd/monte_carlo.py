@@ -95,11 +95,20 @@ def draw_orbits(seed, lo, hi, s):
     return A
 
 
+def knot_counts(t_final, t0, dt):
+    """length(range(t0, step=dt, stop=t_final)) (src/monte_carlo.jl:145). Julia builds a float range in twice precision, so
+    0:0.2:2.4 has 13 elements although 2.4/0.2 evaluates to 11.999999999999998 in plain fp64; with the script's constants
+    (t_final = idx*0.48) that hits every idx that is a multiple of 5. The quotient is therefore floored with a relative
+    guard of a few ulps instead of bare ``floor``."""
+    q = (np.asarray(t_final, dtype=np.float64) - t0) / dt
+    return (np.floor(q * (1.0 + 8.0 * np.finfo(np.float64).eps) + 1e-12).astype(np.int64) + 1).astype(np.int32)
+
+
 def build_batch(ids, t_final, B_fine, seed, s):
     """Guess, weights and the ragged batch of trials `ids` (global indices) whose horizon was found
     (src/monte_carlo.jl:145-193)."""
     T = len(ids)
-    n_knots = (np.floor((t_final - s.t0) / s.dt).astype(np.int64) + 1).astype(np.int32)     # length(t0:0.2:t_final)
+    n_knots = knot_counts(t_final, s.t0, s.dt)                                               # length(t0:0.2:t_final)
     N = int(n_knots.max())
     J = INERTIA[s.inertia]
     x0 = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])                                       # (:107-110)

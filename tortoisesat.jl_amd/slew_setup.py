@@ -74,6 +74,9 @@ def eigen_axis_slew(x0, xf, t, rates_only=False):
     q1, q2 = x0[3:7], xf[3:7]
     q_e = qmult(q2, q1)
     theta_f = 2.0 * np.arccos(np.clip(q_e[0], -1.0, 1.0))
+    if not np.sin(theta_f / 2.0) > 0.0:
+        raise ValueError("eigen_axis_slew: zero-angle slew (q0 and qf coincide): the guess has no rotation axis "
+                         "(src/eigen_axis_slew.jl:19 divides by sin(theta/2))")
     axis = -q_e[1:4] / np.sin(theta_f / 2.0)
     alpha = np.pi / t[-1]
     theta = theta_f * 0.5 * (1.0 - np.cos(alpha * t))
@@ -87,13 +90,24 @@ def eigen_axis_slew(x0, xf, t, rates_only=False):
     return w_guess, q_guess
 
 
-def bryson_weights(w_guess, J, dt, alpha, beta):
+def bryson_weights(w_guess, J, dt, alpha, beta, degenerate_rd=None):
     """Diagonal (Qd(7), Qfd(7), Rd(3)) per src/TortoiseSat.jl:157-168 / src/monte_carlo.jl:165-176.
 
-    ``tau_max`` is the *signed* maximum, as written in the reference (``maximum(J*diff(w)/dt)``).
+    ``tau_max`` is the *signed* maximum, as written in the reference (``maximum(J*diff(w)/dt)``). A guess without an
+    acceleration sample (two knots, or a constant rate) has ``tau_max <= 0`` and the reference's ``R = 1/m_max^2`` is
+    infinite: that raises here, unless ``degenerate_rd`` names the control weight to use instead.
     """
     w_max = np.max(np.abs(w_guess))
-    tau_max = np.max((J @ np.diff(w_guess, axis=0).T) / dt)
+    if not w_max > 0.0:
+        raise ValueError("bryson_weights: the rate guess is identically zero (w_max = 0): Q = alpha/w_max^2 is undefined")
+    dw = np.diff(w_guess, axis=0)
+    tau_max = np.max((J @ dw.T) / dt) if dw.shape[0] > 0 else 0.0
+    if not tau_max > 0.0:
+        if degenerate_rd is None:
+            raise ValueError("bryson_weights: the guess has no positive torque sample (tau_max <= 0): R = 1/m_max^2 is "
+                             "undefined; pass degenerate_rd to choose a control weight")
+        Qd = np.concatenate([np.full(3, alpha / w_max**2), np.full(4, alpha * beta)])
+        return Qd, 10.0 * Qd, np.full(3, float(degenerate_rd))
     m_max = tau_max / 1.0e-5 * 1.0e2
     Qd = np.concatenate([np.full(3, alpha / w_max**2), np.full(4, alpha * beta)])
     Qfd = 10.0 * Qd
@@ -170,7 +184,7 @@ def jmat_cm(J):
     return np.ascontiguousarray(np.transpose(J, (0, 2, 1)).reshape(-1, 9))
 
 
-def make_batch(N, dt, q0, qf, J, Btab, btab_idx, alpha, beta, u_bnd, U0, w0=None, wf=None):
+def make_batch(N, dt, q0, qf, J, Btab, btab_idx, alpha, beta, u_bnd, U0, w0=None, wf=None, degenerate_rd=None):
     """Assemble a SlewBatch from per-trajectory initial/goal quaternions (T,4); weights per trajectory from
     each trajectory's own eigen-axis guess (src/monte_carlo.jl:161-176)."""
     q0 = np.atleast_2d(np.asarray(q0, dtype=np.float64))
@@ -186,7 +200,7 @@ def make_batch(N, dt, q0, qf, J, Btab, btab_idx, alpha, beta, u_bnd, U0, w0=None
     Qd = np.empty((T, 7)); Qfd = np.empty((T, 7)); Rd = np.empty((T, 3))
     for i in range(T):
         wg, _ = eigen_axis_slew(x0[i], xf[i], t)
-        Qd[i], Qfd[i], Rd[i] = bryson_weights(wg, J, dt, alpha, beta)
+        Qd[i], Qfd[i], Rd[i] = bryson_weights(wg, J, dt, alpha, beta, degenerate_rd)
     Btab = np.ascontiguousarray(np.asarray(Btab, dtype=np.float64))
     if Btab.ndim == 2:
         Btab = Btab[None]
@@ -226,7 +240,7 @@ def workload_single_slew(N=500):
     return b
 
 
-def workload_monte_carlo(T=1024, N=1000, seed=20190530, random_orbit=False):
+def workload_monte_carlo(T=1024, N=1000, seed=20190530, random_orbit=False, degenerate_rd=None):
     """configs[1] (and [2] with random_orbit=True): Monte-Carlo of src/monte_carlo.jl:107-198 with the initial
     attitude randomised — q0 uniform on S^3, qf = [sqrt2/2, sqrt2/2, 0, 0] (:114), 1U inertia (:31-33),
     dt 0.2, U0 ~ U(0,1e-3) (:193), Bryson weights alpha = 0.1, beta = 1e3 (:170-176), |u| <= 19 (:179),
@@ -245,7 +259,7 @@ def workload_monte_carlo(T=1024, N=1000, seed=20190530, random_orbit=False):
     else:
         B = dipole_btable(N, dt, a_km, 96.6, 0.0, 0.0)
         idx = np.zeros(T, np.int32)
-    b = make_batch(N, dt, q0, qf[None], INERTIA["1U"], B, idx, 0.1, 1.0e3, 19.0, U0)
+    b = make_batch(N, dt, q0, qf[None], INERTIA["1U"], B, idx, 0.1, 1.0e3, 19.0, U0, degenerate_rd=degenerate_rd)
     b.meta = dict(name="monte_carlo_random_orbit" if random_orbit else "monte_carlo", max_outer=5, max_inner=10,
                   dj_counter_limit=1, seed=seed)
     return b
