@@ -254,6 +254,19 @@ TSAT_DEV real sel7(const real a[7], int i) {
 
 template <typename real> TSAT_DEV real inf_() { return (real)__builtin_huge_val(); }
 
+// Store of a branch-free lane-role step: lanes without a role in the step aim at the sink word L_SINK (never read). On the
+// GPU that is one ds_write for the whole wave — lanes hitting the same address in one instruction are well defined — while
+// host threads storing to one word concurrently are a data race, so the emulator drops the sink stores instead.
+template <typename real>
+TSAT_DEV void role_store(real* lds, int off, int sink, real v) {
+#ifdef TSAT_EMU
+  if (off == sink) return;
+#else
+  (void)sink;
+#endif
+  lds[off] = v;
+}
+
 // wave collectives through LDS scratch; identical butterfly order in the GPU and emulated builds
 template <typename real>
 TSAT_DEV real wave_sum(real v, real* red) {
@@ -917,8 +930,8 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
       TSAT_SCHED_FENCE();
       real acc = 0, acc2 = 0;
       for (int m = 0; m < NH; ++m) { acc += sv[m] * fa1[m]; acc2 += sv[m] * fb1[m]; }
-      lds[s1_oa] = acc;
-      lds[s1_ob] = acc2;
+      role_store(lds, s1_oa, L_SINK, acc);
+      role_store(lds, s1_ob, L_SINK, acc2);
     }
     TSAT_SYNC_LDS();
     // step 2: Qxx = lxx + A'SA, Qux = B'SA, Quu = luu + B'SB, Qu = lu + B's
@@ -928,8 +941,8 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
       TSAT_SCHED_FENCE();
       real acc = s2_diag + ini2;
       for (int m = 0; m < NH; ++m) acc += fa2[m] * wb[m];
-      lds[s2_o1] = acc;
-      lds[s2_o2] = acc;
+      role_store(lds, s2_o1, L_SINK, acc);
+      role_store(lds, s2_o2, L_SINK, acc);
     }
     TSAT_SYNC_LDS();
     // step 3: regularise, PD test (Sylvester), adjugate inverse, K = -Quu_reg^-1 Qux, d = -Quu_reg^-1 Qu
@@ -963,7 +976,7 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
       const real Qi2 = ((a3c == 0) ? c02 : (a3c == 1 ? c12 : c22)) * nid;
       const real vv = Qi0 * h0 + Qi1 * h1 + Qi2 * h2;
       const real v = s3_live ? vv : (real)0;
-      lds[s3_o] = v;
+      role_store(lds, s3_o, L_SINK, v);
       if (s3_slot >= 0) KDg[(size_t)(k0 + l) * KDW + s3_slot] = v;   // stays in flight: no vmcnt wait in this loop
     }
     if (!pd_ok) break;  // wave-uniform: every lane read the same Huu
@@ -992,8 +1005,8 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
         kk += ki[c] * kj[c];
       }
       acc += (real)0.5 * sy - rho * kk;
-      lds[s4_o1] = acc;
-      lds[s4_o2] = acc;
+      role_store(lds, s4_o1, L_SINK, acc);
+      role_store(lds, s4_o2, L_SINK, acc);
     }
     TSAT_SYNC_LDS();
   }
@@ -1480,8 +1493,7 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
   p.KD = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * (NS - 1) * KDW);
   p.LAM = nullptr; p.CAND = nullptr;
   p.bt = (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[traj] * n_tab * 4);
-  stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)traj * PSTRIDE), a.us);
-  if (lane < 3) lds[L_TR + P_QATT + lane] = a.P[(size_t)traj * PSTRIDE + P_QATT + lane];
+  stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)traj * PSTRIDE), a.us);   // whole record, P_QATT slots included
   TSAT_SYNC();
   const real h = lds[L_TR + P_DT];
   const real hl = a.lin_sq ? h * h : h;
