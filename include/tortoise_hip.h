@@ -216,7 +216,7 @@ void tsat_tvlqr_default_options(tsat_tvlqr_options* o);
  *   noise 9x4x(N-1)xT or NULL    per step and RK4 stage: gyro noise(3), attitude-noise rotation vector(3), field
  *                                noise(3) — the values the reference draws inside `simulator` (src/simulator.jl:5,10,22);
  *                                NULL = noise-free plant (`gain_simulator`)
- *   X_sim 7xNxT, U_sim 3x(N-1)xT, K_lqr 3x6x(N-1)xT (may be NULL), stats T        outputs
+ *   X_sim 7xNxT, U_sim 3x(N-1)xT, K_lqr 3x6x(N-1)xT (each may be NULL: only what is asked for travels back), stats T   outputs
  *   n_knots T or NULL            per-trajectory horizons as for tsat_batch_knots (`t_total[i]`, src/monte_carlo.jl:145):
  *                                trajectory t is tracked over its first n_knots[t] samples, the rest of its slabs is
  *                                zero and its statistic counts n_knots[t] samples; NULL = all N
@@ -263,6 +263,28 @@ int  tsat_tvlqr_resident(tsat_handle* h, const tsat_tvlqr_options* o, const doub
  * ------------------------------------------------------------------------------------------------------------ */
 int  tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t plant_integrator,
                   double* X_hist, double* U_hist, tsat_stats* stats_last, float* solve_ms);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Sweep exchange across GPUs. The reference's Monte-Carlo is a serial loop whose iterations share nothing but the result
+ * lists they append to (src/monte_carlo.jl:52-66, 199-235; src/paper_images/heatmap.jl:114-243). Here each rank — one
+ * process, one handle, one GPU — solves a contiguous shard of equal size T, and ONE collective at the end appends
+ * everybody's results in rank order: an RCCL all-gather over xGMI, issued on the handle's stream straight from the
+ * resident batch (export kernel -> ncclAllGather, no host staging between them).
+ *   tsat_comm_unique_id   rank 0 creates the 128-byte communicator id; the host distributes it to the other ranks by
+ *                         whatever it has (MPI.bcast, a shared file, Distributed.jl, torch.distributed)
+ *   tsat_comm_init        every rank, collectively: binds a communicator of `world` ranks to the handle's GPU
+ *   tsat_sweep_allgather  every rank, collectively, after tsat_batch_run: X_all 7 x N x (world T), U_all 3 x (N-1) x (world T),
+ *                         stats_all (world T) in rank order; any of the three may be NULL. on_device = 0: host buffers;
+ *                         on_device = 1: device buffers of the caller on the handle's GPU. Blocks until the data is there.
+ *   tsat_comm_destroy     releases the communicator (tsat_destroy does it too)
+ * RCCL is loaded at the first tsat_comm_* call (librccl.so.1, or $TSAT_RCCL_LIB); the library has no link-time dependency
+ * on it, error code -11 reports that it is missing or that a collective failed. Ragged totals: pad the last shard.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define TSAT_COMM_ID_BYTES 128
+int  tsat_comm_unique_id(void* id_out /* TSAT_COMM_ID_BYTES */);
+int  tsat_comm_init(tsat_handle* h, const void* id /* TSAT_COMM_ID_BYTES */, int32_t rank, int32_t world);
+int  tsat_sweep_allgather(tsat_handle* h, void* X_all, void* U_all, void* stats_all, int32_t on_device);
+int  tsat_comm_destroy(tsat_handle* h);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Horizon selection (the caller right before the solve): cumulative magnetic Gramian of a field table and the first

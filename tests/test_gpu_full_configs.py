@@ -41,6 +41,8 @@ def _report(name, ref, got):
 @pytest.mark.parametrize("es", [0, 1])
 def test_gpu_configs1_every_trajectory(pkg, ol, solver, es):
     b = pkg.slew_setup.workload_monte_carlo(T=1024, N=1000)
+    if es:      # the bench's configuration: quaternion hooks + IGRF-12 field along the orbit (tsat_btable_batch)
+        pkg.magnetic.attach_igrf_tables(solver, b)
     o = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, error_state=es)
     ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False)
     got = _gpu(pkg, solver, b, o)
@@ -49,7 +51,7 @@ def test_gpu_configs1_every_trajectory(pkg, ol, solver, es):
 
 
 def test_gpu_configs2_inputs_fp64(pkg, ol, solver):
-    b = pkg.slew_setup.workload_monte_carlo(T=512, N=1000, seed=20190531, random_orbit=True)
+    b = pkg.magnetic.attach_igrf_tables(solver, pkg.slew_setup.workload_monte_carlo(T=512, N=1000, seed=20190531, random_orbit=True, tables=False))
     o = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, error_state=1)
     ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False)
     for variant in (1, 2):

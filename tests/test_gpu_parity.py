@@ -213,6 +213,53 @@ def test_gpu_api_errors_are_codes_not_crashes(pkg, ol, solver):
         pkg.tracking.attitude_simulation(solver, b, res["X"], res["U"], b.x0, Qd, Qfd, Rd)
 
 
+def test_gpu_upload_rejects_degenerate_inputs(pkg, ol, solver):
+    """non-finite weights / bounds and singular inertias are API errors at upload, not DIVERGED statuses later"""
+    ss = pkg.slew_setup
+    with pytest.raises(ValueError):
+        ss.workload_monte_carlo(T=2, N=2)                     # Bryson R of a two-knot guess is undefined (1/0)
+    with pytest.raises(ValueError):
+        ss.eigen_axis_slew(np.r_[0, 0, 0, 1, 0, 0, 0.], np.r_[0, 0, 0, 1, 0, 0, 0.], 0.2 * np.arange(5))
+    for field, val in (("Rd", np.inf), ("Qd", np.nan), ("uhi", np.inf), ("Jmat", 0.0), ("dt", 0.0)):
+        b = ss.workload_monte_carlo(T=3, N=20, seed=2)
+        getattr(b, field)[1] = val
+        with pytest.raises(RuntimeError):
+            solver.upload(b, 20)
+    b = ss.workload_monte_carlo(T=3, N=20, seed=2)
+    solver.upload(b, 20)                                       # the handle is still usable
+
+
+def test_gpu_native_sweep_allgather_single_rank(pkg, ol, solver):
+    """tsat_comm_* / tsat_sweep_allgather (RCCL behind the C ABI) with a one-rank communicator: the gathered arrays are
+    the downloaded ones, through host buffers and through caller-owned device buffers"""
+    import torch
+    b = pkg.slew_setup.workload_monte_carlo(T=5, N=64, seed=31)
+    o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1)
+    ref = gpu_solve(pkg, solver, b, o)
+    solver.comm_init(solver.comm_unique_id(), 0, 1)
+    got = solver.sweep_allgather()
+    assert np.array_equal(got["X"], ref["X"]) and np.array_equal(got["U"], ref["U"]) and np.array_equal(got["stats"], ref["stats"])
+    X = torch.empty((5, 64, 7), dtype=torch.float64, device="cuda")
+    st = torch.empty((5, 64), dtype=torch.uint8, device="cuda")
+    solver.sweep_allgather(X.data_ptr(), None, st.data_ptr(), on_device=True)
+    assert np.array_equal(X.cpu().numpy(), ref["X"]) and np.array_equal(st.cpu().numpy().view(pkg._abi.STATS_DTYPE).reshape(-1), ref["stats"])
+    solver.comm_destroy()
+    with pytest.raises(RuntimeError):
+        solver.sweep_allgather()
+
+
+def test_gpu_igrf_tables_attached_to_a_workload(pkg, ol, solver):
+    """the bench workload's field: IGRF-12 along the orbit from tsat_btable_batch (one orbit, and one per trajectory)"""
+    ss, mg = pkg.slew_setup, pkg.magnetic
+    o = oracle_options(ol, max_outer=3, max_inner=6, dj_counter_limit=1, error_state=1)
+    for kw in (dict(), dict(random_orbit=True, tables=False)):
+        b = mg.attach_igrf_tables(solver, ss.workload_monte_carlo(T=6, N=300, seed=17, **kw))
+        assert b.n_tab == 308 and b.Btab.shape == ((6 if kw else 1), 308, 3) and np.all(b.dtau == 1.0)
+        Bo = ol.btable_batch(b.meta["kep"], 0.0, 60.0, 300, want_pos=False)[0][:, :308]
+        assert np.max(np.abs(b.Btab - Bo)) < 1e-9 * np.max(np.abs(Bo))
+        assert_same_solution(ol.solve_batch(b, o, nthreads=6), gpu_solve(pkg, solver, b, o))
+
+
 def test_gpu_dense_and_wide_builds_agree(pkg, ol, solver):
     """tsat_set_kernel_variant: the two builds of the solve kernel give bit-identical results; batches above 1024
     trajectories take the dense one automatically"""

@@ -109,6 +109,21 @@ def test_gpu_receding_horizon_matches_oracle(pkg, ol):
     got = mpc.receding_horizon(to.BatchProblem.from_arrays(b, error_state=1), s, 12, plant_integrator=3)
     got.update(s.download(want_K=False))
     _same(ol.mpc_batch(b, _opts(ol, error_state=1), 12, plant_integrator=3, nthreads=8), got)
+    # tracking the last plan of the resident loop: tsat_mpc_run advanced x0 / tau0 on the device, and the handle's host
+    # mirrors follow (they feed tsat_tvlqr_resident), so resident tracking equals the array entry point given the plan
+    # and the ADVANCED table clock
+    b = _batch(pkg, T=4, N=60, seed=9, rows=300)
+    got = mpc.receding_horizon(to.BatchProblem.from_arrays(b), s, 25, plant_integrator=4)
+    plan = s.download(want_K=False)
+    Qd, Qfd, Rd = pkg.tracking.tvlqr_weights(b.T)
+    x0s = np.ascontiguousarray(got["X_hist"][:, -1])
+    res = pkg.tracking.attitude_simulation(s, b, None, None, x0s, Qd, Qfd, Rd)
+    adv = b.slice(0, b.T)
+    adv.tau0 = np.ascontiguousarray(b.tau0 + 25 * b.dtau)
+    arr = pkg.tracking.attitude_simulation(s, adv, plan["X"], plan["U"], x0s, Qd, Qfd, Rd)
+    assert np.array_equal(res["X_sim"], arr["X_sim"]) and np.array_equal(res["K"], arr["K"])
+    stale = pkg.tracking.attitude_simulation(s, b, plan["X"], plan["U"], x0s, Qd, Qfd, Rd)      # the un-advanced clock differs
+    assert np.max(np.abs(stale["K"] - arr["K"])) > 0
     # bad arguments are codes
     assert lib.tsat_mpc_run(s._h, C.byref(o), 0, 4, abi.as_dp(Xh), abi.as_dp(Uh), None, None) < 0
     assert lib.tsat_mpc_run(s._h, C.byref(o), 10, 5, abi.as_dp(Xh), abi.as_dp(Uh), None, None) < 0

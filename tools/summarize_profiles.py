@@ -8,6 +8,9 @@ import csv, glob, json, os, shutil, sys
 
 src, dst = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from bench import kernel_source_hash   # the stamp bench.py checks before it reports these counters
+os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
@@ -35,6 +38,8 @@ shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(dst, "kernel_stats_b
 shutil.copy(one("pipeline/**/*kernel_stats.csv"), os.path.join(dst, "kernel_stats_pipeline.csv"))
 for a, b in (("phase_clocks.txt", "phase_clocks_final.txt"), ("pipeline.log", "pipeline_wall.txt"),
              ("monte_carlo.txt", "monte_carlo_wall.txt"), ("large_batch.txt", "large_batch.txt"), ("mpc_timing.txt", "mpc_timing.txt"), ("stats.json", "bench_under_rocprof.json")):
+    if not os.path.exists(os.path.join(src, a)):
+        continue
     with open(os.path.join(src, a)) as f:
         keep = [ln for ln in f if not ln.startswith(("W20", "E20", "I20"))]
     with open(os.path.join(dst, b), "w") as f:
@@ -45,7 +50,8 @@ wr, _ = counters("pmc_write")
 sq, _ = counters("pmc_sq")
 rd_raw, wr_b = fe["FETCH_SIZE"] * 1024.0, wr["WRITE_SIZE"] * 1024.0
 out = {
-    "kernel": kern, "workload": bench["config"]["workload"],
+    "kernel": kern, "workload": bench["config"]["workload"], "bench_config": bench["config"].get("bench_config", 1),
+    "kernel_source_sha256_16": kernel_source_hash(),
     "FETCH_SIZE_KB": fe["FETCH_SIZE"], "WRITE_SIZE_KB": wr["WRITE_SIZE"],
     "read_bytes_raw": rd_raw, "read_bytes_x2": 2 * rd_raw, "write_bytes": wr_b,
     "hbm_bytes_per_launch": 2 * rd_raw + wr_b, "hbm_bytes_per_launch_lower": rd_raw + wr_b,

@@ -11,6 +11,7 @@ import numpy as np
 
 TSAT_NX, TSAT_NU, TSAT_NC = 7, 3, 6
 TSAT_MAX_LINESEARCH = 32
+TSAT_COMM_ID_BYTES = 128
 TSAT_CONVERGED, TSAT_MAX_OUTER, TSAT_REG_FAIL, TSAT_DIVERGED = 0, 1, 2, 3
 
 
@@ -99,6 +100,10 @@ PROTOTYPES = {
     "tsat_tvlqr_resident": (C.c_int, [C.c_void_p, C.POINTER(TvlqrOptions), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p,
                                       C.POINTER(C.c_int64)]),
     "tsat_mpc_run": (C.c_int, [C.c_void_p, C.POINTER(Options), C.c_int32, C.c_int32, _dp, _dp, C.c_void_p, C.POINTER(C.c_float)]),
+    "tsat_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "tsat_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "tsat_sweep_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "tsat_comm_destroy": (C.c_int, [C.c_void_p]),
     "tsat_btable_default_options": (None, [C.POINTER(BtableOptions)]),
     "tsat_btable_batch": (C.c_int, [C.c_void_p, C.POINTER(BtableOptions), C.c_int64, _dp, _dp, _dp, _dp, _dp]),
     "tsat_horizon_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, _ip, _dp]),

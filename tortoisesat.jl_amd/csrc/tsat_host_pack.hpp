@@ -198,10 +198,12 @@ void unpack_tv(int64_t T, int N, const real* XS, const real* KD, double* X_sim, 
   for (int64_t t = 0; t < T; ++t)
     for (int k = 0; k < N; ++k) {
       const real* r = XS + ((size_t)t * N + k) * XUW;
-      for (int i = 0; i < 7; ++i) X_sim[((size_t)t * N + k) * 7 + i] = (double)r[i];
+      if (X_sim)
+        for (int i = 0; i < 7; ++i) X_sim[((size_t)t * N + k) * 7 + i] = (double)r[i];
       if (k < N - 1) {
         const size_t ek = (size_t)t * (N - 1) + k;
-        for (int c = 0; c < 3; ++c) U_sim[ek * 3 + c] = (double)r[7 + c];
+        if (U_sim)
+          for (int c = 0; c < 3; ++c) U_sim[ek * 3 + c] = (double)r[7 + c];
         if (K_lqr)
           for (int j = 0; j < 6; ++j)
             for (int c = 0; c < 3; ++c) K_lqr[ek * 18 + j * 3 + c] = -(double)KD[ek * KDW + c * 7 + j];

@@ -3,6 +3,8 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared tsat_kernels.hip -o libtortoise_hip.so
 // One wavefront (a 64-thread workgroup) owns one trajectory for the whole AL-iLQR solve; see tsat_device.hpp.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen'ed on first use (tsat_comm_*), never linked
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -83,6 +85,16 @@ struct tsat_handle {
   int variant = 0;            // solve-kernel build: 0 automatic (dense above 1024 trajectories), 1 wide, 2 dense
   // host copies of the small per-trajectory inputs of the last upload (26 doubles each), for tsat_tvlqr_resident
   std::vector<double> hx0, hxf, htau0, hdtau, hdt, hJ;
+  // grow-only device workspaces of the stages around the solve (tracking, horizon, field tables, MPC history, export):
+  // allocated on first use and kept for the life of the handle, so repeated calls pay no hipMalloc / hipFree
+  enum { WS_TV_NZ, WS_TV_KD, WS_TV_XS, WS_TV_NID, WS_TV_ST, WS_TV_P, WS_TVB_P, WS_TVB_BT, WS_TVB_XUR, WS_TVB_BI, WS_TVB_NK,
+         WS_HZ_B, WS_HZ_DT, WS_HZ_CUT, WS_HZ_C, WS_HZ_I, WS_BT_COEF, WS_BT_KEP, WS_BT_T0, WS_BT_TF, WS_BT_POS, WS_BT_B,
+         WS_MPC_HX, WS_MPC_HU, WS_DL_X, WS_DL_U, WS_DL_K, WS_AG_X, WS_AG_U, WS_AG_ST, WS_AG_XA, WS_AG_UA, WS_AG_STA, WS_COUNT };
+  void* ws[WS_COUNT] = {};
+  size_t ws_bytes[WS_COUNT] = {};
+  // RCCL communicator of the sweep (tsat_comm_init): one rank per handle / GPU
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
 };
 
 namespace {
@@ -107,6 +119,22 @@ void release(tsat_handle* h) {
   h->T = 0; h->bytes = 0; h->uploaded = h->solved = false;
 }
 
+// workspace `slot` with room for `bytes` (grow-only; contents are not preserved across a growth); nullptr on failure
+void* ws_get(tsat_handle* h, int slot, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (h->ws[slot] && h->ws_bytes[slot] >= bytes) return h->ws[slot];
+  if (h->ws[slot]) { (void)hipFree(h->ws[slot]); h->ws[slot] = nullptr; h->ws_bytes[slot] = 0; }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  h->ws[slot] = p;
+  h->ws_bytes[slot] = bytes;
+  return p;
+}
+void ws_release(tsat_handle* h) {
+  for (int i = 0; i < tsat_handle::WS_COUNT; ++i)
+    if (h->ws[i]) { (void)hipFree(h->ws[i]); h->ws[i] = nullptr; h->ws_bytes[i] = 0; }
+}
+
 template <typename Tp>
 int dev_alloc(tsat_handle* h, Tp** p, size_t n) {
   const size_t b = n * sizeof(Tp);
@@ -119,7 +147,7 @@ int dev_alloc(tsat_handle* h, Tp** p, size_t n) {
 
 extern "C" {
 
-int tsat_version(void) { return 100; }
+int tsat_version(void) { return 200; }
 
 void tsat_default_options(tsat_options* o) {
   std::memset(o, 0, sizeof(*o));
@@ -158,7 +186,9 @@ int tsat_create(tsat_handle** out, int device_id) {
 int tsat_destroy(tsat_handle* h) {
   if (!h) return -1;
   (void)hipSetDevice(h->dev);
+  (void)tsat_comm_destroy(h);
   release(h);
+  ws_release(h);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -328,11 +358,9 @@ int tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t
   if (!X_hist || !U_hist) return fail(h, -1, "null array");
   TSAT_HIP(h, hipSetDevice(h->dev));
   const size_t T = (size_t)h->T, nX = T * ((size_t)n_steps + 1) * 7, nU = T * (size_t)n_steps * 3;
-  double *dHX = nullptr, *dHU = nullptr;
-  if (hipMalloc((void**)&dHX, nX * 8) != hipSuccess || hipMalloc((void**)&dHU, nU * 8) != hipSuccess) {
-    if (dHX) (void)hipFree(dHX);
-    return fail(h, -10, "device allocation failed in tsat_mpc_run");
-  }
+  double* dHX = (double*)ws_get(h, tsat_handle::WS_MPC_HX, nX * 8);
+  double* dHU = (double*)ws_get(h, tsat_handle::WS_MPC_HU, nU * 8);
+  if (!dHX || !dHU) return fail(h, -10, "device allocation failed in tsat_mpc_run");
   const KArgs<double> a = solve_args(h, o);
   MpcArgs<double> m;
   m.T = (int)h->T; m.N = h->N; m.n_tab = h->n_tab; m.plant_integ = plant_integrator; m.n_steps = n_steps; m.us = o->u_scale;
@@ -357,8 +385,6 @@ int tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t
   // its own records from, so that tracking after an MPC run linearises against the field rows the last plan was solved on
   std::vector<double> Pb(T * PSTRIDE);
   if (!rc && hipMemcpy(Pb.data(), h->P, Pb.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
-  (void)hipFree(dHX);
-  (void)hipFree(dHU);
   if (rc) { h->solved = false; return fail(h, rc, "launch or copy failed in tsat_mpc_run"); }
   for (size_t t = 0; t < T; ++t) {
     for (int i = 0; i < 7; ++i) h->hx0[7 * t + i] = Pb[t * PSTRIDE + P_X0 + i];
@@ -393,17 +419,14 @@ int tsat_batch_download(tsat_handle* h, double* X, double* U, double* K, tsat_st
   const size_t T = (size_t)h->T, N = (size_t)h->N;
   double *dX = nullptr, *dU = nullptr, *dK = nullptr;
   int rc = 0;
-  if (X && hipMalloc((void**)&dX, T * N * 7 * sizeof(double)) != hipSuccess) rc = -10;
-  if (!rc && U && hipMalloc((void**)&dU, T * (N - 1) * 3 * sizeof(double)) != hipSuccess) rc = -10;
-  if (!rc && K && hipMalloc((void**)&dK, T * (N - 1) * 21 * sizeof(double)) != hipSuccess) rc = -10;
+  if (X && !(dX = (double*)ws_get(h, tsat_handle::WS_DL_X, T * N * 7 * sizeof(double)))) rc = -10;
+  if (!rc && U && !(dU = (double*)ws_get(h, tsat_handle::WS_DL_U, T * (N - 1) * 3 * sizeof(double)))) rc = -10;
+  if (!rc && K && !(dK = (double*)ws_get(h, tsat_handle::WS_DL_K, T * (N - 1) * 21 * sizeof(double)))) rc = -10;
   if (!rc) rc = tsat_batch_export_device(h, dX, dU, dK, nullptr);
   if (!rc && X && hipMemcpy(X, dX, T * N * 7 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && U && hipMemcpy(U, dU, T * (N - 1) * 3 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && K && hipMemcpy(K, dK, T * (N - 1) * 21 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && stats && hipMemcpy(stats, h->stats, T * sizeof(tsat_stats), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
-  if (dX) (void)hipFree(dX);
-  if (dU) (void)hipFree(dU);
-  if (dK) (void)hipFree(dK);
   if (rc == -10) h->err = "device allocation or copy failed in tsat_batch_download";
   return rc;
 }
@@ -450,11 +473,12 @@ int run_tvlqr(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int N, int
   long long* dnid = nullptr;
   tsat_tvlqr_stats* dst = nullptr;
   int rc = 0;
-  auto A = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 16) != hipSuccess) rc = -10; };
+  auto A = [&](void** p, int slot, size_t bytes) { if (!rc && !(*p = ws_get(h, slot, bytes))) rc = -10; };
   auto C = [&](void* d, const void* s, size_t bytes) { if (!rc && hipMemcpy(d, s, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -10; };
-  if (noise) { A((void**)&dNZ, nNZ * 8); C(dNZ, noise, nNZ * 8); }
-  A((void**)&dKD, nKD * 8); A((void**)&dXS, nXS * 8); A((void**)&dst, Tn * sizeof(tsat_tvlqr_stats));
-  if (o->noise_mode == 1 && noise_id) { A((void**)&dnid, Tn * sizeof(long long)); C(dnid, noise_id, Tn * sizeof(long long)); }
+  if (noise) { A((void**)&dNZ, tsat_handle::WS_TV_NZ, nNZ * 8); C(dNZ, noise, nNZ * 8); }
+  A((void**)&dKD, tsat_handle::WS_TV_KD, nKD * 8); A((void**)&dXS, tsat_handle::WS_TV_XS, nXS * 8);
+  A((void**)&dst, tsat_handle::WS_TV_ST, Tn * sizeof(tsat_tvlqr_stats));
+  if (o->noise_mode == 1 && noise_id) { A((void**)&dnid, tsat_handle::WS_TV_NID, Tn * sizeof(long long)); C(dnid, noise_id, Tn * sizeof(long long)); }
   // ragged batch: the slabs beyond a trajectory's own horizon stay zero
   if (dnk && !rc && (hipMemsetAsync(dKD, 0, nKD * 8, h->stream) != hipSuccess || hipMemsetAsync(dXS, 0, nXS * 8, h->stream) != hipSuccess)) rc = -10;
   if (!rc) {
@@ -467,14 +491,12 @@ int run_tvlqr(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int N, int
     hipLaunchKernelGGL(kern, dim3((unsigned)T), dim3(64), 0, h->stream, a);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) rc = -10;
   }
-  std::vector<double> XS(nXS), KD(K_lqr ? nKD : 0);     // the gains travel only when asked for
-  if (!rc && hipMemcpy(XS.data(), dXS, nXS * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  const bool want_traj = X_sim || U_sim || K_lqr;       // the statistic alone travels when no trajectory is asked for
+  std::vector<double> XS(want_traj ? nXS : 0), KD(K_lqr ? nKD : 0);     // the gains travel only when asked for
+  if (!rc && want_traj && hipMemcpy(XS.data(), dXS, nXS * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && K_lqr && hipMemcpy(KD.data(), dKD, nKD * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && hipMemcpy(stats, dst, Tn * sizeof(tsat_tvlqr_stats), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
-  if (!rc) unpack_tv<double>(T, N, XS.data(), KD.data(), X_sim, U_sim, K_lqr);
-  void* fr[] = {dNZ, dKD, dXS, dnid, dst};
-  for (void* q : fr)
-    if (q) (void)hipFree(q);
+  if (!rc && want_traj) unpack_tv<double>(T, N, XS.data(), KD.data(), X_sim, U_sim, K_lqr);
   return rc;
 }
 }  // namespace
@@ -488,7 +510,7 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
   const std::string why = check_tv_options(*o);
   if (!why.empty()) return fail(h, -1, why);
   if (T < 1 || n_btab < 1) return fail(h, -1, "bad batch dimensions");
-  if (!X || !U || !xf || !Btab || !tau0 || !dtau || !dt || !Jmat || !Qd || !Qfd || !Rd || !x0_sim || !X_sim || !U_sim || !stats)
+  if (!X || !U || !xf || !Btab || !tau0 || !dtau || !dt || !Jmat || !Qd || !Qfd || !Rd || !x0_sim || !stats)
     return fail(h, -1, "null array");
   if (!btab_idx && n_btab != T) return fail(h, -1, "btab_idx is NULL but n_btab != T");
   if (o->noise_mode == 1 && noise) return fail(h, -1, "noise_mode = 1 draws the noise in the kernel: pass noise = NULL");
@@ -510,15 +532,13 @@ int tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int
   double *dP = nullptr, *dBT = nullptr, *dXUR = nullptr;
   int *dbi = nullptr, *dnk = nullptr;
   int rc = 0;
-  auto A = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 16) != hipSuccess) rc = -10; };
+  auto A = [&](void** p, int slot, size_t bytes) { if (!rc && !(*p = ws_get(h, slot, bytes))) rc = -10; };
   auto C = [&](void* d, const void* s, size_t bytes) { if (!rc && hipMemcpy(d, s, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -10; };
-  A((void**)&dP, P.size() * 8); A((void**)&dBT, BT.size() * 8); A((void**)&dXUR, XUR.size() * 8); A((void**)&dbi, Tn * sizeof(int));
+  A((void**)&dP, tsat_handle::WS_TVB_P, P.size() * 8); A((void**)&dBT, tsat_handle::WS_TVB_BT, BT.size() * 8);
+  A((void**)&dXUR, tsat_handle::WS_TVB_XUR, XUR.size() * 8); A((void**)&dbi, tsat_handle::WS_TVB_BI, Tn * sizeof(int));
   C(dP, P.data(), P.size() * 8); C(dBT, BT.data(), BT.size() * 8); C(dXUR, XUR.data(), XUR.size() * 8); C(dbi, bi.data(), Tn * sizeof(int));
-  if (n_knots) { A((void**)&dnk, Tn * sizeof(int)); C(dnk, n_knots, Tn * sizeof(int)); }
+  if (n_knots) { A((void**)&dnk, tsat_handle::WS_TVB_NK, Tn * sizeof(int)); C(dnk, n_knots, Tn * sizeof(int)); }
   if (!rc) rc = run_tvlqr(h, o, T, N, n_tab, inertia_class(T, Jmat), dP, dBT, dbi, dnk, dXUR, noise, noise_id, X_sim, U_sim, K_lqr, stats);
-  void* fr[] = {dP, dBT, dXUR, dbi, dnk};
-  for (void* q : fr)
-    if (q) (void)hipFree(q);
   if (rc) h->err = "device allocation, copy or launch failed in tsat_tvlqr_batch";
   return rc;
 }
@@ -532,18 +552,17 @@ int tsat_tvlqr_resident(tsat_handle* h, const tsat_tvlqr_options* o, const doubl
   oo.n_knots = h->N; oo.n_tab = h->n_tab;
   const std::string why = check_tv_options(oo);
   if (!why.empty()) return fail(h, -1, why);
-  if (!Qd || !Qfd || !Rd || !x0_sim || !X_sim || !U_sim || !stats) return fail(h, -1, "null array");
+  if (!Qd || !Qfd || !Rd || !x0_sim || !stats) return fail(h, -1, "null array");
   if (oo.noise_mode == 1 && noise) return fail(h, -1, "noise_mode = 1 draws the noise in the kernel: pass noise = NULL");
   TSAT_HIP(h, hipSetDevice(h->dev));
   const int64_t T = h->T;
   std::vector<double> P((size_t)T * PSTRIDE);
   pack_tv_params<double>(T, x0_sim, h->hxf.data(), h->htau0.data(), h->hdtau.data(), h->hdt.data(), h->hJ.data(), Qd, Qfd, Rd, P.data());
-  double* dP = nullptr;
-  if (hipMalloc((void**)&dP, P.size() * 8) != hipSuccess) return fail(h, -10, "device allocation failed in tsat_tvlqr_resident");
+  double* dP = (double*)ws_get(h, tsat_handle::WS_TV_P, P.size() * 8);
+  if (!dP) return fail(h, -10, "device allocation failed in tsat_tvlqr_resident");
   int rc = hipMemcpy(dP, P.data(), P.size() * 8, hipMemcpyHostToDevice) == hipSuccess ? 0 : -10;
   if (!rc) rc = run_tvlqr(h, &oo, T, h->N, h->n_tab, h->inertia_class, dP, h->BT, h->bidx, h->ragged ? h->nk : nullptr, h->XU,
                           noise, noise_id, X_sim, U_sim, K_lqr, stats);
-  (void)hipFree(dP);
   if (rc) h->err = "device allocation, copy or launch failed in tsat_tvlqr_resident";
   return rc;
 }
@@ -558,8 +577,9 @@ int tsat_horizon_batch(tsat_handle* h, int64_t T, int32_t n_rows, const double* 
   double *dB = nullptr, *ddt = nullptr, *dcut = nullptr, *dc = nullptr;
   int* di = nullptr;
   int rc = 0;
-  auto A = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 16) != hipSuccess) rc = -10; };
-  A((void**)&dB, nB * 8); A((void**)&ddt, Tn * 8); A((void**)&dcut, Tn * 8); A((void**)&dc, Tn * 8); A((void**)&di, Tn * sizeof(int));
+  auto A = [&](void** p, int slot, size_t bytes) { if (!rc && !(*p = ws_get(h, slot, bytes))) rc = -10; };
+  A((void**)&dB, tsat_handle::WS_HZ_B, nB * 8); A((void**)&ddt, tsat_handle::WS_HZ_DT, Tn * 8); A((void**)&dcut, tsat_handle::WS_HZ_CUT, Tn * 8);
+  A((void**)&dc, tsat_handle::WS_HZ_C, Tn * 8); A((void**)&di, tsat_handle::WS_HZ_I, Tn * sizeof(int));
   auto Cp = [&](void* d, const void* s, size_t bytes) { if (!rc && hipMemcpy(d, s, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -10; };
   Cp(dB, Btab, nB * 8); Cp(ddt, dt_row, Tn * 8); Cp(dcut, cutoff, Tn * 8);
   if (!rc) {
@@ -570,11 +590,130 @@ int tsat_horizon_batch(tsat_handle* h, int64_t T, int32_t n_rows, const double* 
   }
   if (!rc && hipMemcpy(tf_index, di, Tn * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && cond_at && hipMemcpy(cond_at, dc, Tn * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
-  void* fr[] = {dB, ddt, dcut, dc, di};
-  for (void* q : fr)
-    if (q) (void)hipFree(q);
   if (rc) h->err = "device allocation, copy or launch failed in tsat_horizon_batch";
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sweep exchange: the RCCL all-gather of every rank's converged trajectories (north_star). RCCL is loaded on
+// first use — a single-GPU host never needs it — and called on the handle's own stream right behind the export kernel.
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string why;
+};
+RcclApi& rccl() {
+  static RcclApi api;
+  if (api.lib || !api.why.empty()) return api;
+  // a host that already carries an RCCL (PyTorch-ROCm bundles one) keeps using that copy; otherwise the system library
+  const char* env = std::getenv("TSAT_RCCL_LIB");
+  const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names)
+    if (n && *n && (api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  if (!api.lib)
+    for (const char* n : names)
+      if (n && *n && (api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!api.lib) { api.why = "librccl.so.1 not found (set TSAT_RCCL_LIB)"; return api; }
+  api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+  api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+  api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+  api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) { api.why = "RCCL symbols missing"; api.lib = nullptr; }
+  return api;
+}
+int rccl_fail(tsat_handle* h, const char* what, ncclResult_t r) {
+  RcclApi& a = rccl();
+  return fail(h, -11, std::string(what) + ": " + (a.GetErrorString ? a.GetErrorString(r) : "RCCL error"));
+}
+}  // namespace
+extern "C" {
+
+int tsat_comm_unique_id(void* id_out) {
+  if (!id_out) return -1;
+  RcclApi& a = rccl();
+  if (!a.lib) return -11;
+  static_assert(sizeof(ncclUniqueId) == TSAT_COMM_ID_BYTES, "unique-id size");
+  ncclUniqueId id;
+  if (a.GetUniqueId(&id) != ncclSuccess) return -11;
+  std::memcpy(id_out, &id, sizeof(id));
+  return 0;
+}
+
+int tsat_comm_init(tsat_handle* h, const void* id_in, int32_t rank, int32_t world) {
+  if (!h || !id_in) return -1;
+  if (world < 1 || rank < 0 || rank >= world) return fail(h, -1, "need 0 <= rank < world");
+  RcclApi& a = rccl();
+  if (!a.lib) return fail(h, -11, "RCCL unavailable: " + a.why);
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  (void)tsat_comm_destroy(h);
+  ncclUniqueId id;
+  std::memcpy(&id, id_in, sizeof(id));
+  ncclComm_t c = nullptr;
+  const ncclResult_t r = a.CommInitRank(&c, world, id, rank);
+  if (r != ncclSuccess) return rccl_fail(h, "ncclCommInitRank", r);
+  h->comm = c; h->comm_rank = rank; h->comm_world = world;
+  return 0;
+}
+
+int tsat_comm_destroy(tsat_handle* h) {
+  if (!h) return -1;
+  if (h->comm) {
+    (void)hipSetDevice(h->dev);
+    (void)hipStreamSynchronize(h->stream);
+    (void)rccl().CommDestroy((ncclComm_t)h->comm);
+    h->comm = nullptr; h->comm_rank = 0; h->comm_world = 1;
+  }
+  return 0;
+}
+
+int tsat_sweep_allgather(tsat_handle* h, void* X_all, void* U_all, void* stats_all, int32_t on_device) {
+  if (!h) return -1;
+  if (!h->solved) return fail(h, -1, "tsat_batch_run has not been called");
+  if (!h->comm) return fail(h, -1, "tsat_comm_init has not been called");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  RcclApi& a = rccl();
+  const size_t T = (size_t)h->T, N = (size_t)h->N, W = (size_t)h->comm_world;
+  const size_t nX = T * N * 7, nU = T * (N - 1) * 3, nS = T * sizeof(tsat_stats);
+  // this rank's shard in the ABI layout (export kernel, device to device), then one ncclAllGather per array on the same
+  // stream; with host outputs the gathered arrays land in library workspaces and are copied down afterwards
+  double* dX = X_all ? (double*)ws_get(h, tsat_handle::WS_AG_X, nX * 8) : nullptr;
+  double* dU = U_all ? (double*)ws_get(h, tsat_handle::WS_AG_U, nU * 8) : nullptr;
+  void* dS = stats_all ? ws_get(h, tsat_handle::WS_AG_ST, nS) : nullptr;
+  if ((X_all && !dX) || (U_all && !dU) || (stats_all && !dS)) return fail(h, -10, "device allocation failed in tsat_sweep_allgather");
+  void *gX = X_all, *gU = U_all, *gS = stats_all;
+  if (!on_device) {
+    gX = X_all ? ws_get(h, tsat_handle::WS_AG_XA, W * nX * 8) : nullptr;
+    gU = U_all ? ws_get(h, tsat_handle::WS_AG_UA, W * nU * 8) : nullptr;
+    gS = stats_all ? ws_get(h, tsat_handle::WS_AG_STA, W * nS) : nullptr;
+    if ((X_all && !gX) || (U_all && !gU) || (stats_all && !gS)) return fail(h, -10, "device allocation failed in tsat_sweep_allgather");
+  }
+  const int64_t n_rec = h->T * (int64_t)h->N;
+  if (dX || dU) {
+    hipLaunchKernelGGL(tsat_export_kernel<double>, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, h->stream, n_rec, h->N,
+                       h->ragged ? h->nk : nullptr, h->XU, h->KD, dX, dU, (double*)nullptr);
+    TSAT_HIP(h, hipGetLastError());
+  }
+  if (dS) TSAT_HIP(h, hipMemcpyAsync(dS, h->stats, nS, hipMemcpyDeviceToDevice, h->stream));
+  ncclResult_t r = ncclSuccess;
+  if (dS && r == ncclSuccess) r = a.AllGather(dS, gS, nS, ncclUint8, (ncclComm_t)h->comm, h->stream);
+  if (dX && r == ncclSuccess) r = a.AllGather(dX, gX, nX, ncclFloat64, (ncclComm_t)h->comm, h->stream);
+  if (dU && r == ncclSuccess) r = a.AllGather(dU, gU, nU, ncclFloat64, (ncclComm_t)h->comm, h->stream);
+  if (r != ncclSuccess) return rccl_fail(h, "ncclAllGather", r);
+  if (!on_device) {
+    if (gX) TSAT_HIP(h, hipMemcpyAsync(X_all, gX, W * nX * 8, hipMemcpyDeviceToHost, h->stream));
+    if (gU) TSAT_HIP(h, hipMemcpyAsync(U_all, gU, W * nU * 8, hipMemcpyDeviceToHost, h->stream));
+    if (gS) TSAT_HIP(h, hipMemcpyAsync(stats_all, gS, W * nS, hipMemcpyDeviceToHost, h->stream));
+  }
+  TSAT_HIP(h, hipStreamSynchronize(h->stream));
+  return 0;
 }
 
 void tsat_btable_default_options(tsat_btable_options* o) {
@@ -602,9 +741,10 @@ int tsat_btable_batch(tsat_handle* h, const tsat_btable_options* o, int64_t T, c
   igrf_records(o->date, o->r_igrf_km, coef);
   double *dc = nullptr, *dk = nullptr, *d0 = nullptr, *d1 = nullptr, *dP = nullptr, *dB = nullptr;
   int rc = 0;
-  auto A = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 16) != hipSuccess) rc = -10; };
-  A((void**)&dc, coef.size() * 8); A((void**)&dk, Tn * 6 * 8); A((void**)&d0, Tn * 8); A((void**)&d1, Tn * 8);
-  A((void**)&dP, nP * 8); A((void**)&dB, nB * 8);
+  auto A = [&](void** p, int slot, size_t bytes) { if (!rc && !(*p = ws_get(h, slot, bytes))) rc = -10; };
+  A((void**)&dc, tsat_handle::WS_BT_COEF, coef.size() * 8); A((void**)&dk, tsat_handle::WS_BT_KEP, Tn * 6 * 8);
+  A((void**)&d0, tsat_handle::WS_BT_T0, Tn * 8); A((void**)&d1, tsat_handle::WS_BT_TF, Tn * 8);
+  A((void**)&dP, tsat_handle::WS_BT_POS, nP * 8); A((void**)&dB, tsat_handle::WS_BT_B, nB * 8);
   auto Cp = [&](void* d, const void* s, size_t bytes) { if (!rc && hipMemcpy(d, s, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -10; };
   Cp(dc, coef.data(), coef.size() * 8); Cp(dk, kep, Tn * 6 * 8); Cp(d0, t0, Tn * 8); Cp(d1, tf, Tn * 8);
   if (!rc) {
@@ -616,9 +756,6 @@ int tsat_btable_batch(tsat_handle* h, const tsat_btable_options* o, int64_t T, c
   }
   if (!rc && hipMemcpy(Btab, dB, nB * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && pos && hipMemcpy(pos, dP, nP * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
-  void* fr[] = {dc, dk, d0, d1, dP, dB};
-  for (void* q : fr)
-    if (q) (void)hipFree(q);
   if (rc) h->err = "device allocation, copy or launch failed in tsat_btable_batch";
   return rc;
 }

@@ -32,3 +32,27 @@ def magnetic_simulation(solver, kep, t0, tf, N, mjd=58155.0, gm=3.986004418e5, a
                                _abi.as_dp(pos))
     solver._check(rc, "tsat_btable_batch")
     return B, pos
+
+
+def attach_igrf_tables(solver, batch, kep=None, chunk=4096):
+    """Replace the field tables of a workload batch by IGRF-12 tables generated on the GPU for its orbits — what the
+    reference does before every solve (``magnetic_simulation(A[i,:], t0, t_final, N, ...)``, src/monte_carlo.jl:149): one
+    table per row of ``kep`` (default ``batch.meta["kep"]``), sampled over the slew horizon N dt with one row per knot step
+    (2N rows, the last one zero; the solve reads rows 0 .. N, so only the first N + 8 travel on). One orbit for the whole
+    batch, or one per trajectory."""
+    kep = np.atleast_2d(np.asarray(batch.meta["kep"] if kep is None else kep, dtype=np.float64))
+    if kep.shape[0] not in (1, batch.T):
+        raise ValueError("one orbit for the batch or one per trajectory")
+    N, dt = batch.N, float(batch.dt[0])
+    if not np.all(batch.dt == dt):
+        raise ValueError("attach_igrf_tables needs a common step")
+    rows = min(2 * N, N + 8)
+    parts = [np.ascontiguousarray(magnetic_simulation(solver, kep[a:a + chunk], 0.0, N * dt, N, want_pos=False)[0][:, :rows])
+             for a in range(0, kep.shape[0], chunk)]
+    batch.Btab = np.ascontiguousarray(np.concatenate(parts)) if len(parts) > 1 else parts[0]
+    batch.n_tab = rows
+    batch.btab_idx = np.zeros(batch.T, np.int32) if kep.shape[0] == 1 else np.arange(batch.T, dtype=np.int32)
+    batch.tau0[:] = 0.0
+    batch.dtau[:] = 1.0
+    batch.meta = dict(batch.meta, field="IGRF-12 (tsat_btable_batch)")
+    return batch

@@ -240,7 +240,7 @@ def workload_single_slew(N=500):
     return b
 
 
-def workload_monte_carlo(T=1024, N=1000, seed=20190530, random_orbit=False, degenerate_rd=None):
+def workload_monte_carlo(T=1024, N=1000, seed=20190530, random_orbit=False, degenerate_rd=None, tables=True):
     """configs[1] (and [2] with random_orbit=True): Monte-Carlo of src/monte_carlo.jl:107-198 with the initial
     attitude randomised — q0 uniform on S^3, qf = [sqrt2/2, sqrt2/2, 0, 0] (:114), 1U inertia (:31-33),
     dt 0.2, U0 ~ U(0,1e-3) (:193), Bryson weights alpha = 0.1, beta = 1e3 (:170-176), |u| <= 19 (:179),
@@ -254,18 +254,24 @@ def workload_monte_carlo(T=1024, N=1000, seed=20190530, random_orbit=False, dege
     if random_orbit:
         raan = rng.random(T) * 360.0
         nu = rng.random(T) * 360.0
-        B = np.stack([dipole_btable(N, dt, a_km, 96.6, raan[i], nu[i]) for i in range(T)])
+        # tables = False: placeholders, for callers that attach IGRF tables afterwards (magnetic.attach_igrf_tables)
+        B = np.stack([dipole_btable(N, dt, a_km, 96.6, raan[i], nu[i]) for i in range(T)]) if tables else np.zeros((T, 1, 3))
         idx = np.arange(T, dtype=np.int32)
     else:
         B = dipole_btable(N, dt, a_km, 96.6, 0.0, 0.0)
         idx = np.zeros(T, np.int32)
     b = make_batch(N, dt, q0, qf[None], INERTIA["1U"], B, idx, 0.1, 1.0e3, 19.0, U0, degenerate_rd=degenerate_rd)
+    # A[i,:] = [0, alt + R_E, 96.6, RAAN, 0, anomaly] (src/monte_carlo.jl:118-127): what magnetic.attach_igrf_tables reads
+    kep = np.zeros((T if random_orbit else 1, 6))
+    kep[:, 1], kep[:, 2] = a_km, 96.6
+    if random_orbit:
+        kep[:, 3], kep[:, 5] = raan, nu
     b.meta = dict(name="monte_carlo_random_orbit" if random_orbit else "monte_carlo", max_outer=5, max_inner=10,
-                  dj_counter_limit=1, seed=seed)
+                  dj_counter_limit=1, seed=seed, kep=kep, field="tilted dipole (surrogate)")
     return b
 
 
-def workload_inclination_sweep(T=8192, N=1000, seed=20190601, j0=0, T_total=65536):
+def workload_inclination_sweep(T=8192, N=1000, seed=20190601, j0=0, T_total=65536, tables=True):
     """configs[3] shard: deterministic inclination sweep i = 90 (j + 1/2)/T_total deg (the reference draws
     rand*90, src/paper_images/heatmap.jl:120), random RAAN / true anomaly, q0 = [0,0,1,0] (heatmap.jl:106),
     budget 3 x 50 (heatmap.jl:197-198). ``j0`` is the first global index of this shard."""
@@ -275,10 +281,13 @@ def workload_inclination_sweep(T=8192, N=1000, seed=20190601, j0=0, T_total=6553
     inc = 90.0 * (np.arange(j0, j0 + T) + 0.5) / float(T_total)
     raan = rng.random(T) * 360.0
     nu = rng.random(T) * 360.0
-    B = np.stack([dipole_btable(N, dt, a_km, inc[i], raan[i], nu[i]) for i in range(T)])
+    B = np.stack([dipole_btable(N, dt, a_km, inc[i], raan[i], nu[i]) for i in range(T)]) if tables else np.zeros((T, 1, 3))
     q0 = np.repeat(np.array([[0.0, 0.0, 1.0, 0.0]]), T, axis=0)
     qf = np.array([np.sqrt(2.0) / 2.0, np.sqrt(2.0) / 2.0, 0.0, 0.0])
     U0 = rng.random((T, N - 1, 3)) / 1000.0
     b = make_batch(N, dt, q0, qf[None], INERTIA["1U"], B, np.arange(T, dtype=np.int32), 0.1, 1.0e3, 19.0, U0)
-    b.meta = dict(name="inclination_sweep", max_outer=3, max_inner=50, dj_counter_limit=1, seed=seed)
+    kep = np.zeros((T, 6))
+    kep[:, 1], kep[:, 2], kep[:, 3], kep[:, 5] = a_km, inc, raan, nu
+    b.meta = dict(name="inclination_sweep", max_outer=3, max_inner=50, dj_counter_limit=1, seed=seed, kep=kep,
+                  field="tilted dipole (surrogate)")
     return b

@@ -114,3 +114,35 @@ class ResultGather:
             dist.all_gather_into_tensor(self.gathered["X"], self.X, group=self.group)
             dist.all_gather_into_tensor(self.gathered["U"], self.U, group=self.group)
         return self.gathered
+
+
+class NativeGather:
+    """The same per-step exchange through the library's own collective (``tsat_sweep_allgather``: export kernel +
+    ncclAllGather on the solver's stream) — what a Julia host without torch calls. torch.distributed is used here only to
+    hand the 128-byte communicator id from rank 0 to the other ranks; the gathered arrays land in torch device tensors."""
+
+    def __init__(self, solver, T, N, world, rank, device, mode="full"):
+        import torch
+        import torch.distributed as dist
+
+        self.solver, self.world, self.mode = solver, world, mode
+        idt = torch.zeros(_abi.TSAT_COMM_ID_BYTES, dtype=torch.uint8, device=device)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(solver.comm_unique_id()), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(idt, src=0)
+        solver.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        self.gathered = {}
+        if mode != "none":
+            self.gathered["stats"] = torch.empty((world * T, _abi.STATS_DTYPE.itemsize), dtype=torch.uint8, device=device)
+            if mode == "full":
+                self.gathered["X"] = torch.empty((world * T, N, 7), dtype=torch.float64, device=device)
+                self.gathered["U"] = torch.empty((world * T, N - 1, 3), dtype=torch.float64, device=device)
+
+    def gather(self):
+        if self.mode == "none":
+            return None
+        g = self.gathered
+        self.solver.sweep_allgather(g["X"].data_ptr() if "X" in g else None, g["U"].data_ptr() if "U" in g else None,
+                                    g["stats"].data_ptr(), on_device=True)
+        return g

@@ -83,12 +83,13 @@ def generated_noise(seed, ids, N, sigma_gyro=(0.38 * np.pi / 180.0) ** 2, sigma_
 
 def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noise=None, linearize_dt_sq=True,
                         u_scale=1e-2, min_steps=10, w_tol=0.05, angle_tol=0.08727, noise_seed=None, noise_ids=None,
-                        want_K=True):
+                        want_K=True, want_trajectories=True):
     """Batched ``attitude_simulation`` + slew-time statistic. ``solver`` is an AugmentedLagrangianSolver (owns the GPU
     handle); X (T,N,7), U (T,N-1,3) are the solved trajectories — or both ``None`` to track the batch that is resident on
     the device right after ``solve_`` (no re-upload of trajectories and tables; ``batch`` must be the one just solved).
     Plant noise: ``noise`` array (T,N-1,4,9), or ``noise_seed`` (+ optional per-trajectory ``noise_ids``) to have the
-    kernel draw it, or neither for the noise-free plant. Returns dict(X_sim, U_sim, K (T,N-1,6,3), stats)."""
+    kernel draw it, or neither for the noise-free plant. Returns dict(X_sim, U_sim, K (T,N-1,6,3), stats);
+    ``want_trajectories=False`` brings only the slew-time statistic back (X_sim = U_sim = None)."""
     lib = _abi.load()
     T, N = batch.T, batch.N
     o = _abi.TvlqrOptions()
@@ -114,7 +115,9 @@ def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noi
         noise = c(noise)
         if noise.shape != (T, N - 1, 4, 9):
             raise ValueError("noise must be (T, N-1, 4, 9)")
-    Xs = np.empty((T, N, 7)); Us = np.empty((T, N - 1, 3)); K = np.empty((T, N - 1, 6, 3)) if want_K else None
+    Xs = np.empty((T, N, 7)) if want_trajectories else None
+    Us = np.empty((T, N - 1, 3)) if want_trajectories else None
+    K = np.empty((T, N - 1, 6, 3)) if want_K else None
     nk = None if batch.n_knots is None else np.ascontiguousarray(batch.n_knots, dtype=np.int32)
     st = np.zeros(T, dtype=_abi.TVLQR_STATS_DTYPE)
     d = _abi.as_dp

@@ -301,6 +301,36 @@ class AugmentedLagrangianSolver:
         self._check(self._lib.tsat_batch_export_device(self._h, X_ptr, U_ptr, K_ptr, stats_ptr),
                     "tsat_batch_export_device")
 
+    # ---- sweep exchange (RCCL all-gather behind the C ABI) ------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte communicator id (rank 0 creates it, every rank passes the same bytes to ``comm_init``)."""
+        buf = C.create_string_buffer(_abi.TSAT_COMM_ID_BYTES)
+        rc = _abi.load().tsat_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError(f"tsat_comm_unique_id failed ({rc}): RCCL not available")
+        return buf.raw
+
+    def comm_init(self, id_bytes, rank, world):
+        self._check(self._lib.tsat_comm_init(self._h, bytes(id_bytes), int(rank), int(world)), "tsat_comm_init")
+        self._comm = (int(rank), int(world))
+
+    def comm_destroy(self):
+        self._check(self._lib.tsat_comm_destroy(self._h), "tsat_comm_destroy")
+
+    def sweep_allgather(self, X_all=None, U_all=None, stats_all=None, on_device=False):
+        """All ranks, after ``run``: results of every rank's shard in rank order. Arguments are raw pointers (device
+        pointers with ``on_device``), or — host mode — None to have NumPy arrays allocated and returned."""
+        if on_device:
+            self._check(self._lib.tsat_sweep_allgather(self._h, X_all, U_all, stats_all, 1), "tsat_sweep_allgather")
+            return None
+        T, N = self._shape
+        W = self._comm[1]
+        X = np.empty((W * T, N, 7)); U = np.empty((W * T, N - 1, 3)); st = np.zeros(W * T, dtype=_abi.STATS_DTYPE)
+        self._check(self._lib.tsat_sweep_allgather(self._h, X.ctypes.data_as(C.c_void_p), U.ctypes.data_as(C.c_void_p),
+                                                   st.ctypes.data_as(C.c_void_p), 0), "tsat_sweep_allgather")
+        return dict(X=X, U=U, stats=st)
+
     def trace(self, rows):
         self._check(self._lib.tsat_batch_trace(self._h, rows), "tsat_batch_trace")
         self._trace_rows = rows
