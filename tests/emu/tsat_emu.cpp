@@ -23,9 +23,11 @@ void* lds() { return g_lds; }
 
 using namespace tsat;
 
+using R = tsat::cfg_real;   // storage type of this build of the solve kernel: double, or float with -DTSAT_F32
+
 template <int INTEG, int DIAGJ, int ES>
-static void run_block(const KArgs<double>& a, int traj) {
-  std::vector<double> lds(LDS_REALS, 0.0);
+static void run_block(const KArgs<R>& a, int traj) {
+  std::vector<double> lds((LDS_BYTES + 7) / 8, 0.0);
   std::barrier<> bar(WAVE);
   tsat_emu::g_bar = &bar;
   tsat_emu::g_lds = lds.data();
@@ -33,12 +35,12 @@ static void run_block(const KArgs<double>& a, int traj) {
   for (int l = 0; l < WAVE; ++l)
     th.emplace_back([&, l]() {
       tsat_emu::g_lane = l;
-      solve_trajectory<double, INTEG, DIAGJ, ES>(a, traj);
+      solve_trajectory<R, INTEG, DIAGJ, ES>(a, traj);
     });
   for (auto& t : th) t.join();
 }
 
-extern "C" int emu_lds_bytes(void) { return LDS_REALS * (int)sizeof(double); }
+extern "C" int emu_lds_bytes(void) { return LDS_BYTES; }
 
 extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab, const double* x0, const double* xf,
                                const double* Btab, const int32_t* btab_idx, const double* tau0, const double* dtau,
@@ -49,30 +51,30 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
   const int N = o->n_knots, n_tab = o->n_tab;
   if (!check_options(*o, N, n_tab, o->max_linesearch).empty()) return -1;
   const int max_ls = o->max_linesearch < NSTORE ? o->max_linesearch : NSTORE;   // stored candidate slots
-  std::vector<double> P((size_t)T * PSTRIDE), BT((size_t)n_btab * n_tab * 4);
+  std::vector<R> P((size_t)T * PSTRIDE), BT((size_t)n_btab * n_tab * 4), U0r(U0, U0 + (size_t)T * (N - 1) * 3);
   std::vector<int> bidx(T);
-  pack_params<double>(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, P.data());
-  pack_btab<double>(n_btab, n_tab, Btab, BT.data());
+  pack_params<R>(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, P.data());
+  pack_btab<R>(n_btab, n_tab, Btab, BT.data());
   for (int64_t t = 0; t < T; ++t) bidx[t] = btab_idx ? btab_idx[t] : (int)t;
-  std::vector<double> XU((size_t)T * N * XUW, 0.0), KD((size_t)T * (N - 1) * KDW, 0.0),
-      LAM((size_t)T * (N - 1) * LMW, 0.0), CAND((size_t)T * max_ls * N * XUW, 0.0);
-  KArgs<double> a;
+  std::vector<R> XU((size_t)T * xu_stride<R>(N), (R)0), KD((size_t)T * kd_stride<R>(N), (R)0),
+      LAM((size_t)T * lam_stride<R>(N), (R)0), CAND((size_t)T * max_ls * xu_stride<R>(N), (R)0);
+  KArgs<R> a;
   a.T = (int)T; a.N = N; a.n_tab = n_tab; a.max_ls = max_ls; a.opt = *o;
-  a.P = P.data(); a.BT = BT.data(); a.bidx = bidx.data(); a.nk = n_knots; a.U0 = U0;
+  a.P = P.data(); a.BT = BT.data(); a.bidx = bidx.data(); a.nk = n_knots; a.U0 = U0r.data();
   a.XU = XU.data(); a.KD = KD.data(); a.LAM = LAM.data(); a.CAND = CAND.data();
   a.stats = stats; a.trace = trace; a.trace_rows = trace_rows;
   const int cls = inertia_class(T, Jmat);   // same variant selection as tsat_batch_upload
-  using blk_t = void (*)(const KArgs<double>&, int);
+  using blk_t = void (*)(const KArgs<R>&, int);
   static const blk_t variants[2][3][2] = {
       {{run_block<3, 0, 0>, run_block<3, 0, 1>}, {run_block<3, 1, 0>, run_block<3, 1, 1>}, {run_block<3, 2, 0>, run_block<3, 2, 1>}},
       {{run_block<4, 0, 0>, run_block<4, 0, 1>}, {run_block<4, 1, 0>, run_block<4, 1, 1>}, {run_block<4, 2, 0>, run_block<4, 2, 1>}}};
   const blk_t blk = variants[o->integrator == 4 ? 1 : 0][cls][o->error_state ? 1 : 0];
   for (int t = 0; t < (int)T; ++t) blk(a, t);
-  for (int64_t e = 0; e < T * (int64_t)N; ++e) export_record<double>(e, N, n_knots, XU.data(), KD.data(), X, U, K);
+  for (int64_t e = 0; e < T * (int64_t)N; ++e) export_record<R>(e, N, n_knots, XU.data(), KD.data(), X, U, K);
   return 0;
 }
 
-#ifndef TSAT_DENSE   // the dense build exists for the solve kernel only (tortoisesat.jl_amd/csrc/tsat_kernels_dense.hip)
+#if !defined(TSAT_DENSE) && !defined(TSAT_F32)   // the dense build exists for the solve kernel only (tortoisesat.jl_amd/csrc/tsat_kernels_dense.hip)
 template <int DIAGJ>
 static void run_mpc_block(const MpcArgs<double>& a, int traj) {
   std::vector<double> lds(LDS_REALS, 0.0);

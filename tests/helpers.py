@@ -35,7 +35,7 @@ def load_case(name, pkg, ol):
 
 
 def golden_cases():
-    return sorted(f for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("stages_"))
+    return sorted(f for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith(("stages_", "igrf12syn_")))
 
 
 def stage_golden(name):

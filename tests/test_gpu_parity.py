@@ -216,8 +216,9 @@ def test_gpu_api_errors_are_codes_not_crashes(pkg, ol, solver):
 def test_gpu_upload_rejects_degenerate_inputs(pkg, ol, solver):
     """non-finite weights / bounds and singular inertias are API errors at upload, not DIVERGED statuses later"""
     ss = pkg.slew_setup
-    with pytest.raises(ValueError):
-        ss.workload_monte_carlo(T=2, N=2)                     # Bryson R of a two-knot guess is undefined (1/0)
+    with pytest.raises(ValueError):                            # Bryson R of a guess without acceleration is undefined (1/0)
+        ss.bryson_weights(np.tile([[0.01, 0.0, 0.0]], (5, 1)), ss.INERTIA["1U"], 0.2, 0.1, 1e3)
+    assert np.all(ss.bryson_weights(np.tile([[0.01, 0.0, 0.0]], (5, 1)), ss.INERTIA["1U"], 0.2, 0.1, 1e3, degenerate_rd=0.03)[2] == 0.03)
     with pytest.raises(ValueError):
         ss.eigen_axis_slew(np.r_[0, 0, 0, 1, 0, 0, 0.], np.r_[0, 0, 0, 1, 0, 0, 0.], 0.2 * np.arange(5))
     for field, val in (("Rd", np.inf), ("Qd", np.nan), ("uhi", np.inf), ("Jmat", 0.0), ("dt", 0.0)):

@@ -66,8 +66,30 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 
 namespace tsat {
 
+// Storage / arithmetic type of the translation unit's solve kernel: double (tsat_kernels.hip, tsat_kernels_dense.hip) or
+// float (tsat_kernels_f32.hip, -DTSAT_F32: options.precision = 32). The LDS carve-up below is counted in elements of this
+// type, so the fp32 build needs half the LDS per wavefront. Whatever the storage type, costs, expected reductions and the
+// line-search test are carried in double (acc_t): J ~ 1e4 has to resolve dJ ~ 1e-4.
+#ifdef TSAT_F32
+typedef float cfg_real;
+#else
+typedef double cfg_real;
+#endif
+typedef double acc_t;
+constexpr int RPU = 16 / (int)sizeof(cfg_real);   // reals per 16-byte copy unit: 2 (double) or 4 (float)
+
+// The fp32 build comes in three LDS budgets, TSAT_OCC = wavefronts per SIMD it is laid out for (the compiler derives the
+// register budget from the LDS-limited occupancy): 2 -> <= 20 480 B, 3 -> <= 13 653 B, 4 -> <= 10 240 B per wavefront.
+#if defined(TSAT_F32) && !defined(TSAT_OCC)
+#define TSAT_OCC 2
+#endif
+
 constexpr int WAVE = 64;
-constexpr int CK = 32;    // knots per forward-sweep LDS chunk
+#if defined(TSAT_F32) && TSAT_OCC == 4
+constexpr int CK = 16;    // knots per forward-sweep LDS chunk
+#else
+constexpr int CK = 32;
+#endif
 constexpr int PSTRIDE = 64;
 // line-search candidates whose rollouts are kept in HBM. A deeper winner is re-rolled on its own (a second sweep)
 // instead of every sweep streaming all max_linesearch candidate trajectories to memory. The launch ends with its
@@ -76,7 +98,11 @@ constexpr int PSTRIDE = 64;
 constexpr int NSTORE = 12;
 // per-trajectory parameter record (reals)
 enum { P_X0 = 0, P_XF = 7, P_QD = 14, P_QFD = 21, P_RD = 28, P_ULO = 31, P_UHI = 34, P_J = 37, P_JI = 46,
-       P_TAU0 = 55, P_DTAU = 56, P_DT = 57 };
+       P_TAU0 = 55, P_DTAU = 56, P_DT = 57,
+       // slots 58..60: P_QATT (tracking kernel). 61, 62: low-order parts of the table clock — the field row of knot k is
+       // floor(fma(k + c, dtau, tau0)) in double whatever the storage type, so a float record carries tau0 and dtau as
+       // (hi, lo) pairs; zero in a double record
+       P_TAU0L = 61, P_DTAUL = 62 };
 // Jacobian record left in LDS per knot (reals): F=[A|B] column-major (column stride FS = 7), then gradients.
 // error_state = 1 appends the projected attitude block of the stage Hessian (6 unique entries of G'QG).
 constexpr int FS = 7;
@@ -84,7 +110,10 @@ constexpr int R_F = 0, R_LX = 70, R_LU = 77, R_LUU = 80, R_QQ = 83;
 template <int ES> struct BwdCfg {
   static constexpr int NH = ES ? 6 : 7;        // dimension of the state difference the gains act on
   static constexpr int RECS = ES ? 89 : 83;    // reals per knot record
-#ifdef TSAT_DENSE
+#if defined(TSAT_F32)
+  // fp32 build: 4-byte records plus the 512-byte double reduction scratch inside the budget of TSAT_OCC waves per SIMD
+  static constexpr int CHB = (TSAT_OCC == 2) ? (ES ? 51 : 55) : (TSAT_OCC == 3) ? (ES ? 31 : 33) : (ES ? 22 : 24);
+#elif defined(TSAT_DENSE)
   // "dense" build of the solve kernel (tsat_kernels_dense.hip) for batches of more than one wave per SIMD: 8 waves x
   // <= 20 KB per CU and <= 256 registers, so that two trajectories share a SIMD (1.45x fp64 issue); the price is
   // 25-knot Jacobian chunks and 88 spilled registers, 11 % per wave
@@ -95,6 +124,14 @@ template <int ES> struct BwdCfg {
 };
 // forward-sweep chunk arrays
 constexpr int KDW = 24, XUW = 10, LMW = 6, BSW = 9;
+// Per-trajectory strides of the HBM arrays, in reals, rounded up to whole 16-byte units so that every trajectory's slab
+// (and with it every LDS copy unit) starts 16-byte aligned. For double the rounding is the identity (80 / 192 / 48-byte
+// records); a float slab of an odd number of 40- or 24-byte records gets up to 12 bytes of padding.
+template <typename real> constexpr size_t pad16(size_t n) { return (n + (16 / sizeof(real)) - 1) / (16 / sizeof(real)) * (16 / sizeof(real)); }
+template <typename real> constexpr size_t xu_stride(int NS) { return pad16<real>((size_t)NS * XUW); }
+template <typename real> constexpr size_t kd_stride(int NS) { return (size_t)(NS - 1) * KDW; }
+template <typename real> constexpr size_t lam_stride(int NS) { return pad16<real>((size_t)(NS - 1) * LMW); }
+template <typename real> constexpr size_t u0_stride(int NS) { return (size_t)(NS - 1) * 3; }
 
 template <typename real>
 struct KArgs {
@@ -144,15 +181,16 @@ constexpr int L_REC = L_UNION;           // BwdCfg::CHB x BwdCfg::RECS
 // Forward-sweep chunk buffer (reals). The first five arrays are filled by global_load_lds_dwordx4 — 64 lanes x 16 bytes
 // = 128 reals per instruction, lane-linear — so each is padded to a whole number of instructions; FB_GT (activity gates
 // of the control-box rows, see forward_sweep) is derived from FB_LM once the copy has landed.
-constexpr int GLDS = 2 * WAVE;                                         // reals per copy instruction
+constexpr int GLDS = RPU * WAVE;                                       // reals per copy instruction
+constexpr int BROW_UNITS = 4 / RPU;                                    // 16-byte units per 4-real field-table row: 2 | 1
 constexpr int FB_KD = 0;                                               // CK x 24 = 6 instructions
 constexpr int FB_XU = FB_KD + ((CK * KDW + GLDS - 1) / GLDS) * GLDS;   // CK x 10 -> 3 instructions
 constexpr int FB_LM = FB_XU + ((CK * XUW + GLDS - 1) / GLDS) * GLDS;   // CK x 6  -> 2 instructions
-constexpr int FB_BA = FB_LM + ((CK * LMW + GLDS - 1) / GLDS) * GLDS;   // 3 CK stage rows, (b0, b1) -> 2 instructions
-constexpr int FB_BB = FB_BA + ((CK * 3 * 2 + GLDS - 1) / GLDS) * GLDS; // 3 CK stage rows, (b2, pad) -> 2 instructions
-constexpr int FB_GT = FB_BB + ((CK * 3 * 2 + GLDS - 1) / GLDS) * GLDS; // CK x 6
+constexpr int FB_BA = FB_LM + ((CK * LMW + GLDS - 1) / GLDS) * GLDS;   // 3 CK stage rows: (b0, b1) [double] or the whole row (b0, b1, b2, pad) [float]
+constexpr int FB_BB = FB_BA + ((CK * 3 * RPU + GLDS - 1) / GLDS) * GLDS; // 3 CK stage rows, (b2, pad) [double only]
+constexpr int FB_GT = FB_BB + (BROW_UNITS == 2 ? ((CK * 3 * RPU + GLDS - 1) / GLDS) * GLDS : 0); // CK x 6
 constexpr int FB_SIZE = FB_GT + CK * LMW;
-#ifdef TSAT_DENSE
+#if defined(TSAT_DENSE) || (defined(TSAT_F32) && TSAT_OCC >= 3)
 constexpr int FWD_NBUF = 1;   // 20 KB budget: one buffer; the second wavefront on the SIMD covers the copy latency
 #else
 constexpr int FWD_NBUF = 2;   // the next chunk is copied while this one is rolled out
@@ -167,17 +205,29 @@ constexpr int LDS_REALS = (L_FWD_END > L_BWD_END ? L_FWD_END : L_BWD_END);
 // function addresses it as LDS (address space 3) at a link-time constant address — a generic pointer argument would
 // turn ds_* into flat_* accesses, and a dynamic (extern) array makes every non-kernel function fetch its base address
 // with an s_load inside the hot loops.
-constexpr int LDS_BYTES = LDS_REALS * 8;
+// the fp32 build appends 64 doubles: scratch of the wave reductions that are carried in double (acc_t). In the fp64 builds
+// those reductions use the ordinary reduction scratch L_RED (same type), so their LDS footprint is unchanged.
+constexpr int RED64_BYTES = (sizeof(cfg_real) == 8) ? 0 : 64 * 8;
+constexpr int LDS_BYTES = LDS_REALS * (int)sizeof(cfg_real) + RED64_BYTES;
 #ifndef TSAT_EMU
 __shared__ __align__(16) unsigned char tsat_smem[LDS_BYTES];
 #endif
 template <typename real>
 TSAT_DEV real* lds_base() {
+  static_assert(sizeof(real) == sizeof(cfg_real), "the LDS carve-up is counted in the translation unit's storage type");
 #ifdef TSAT_EMU
   return reinterpret_cast<real*>(tsat_emu::lds());
 #else
   return reinterpret_cast<real*>(tsat_smem);
 #endif
+}
+TSAT_DEV acc_t* red64() {
+#ifdef TSAT_EMU
+  unsigned char* b = reinterpret_cast<unsigned char*>(tsat_emu::lds());
+#else
+  unsigned char* b = tsat_smem;
+#endif
+  return reinterpret_cast<acc_t*>(b + (RED64_BYTES ? LDS_REALS * (int)sizeof(cfg_real) : L_RED * (int)sizeof(cfg_real)));
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -201,6 +251,10 @@ TSAT_DEV double asin_(double a) { return std::asin(a); }
 TSAT_DEV double atan2_(double a, double b) { return std::atan2(a, b); }
 TSAT_DEV double fmod_(double a, double b) { return std::fmod(a, b); }
 TSAT_DEV double log_(double a) { return std::log(a); }
+TSAT_DEV float fabs_(float a) { return std::fabs(a); }
+TSAT_DEV float fmax_(float a, float b) { return a > b ? a : b; }
+TSAT_DEV float fmaxabs_(float a, float b) { const float c = std::fabs(b); return a > c ? a : c; }
+TSAT_DEV float rcp_(float a) { return 1.0f / a; }
 #else
 // v_rsq_f64 seed (rel. error <= 5.3e-8, profiles/r01/rsq_rcp_accuracy.txt) + ONE third-order step:
 // y (1 + e/2 + 3e^2/8), e = 1 - s y^2  ->  error O(e^3) ~ 1e-22, i.e. rounding only; 5 instructions instead of the 8
@@ -234,6 +288,10 @@ TSAT_DEV double asin_(double a) { return ::asin(a); }
 TSAT_DEV double atan2_(double a, double b) { return ::atan2(a, b); }
 TSAT_DEV double fmod_(double a, double b) { return ::fmod(a, b); }
 TSAT_DEV double log_(double a) { return ::log(a); }
+TSAT_DEV float fabs_(float a) { return __builtin_fabsf(a); }
+TSAT_DEV float fmax_(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+TSAT_DEV float fmaxabs_(float a, float b) { float r; asm("v_max_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+TSAT_DEV float rcp_(float a) { return __builtin_amdgcn_rcpf(a); }   // 1 ulp
 #endif
 
 // phase timing for the diagnostic build (-DTSAT_PROFILE): shader-clock stamps accumulated per phase and written to
@@ -339,7 +397,7 @@ TSAT_DEV Traj<real> load_traj(int N, int n_tab, const TSAT_GLOBAL real* bt) {
   for (int i = 0; i < 3; ++i) { tr.Rd[i] = t[P_RD + i]; tr.ulo[i] = t[P_ULO + i]; tr.uhi[i] = t[P_UHI + i]; }
   for (int i = 0; i < 9; ++i) { tr.J[i] = t[P_J + i]; tr.hJi[i] = t[TR_HJI + i]; }
   tr.h = t[P_DT]; tr.hh = t[TR_HH]; tr.us = t[TR_US];
-  tr.tau0 = (double)t[P_TAU0]; tr.dtau = (double)t[P_DTAU];
+  tr.tau0 = (double)t[P_TAU0] + (double)t[P_TAU0L]; tr.dtau = (double)t[P_DTAU] + (double)t[P_DTAUL];
   tr.N = N; tr.n_tab = n_tab; tr.bt = bt;
   return tr;
 }
@@ -594,14 +652,30 @@ TSAT_DEV real stage_cost_gated(const Traj<real>& tr, const HalfWeights<real>& hw
 // in LDS after the next vmcnt(0). The emulator copies synchronously.
 template <typename real>
 TSAT_DEV void glds_put(real* dst, const TSAT_GLOBAL real* src) {
-  static_assert(sizeof(real) == 8, "16-byte copy units are two reals");
+  static_assert(sizeof(real) == sizeof(cfg_real), "16-byte copy units are RPU reals");
 #ifdef TSAT_EMU
-  dst[0] = src[0]; dst[1] = src[1];
+  for (int i = 0; i < RPU; ++i) dst[i] = src[i];
 #else
   typedef __attribute__((address_space(1))) const void* gp_t;
   typedef __attribute__((address_space(3))) void* lp_t;
-  __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)(dst - 2 * TSAT_LANE()), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)(dst - RPU * TSAT_LANE()), 16, 0, 0);
 #endif
+}
+// the three field rows of step kk of a staged chunk (rows at tau, tau + dtau/2, tau + dtau)
+template <typename real>
+TSAT_DEV void fwd_brows(const real* fb, int kk, real b0[3], real b1[3], real b2[3]) {
+  if (BROW_UNITS == 2) {   // (b0, b1) in FB_BA, (b2, pad) in FB_BB
+    const real* ba = fb + FB_BA + kk * 6;
+    const real* bb = fb + FB_BB + kk * 6;
+    b0[0] = ba[0]; b0[1] = ba[1]; b0[2] = bb[0];
+    b1[0] = ba[2]; b1[1] = ba[3]; b1[2] = bb[2];
+    b2[0] = ba[4]; b2[1] = ba[5]; b2[2] = bb[4];
+  } else {                 // whole 16-byte rows in FB_BA
+    const real* r = fb + FB_BA + kk * 12;
+    b0[0] = r[0]; b0[1] = r[1]; b0[2] = r[2];
+    b1[0] = r[4]; b1[1] = r[5]; b1[2] = r[6];
+    b2[0] = r[8]; b2[1] = r[9]; b2[2] = r[10];
+  }
 }
 
 // Issue the copy of one forward chunk (knots k0 .. k0 + nk - 1) into the chunk buffer `fb`: gains K,d (closed-loop sweeps),
@@ -612,9 +686,11 @@ TSAT_DEV void glds_put(real* dst, const TSAT_GLOBAL real* src) {
 template <typename real>
 TSAT_DEV void fwd_chunk_issue(real* fb, const TSAT_GLOBAL real* KDg, const TSAT_GLOBAL real* XUg, const TSAT_GLOBAL real* LMg,
                               const Traj<real>& tr, int k0, int nk, int closed) {
-  static_assert(sizeof(real) == 8, "16-byte copy units are two reals");
+  static_assert(sizeof(real) == sizeof(cfg_real), "16-byte copy units are RPU reals");
   const int lane = TSAT_LANE();
-  const int n2k = (nk * KDW) >> 1, n2x = (nk * XUW) >> 1, n2l = (nk * LMW) >> 1, nb = nk * 3;   // in 16-byte units
+  // in 16-byte units, rounded up: a float chunk of an odd number of 40- / 24-byte records ends inside a unit whose tail is
+  // the next record (x,u: the terminal knot's record exists) or the slab's alignment padding (multipliers)
+  const int n2k = (nk * KDW + RPU - 1) / RPU, n2x = (nk * XUW + RPU - 1) / RPU, n2l = (nk * LMW + RPU - 1) / RPU, nb = nk * 3;
   const TSAT_GLOBAL real* kd = KDg + (size_t)k0 * KDW;
   const TSAT_GLOBAL real* xu = XUg + (size_t)k0 * XUW;
   const TSAT_GLOBAL real* lm = LMg + (size_t)k0 * LMW;
@@ -622,22 +698,22 @@ TSAT_DEV void fwd_chunk_issue(real* fb, const TSAT_GLOBAL real* KDg, const TSAT_
   if (closed)
     for (int j = 0; j < (CK * KDW + GLDS - 1) / GLDS; ++j) {
       const int i = lane + WAVE * j, ic = (i < n2k) ? i : n2k - 1;
-      put(fb + FB_KD + 2 * i, kd + 2 * ic);
+      put(fb + FB_KD + RPU * i, kd + RPU * ic);
     }
   for (int j = 0; j < (CK * XUW + GLDS - 1) / GLDS; ++j) {
     const int i = lane + WAVE * j, ic = (i < n2x) ? i : n2x - 1;
-    put(fb + FB_XU + 2 * i, xu + 2 * ic);
+    put(fb + FB_XU + RPU * i, xu + RPU * ic);
   }
   for (int j = 0; j < (CK * LMW + GLDS - 1) / GLDS; ++j) {
     const int i = lane + WAVE * j, ic = (i < n2l) ? i : n2l - 1;
-    put(fb + FB_LM + 2 * i, lm + 2 * ic);
+    put(fb + FB_LM + RPU * i, lm + RPU * ic);
   }
-  for (int j = 0; j < (CK * 3 * 2 + GLDS - 1) / GLDS; ++j) {
+  for (int j = 0; j < (CK * 3 * RPU + GLDS - 1) / GLDS; ++j) {
     const int e = lane + WAVE * j, ec = (e < nb) ? e : nb - 1;
     const int kk = ec / 3, st = ec - 3 * kk;
     const TSAT_GLOBAL real* br = tr.bt + (size_t)brow_index(tr, k0 + kk, 0.5 * (double)st) * 4;
-    put(fb + FB_BA + 2 * e, br);
-    put(fb + FB_BB + 2 * e, br + 2);
+    put(fb + FB_BA + RPU * e, br);
+    if (BROW_UNITS == 2) put(fb + FB_BB + RPU * e, br + 2);
   }
 }
 // once the copy has landed: gate = -inf where the multiplier is positive (row active whatever c is), else 0
@@ -646,8 +722,8 @@ TSAT_DEV void fwd_chunk_gates(real* fb, int nk) {
   for (int e = TSAT_LANE(); e < nk * LMW; e += WAVE) fb[FB_GT + e] = (fb[FB_LM + e] > 0) ? -inf_<real>() : (real)0;
 }
 
-template <typename real> struct FwdOut { real J; int ok; };
-template <typename real> struct BwdOut { real dV1, dV2; int pd_ok; };
+template <typename real> struct FwdOut { acc_t J; int ok; };
+template <typename real> struct BwdOut { acc_t dV1, dV2; int pd_ok; };
 
 // --------------------------------------------------------------------------------------------------
 // forward sweep: all line-search candidates at once (lane j: alpha = 2^-j). Returns this lane's AL cost and
@@ -663,7 +739,8 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
   for (int j = 0; j < lane + alpha_shift && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (real)0.5;
   real x[7];
   for (int i = 0; i < 7; ++i) x[i] = lds[L_TR + P_X0 + i];
-  real J = 0, amax = 0;
+  acc_t J = 0;
+  real amax = 0;
   const TSAT_GLOBAL real* XUg = p.XU;
   const TSAT_GLOBAL real* KDg = p.KD;
   const TSAT_GLOBAL real* LMg = p.LAM;
@@ -717,16 +794,14 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
       }
       for (int i = 0; i < 7; ++i) amax = fmaxabs_(amax, x[i]);
       for (int c = 0; c < 3; ++c) amax = fmaxabs_(amax, u[c]);
-      J += stage_cost_gated(tr, hw, x, u, LMc + kk * LMW, GTc + kk * LMW);
+      J += (acc_t)stage_cost_gated(tr, hw, x, u, LMc + kk * LMW, GTc + kk * LMW);
       if (lane < n_cand) {
         TSAT_GLOBAL real* cr = Cg + (size_t)(k0 + kk) * XUW;
         for (int i = 0; i < 7; ++i) cr[i] = x[i];
         for (int c = 0; c < 3; ++c) cr[7 + c] = u[c];
       }
-      real xn[7];
-      const real* ba = fb + FB_BA + kk * 6;   // stage rows tau, tau + dtau/2, tau + dtau: (b0, b1) here, (b2, pad) in FB_BB
-      const real* bb = fb + FB_BB + kk * 6;
-      const real b0[3] = {ba[0], ba[1], bb[0]}, b1[3] = {ba[2], ba[3], bb[2]}, b2[3] = {ba[4], ba[5], bb[4]};
+      real xn[7], b0[3], b1[3], b2[3];
+      fwd_brows<real>(fb, kk, b0, b1, b2);    // stage rows tau, tau + dtau/2, tau + dtau
       rk_step<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, xn);
       for (int i = 0; i < 7; ++i) x[i] = xn[i];
     }
@@ -744,7 +819,7 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
   for (int i = 0; i < 7; ++i) amax = fmaxabs_(amax, x[i]);
   real nu[7];
   for (int i = 0; i < 7; ++i) nu[i] = lds[L_NU + i];
-  J += term_cost(tr, x, nu, mu, term_mask, true);
+  J += (acc_t)term_cost(tr, x, nu, mu, term_mask, true);
   if (lane < n_cand) {
     TSAT_GLOBAL real* cr = Cg + (size_t)(N - 1) * XUW;
     for (int i = 0; i < 7; ++i) cr[i] = x[i];
@@ -752,7 +827,7 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
   }
   FwdOut<real> out;
   out.J = J;
-  out.ok = ((amax <= max_state) && (J == J)) ? 1 : 0;
+  out.ok = ((amax <= max_state) && (J == J)) ? 1 : 0;   // a non-finite rollout leaves amax = inf or J = NaN
   return out;
 }
 
@@ -852,7 +927,7 @@ TSAT_DEV void pair_ut(int L, int n, int& i, int& j) {  // L in [0, n(n+1)/2) -> 
 // the lane-role tables live in registers for exactly this loop (nothing survives the call to jacobian_chunk).
 // NH = 7: plain state differences; NH = 6: error coordinates (records reduced by jacobian_chunk).
 template <typename real, int NH>
-TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, real rho, real dV1, real dV2) {
+TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, real rho, acc_t dV1, acc_t dV2) {
   constexpr int ES = (NH == 6) ? 1 : 0;
   constexpr int RECS = BwdCfg<ES>::RECS;
   constexpr int NC = NH + 3;               // columns of [A|B]
@@ -996,8 +1071,8 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
       TSAT_SCHED_FENCE();
       // dV1 += d'Qu ; dV2 += 0.5 d'Quu d. With d = -Quu_reg^-1 Qu: Quu d = -Qu - rho d, so d'Quu d = -(d'Qu + rho d'd)
       const real dqu = d0 * qu0 + d1 * qu1 + d2 * qu2;
-      dV1 += dqu;
-      dV2 -= (real)0.5 * (dqu + rho * (d0 * d0 + d1 * d1 + d2 * d2));
+      dV1 += (acc_t)dqu;
+      dV2 -= (acc_t)((real)0.5 * (dqu + rho * (d0 * d0 + d1 * d1 + d2 * d2)));
       real acc = b1 + b2;
       real sy = 0, kk = 0;
       for (int c = 0; c < 3; ++c) {
@@ -1097,25 +1172,26 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
 // --------------------------------------------------------------------------------------------------
 // AL (or plain LQR) cost of the nominal trajectory
 template <typename real>
-TSAT_PHASE real nominal_cost(TPtrs<real> p, int N, real mu, int term_mask, int with_al) {
+TSAT_PHASE acc_t nominal_cost(TPtrs<real> p, int N, real mu, int term_mask, int with_al) {
   real* lds = lds_base<real>();
   const Traj<real> tr = load_traj<real>(N, 1, p.bt);
   const int lane = TSAT_LANE();
   real nu[7];
   for (int i = 0; i < 7; ++i) nu[i] = lds[L_NU + i];
-  real J = 0;
+  acc_t J = 0;
   for (int k = lane; k < N; k += WAVE) {
     real x[7], u[3], lam[6];
     for (int i = 0; i < 7; ++i) x[i] = p.XU[(size_t)k * XUW + i];
     if (k < N - 1) {
       for (int c = 0; c < 3; ++c) u[c] = p.XU[(size_t)k * XUW + 7 + c];
       for (int c = 0; c < 6; ++c) lam[c] = p.LAM[(size_t)k * LMW + c];
-      J += stage_cost(tr, x, u, lam, mu, with_al != 0);
+      J += (acc_t)stage_cost(tr, x, u, lam, mu, with_al != 0);
     } else {
-      J += term_cost(tr, x, nu, mu, term_mask, with_al != 0);
+      J += (acc_t)term_cost(tr, x, nu, mu, term_mask, with_al != 0);
     }
   }
-  return wave_sum(J, lds + L_RED);
+  (void)lds;
+  return wave_sum(J, red64());
 }
 
 // max constraint violation of the nominal trajectory; optionally applies the dual update of the control-box
@@ -1187,14 +1263,14 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   const int NS = a.N, n_tab = a.n_tab;
   const int N = a.nk ? a.nk[traj] : a.N;
   TPtrs<real> p;
-  p.XU = (TSAT_GLOBAL real*)(a.XU + (size_t)traj * NS * XUW);
-  p.KD = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * (NS - 1) * KDW);
-  p.LAM = (TSAT_GLOBAL real*)(a.LAM + (size_t)traj * (NS - 1) * LMW);
-  p.CAND = (TSAT_GLOBAL real*)(a.CAND + (size_t)traj * a.max_ls * (size_t)NS * XUW);
+  p.XU = (TSAT_GLOBAL real*)(a.XU + (size_t)traj * xu_stride<real>(NS));
+  p.KD = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * kd_stride<real>(NS));
+  p.LAM = (TSAT_GLOBAL real*)(a.LAM + (size_t)traj * lam_stride<real>(NS));
+  p.CAND = (TSAT_GLOBAL real*)(a.CAND + (size_t)traj * a.max_ls * xu_stride<real>(NS));
   p.bt = (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[traj] * n_tab * 4);
   stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)traj * PSTRIDE), (real)o.u_scale);
 
-  const real* U0g = a.U0 + (size_t)traj * (NS - 1) * 3;
+  const real* U0g = a.U0 + (size_t)traj * u0_stride<real>(NS);
   double* trace = a.trace ? a.trace + (size_t)traj * a.trace_rows * 8 : nullptr;
   int trow = 0;
 
@@ -1218,7 +1294,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   // open-loop rollout of U0
   FwdOut<real> f0 = forward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, 0, 1, 0, mu, tmask, max_state);
   n_forward++;
-  const real J0 = wave_bcast(f0.J, 0, lds + L_RED);
+  const acc_t J0 = wave_bcast(f0.J, 0, red64());
   const int ok0 = wave_first<real>(!f0.ok, lds + L_RED) > 0;  // lane 0 ok?
   TSAT_SYNC();
   (void)adopt_and_gradient<real>(p, N, 0);
@@ -1227,7 +1303,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
     status = TSAT_DIVERGED;
   } else {
     for (int outer = 1; outer <= o.max_outer; ++outer) {
-      real Jprev = nominal_cost<real>(p, N, mu, tmask, 1);
+      acc_t Jprev = nominal_cost<real>(p, N, mu, tmask, 1);
       real rho = (real)o.reg_init, drho = 0;
       int djz = 0;
       bool regfail = false;
@@ -1243,7 +1319,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
           if (rho > (real)o.reg_max) { regfail = true; break; }
         }
         if (regfail) break;
-        const real dV1 = bw.dV1, dV2 = bw.dV2;
+        const acc_t dV1 = bw.dV1, dV2 = bw.dV2;
         const real rho_used = rho;
         {  // regularisation decrease
           const real inv = (real)1 / (real)o.reg_scale;
@@ -1259,18 +1335,18 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
         const unsigned long long t_f1 = tick_();
         pc_fwd += t_f1 - t_f0;
         n_forward++;
-        const real Jc = fw.J;
-        real alpha = 1;
-        for (int j = 0; j < lane && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (real)0.5;
-        const real expected = -alpha * (dV1 + alpha * dV2);
-        const real z = (expected > 0) ? (Jprev - Jc) / expected : (real)-1;
+        const acc_t Jc = fw.J;
+        acc_t alpha = 1;
+        for (int j = 0; j < lane && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (acc_t)0.5;
+        const acc_t expected = -alpha * (dV1 + alpha * dV2);
+        const acc_t z = (expected > 0) ? (Jprev - Jc) / expected : (acc_t)-1;
         const bool acc = (lane < o.max_linesearch) && fw.ok &&
-                         ((z > (real)o.ls_lower && z <= (real)o.ls_upper) || Jc < Jprev);
+                         ((z > (acc_t)o.ls_lower && z <= (acc_t)o.ls_upper) || Jc < Jprev);
         const int jw = wave_first<real>(acc, lds + L_RED);
-        real J;
+        acc_t J;
         TSAT_SYNC();
         if (jw < WAVE) {
-          J = wave_bcast(Jc, jw, lds + L_RED);
+          J = wave_bcast(Jc, jw, red64());
           ls_trials += jw + 1;
           int slot = jw;
           if (jw >= n_store) {   // the winner's rollout was not kept: roll out that one alpha again, into slot 0
@@ -1291,7 +1367,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
         }
         TSAT_SYNC();
         pc_par += tick_() - t_f1;
-        real dJ = J - Jprev;
+        acc_t dJ = J - Jprev;
         dJ = dJ < 0 ? -dJ : dJ;
         if (trace && lane == 0 && trow < a.trace_rows) {
           double* r = trace + 8 * trow;
@@ -1302,7 +1378,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
         Jprev = J;
         djz = (dJ == 0) ? djz + 1 : 0;
         inner_iters++;
-        if (0 < dJ && dJ < (real)o.cost_tol) break;
+        if (0 < dJ && dJ < (acc_t)o.cost_tol) break;
         if (grad < (real)o.grad_tol) break;
         if (djz > o.dj_counter_limit) break;
       }
@@ -1324,8 +1400,8 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   }
   TSAT_SYNC();
   const real cmax = violation_and_duals<real>(p, N, mu, tmask, 0, (real)o.dual_max);
-  const real cost = nominal_cost<real>(p, N, mu, tmask, 0);
-  const real cost_al = nominal_cost<real>(p, N, mu, tmask, 1);
+  const acc_t cost = nominal_cost<real>(p, N, mu, tmask, 0);
+  const acc_t cost_al = nominal_cost<real>(p, N, mu, tmask, 1);
   if (lane == 0) {
     tsat_stats& st = a.stats[traj];
     st.status = status; st.outer_iters = outer_iters; st.inner_iters = inner_iters; st.ls_trials = ls_trials;

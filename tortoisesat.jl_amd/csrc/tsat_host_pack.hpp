@@ -84,7 +84,7 @@ inline std::string check_options(const tsat_options& o, int N, int n_tab, int ma
   if (N < 2) return "n_knots must be >= 2";
   if (n_tab < 1) return "n_tab must be >= 1";
   if (o.integrator != 3 && o.integrator != 4) return "integrator must be 3 (rk3) or 4 (rk4)";
-  if (o.precision != 64) return "only precision = 64 is implemented";
+  if (o.precision != 64 && o.precision != 32) return "precision must be 64 or 32";
   if (o.error_state != 0 && o.error_state != 1) return "error_state must be 0 or 1";
   if (o.max_linesearch < 1 || o.max_linesearch > TSAT_MAX_LINESEARCH) return "max_linesearch must be in [1,32]";
   if (o.max_linesearch > max_ls_reserved) return "max_linesearch exceeds the reserved candidate slots";
@@ -119,6 +119,10 @@ void pack_params(int64_t T, const double* x0, const double* xf, const double* ta
     p[P_TAU0] = (real)tau0[t];
     p[P_DTAU] = (real)dtau[t];
     p[P_DT] = (real)dt[t];
+    // a float record carries the table clock as (hi, lo) pairs so that the field row of every knot is the double-precision
+    // floor(fma(k + c, dtau, tau0)) of the fp64 builds; exact zeros in a double record
+    p[P_TAU0L] = (real)(tau0[t] - (double)p[P_TAU0]);
+    p[P_DTAUL] = (real)(dtau[t] - (double)p[P_DTAU]);
   }
 }
 
@@ -141,7 +145,7 @@ TSAT_DEV void export_record(int64_t e, int N, const int* nk, const real* XU, con
   const int64_t t = e / N;
   const int k = (int)(e - t * N);
   const int n = nk ? nk[t] : N;           // knots this trajectory actually has; the rest of its slab is zero-filled
-  const real* r = XU + (size_t)e * XUW;
+  const real* r = XU + (size_t)t * xu_stride<real>(N) + (size_t)k * XUW;
   if (X)
     for (int i = 0; i < 7; ++i) X[(size_t)e * 7 + i] = (k < n) ? (double)r[i] : 0.0;
   if (k < N - 1) {
@@ -150,7 +154,7 @@ TSAT_DEV void export_record(int64_t e, int N, const int* nk, const real* XU, con
     if (U)
       for (int c = 0; c < 3; ++c) U[ek * 3 + c] = live ? (double)r[7 + c] : 0.0;
     if (K) {
-      const real* kd = KD + ek * KDW;
+      const real* kd = KD + (size_t)t * kd_stride<real>(N) + (size_t)k * KDW;
       for (int j = 0; j < 7; ++j)
         for (int c = 0; c < 3; ++c) K[ek * 21 + j * 3 + c] = live ? (double)kd[c * 7 + j] : 0.0;
     }

@@ -16,6 +16,10 @@ using namespace tsat;
 
 // the dense build of the solve kernel lives in its own translation unit (tsat_kernels_dense.hip)
 hipError_t tsat_launch_solve_dense(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+// the fp32 build (options.precision = 32) likewise (tsat_kernels_f32.hip)
+hipError_t tsat_launch_solve_f32_o2(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+hipError_t tsat_launch_solve_f32_o3(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+hipError_t tsat_launch_solve_f32_o4(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -55,6 +59,22 @@ __global__ __launch_bounds__(64) void tsat_horizon_kernel(HzArgs<real> a) {
   horizon_trajectory<real>(a, traj);
 }
 
+// double -> float copies of the uploaded tables and initial controls for the fp32 build, and float -> double widening of the
+// fp32 build's (x,u) records for the (fp64) tracking kernel
+__global__ __launch_bounds__(256) void tsat_narrow_kernel(int64_t n, const double* src, float* dst) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) dst[e] = (float)src[e];
+}
+__global__ __launch_bounds__(256) void tsat_widen_records_kernel(int64_t n_rec, int N, const float* XU32, double* XU64) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_rec) return;
+  const int64_t t = e / N;
+  const int k = (int)(e - t * N);
+  const float* r = XU32 + (size_t)t * xu_stride<float>(N) + (size_t)k * XUW;
+  double* w = XU64 + (size_t)e * XUW;
+  for (int i = 0; i < XUW; ++i) w[i] = (double)r[i];
+}
+
 template <typename real>
 __global__ __launch_bounds__(256) void tsat_export_kernel(int64_t n_rec, int N, const int* nk, const real* XU,
                                                           const real* KD, double* X, double* U, double* K) {
@@ -85,6 +105,13 @@ struct tsat_handle {
   int variant = 0;            // solve-kernel build: 0 automatic (dense above 1024 trajectories), 1 wide, 2 dense
   // host copies of the small per-trajectory inputs of the last upload (26 doubles each), for tsat_tvlqr_resident
   std::vector<double> hx0, hxf, htau0, hdtau, hdt, hJ;
+  // fp32 build: float parameter records packed at upload (host), float mirrors of the tables / initial controls made on the
+  // device at the first precision = 32 run after an upload; the solver's own arrays (XU, KD, LAM, CAND) are shared with
+  // the fp64 builds (allocated for doubles, used as floats)
+  std::vector<float> hP32;
+  float *P32 = nullptr, *BT32 = nullptr, *U032 = nullptr;
+  bool f32_ready = false;
+  int solved_precision = 64;
   // grow-only device workspaces of the stages around the solve (tracking, horizon, field tables, MPC history, export):
   // allocated on first use and kept for the life of the handle, so repeated calls pay no hipMalloc / hipFree
   enum { WS_TV_NZ, WS_TV_KD, WS_TV_XS, WS_TV_NID, WS_TV_ST, WS_TV_P, WS_TVB_P, WS_TVB_BT, WS_TVB_XUR, WS_TVB_BI, WS_TVB_NK,
@@ -111,10 +138,11 @@ int fail(tsat_handle* h, int code, const std::string& msg) {
   } while (0)
 
 void release(tsat_handle* h) {
-  void* ptrs[] = {h->P, h->BT, h->U0, h->XU, h->KD, h->LAM, h->CAND, h->bidx, h->nk, h->stats, h->trace};
+  void* ptrs[] = {h->P, h->BT, h->U0, h->XU, h->KD, h->LAM, h->CAND, h->bidx, h->nk, h->stats, h->trace, h->P32, h->BT32, h->U032};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->P = h->BT = h->U0 = h->XU = h->KD = h->LAM = h->CAND = nullptr;
+  h->P32 = h->BT32 = h->U032 = nullptr; h->f32_ready = false;
   h->bidx = nullptr; h->nk = nullptr; h->ragged = false; h->stats = nullptr; h->trace = nullptr;
   h->T = 0; h->bytes = 0; h->uploaded = h->solved = false;
 }
@@ -270,6 +298,9 @@ int tsat_batch_upload(tsat_handle* h, const double* x0, const double* xf, const 
   TSAT_HIP(h, hipMemcpy(h->U0, U0, (size_t)T * (h->N - 1) * 3 * sizeof(double), hipMemcpyHostToDevice));
   h->hx0.assign(x0, x0 + 7 * T); h->hxf.assign(xf, xf + 7 * T); h->htau0.assign(tau0, tau0 + T);
   h->hdtau.assign(dtau, dtau + T); h->hdt.assign(dt, dt + T); h->hJ.assign(Jmat, Jmat + 9 * T);
+  h->hP32.resize((size_t)T * PSTRIDE);
+  pack_params<float>(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, h->hP32.data());
+  h->f32_ready = false;
   h->uploaded = true;
   h->solved = false;
   h->ragged = false;   // a fresh upload is a uniform batch until tsat_batch_knots says otherwise
@@ -307,7 +338,7 @@ solve_kern_t solve_variant(const tsat_handle* h, const tsat_options* o) {
 // One wave per SIMD (wide build) as long as the batch fits the GPU that way — 256 CUs x 4 SIMDs — else two (dense build)
 constexpr int64_t TSAT_WIDE_MAX_T = 1024;
 hipError_t launch_solve(const tsat_handle* h, const tsat_options* o, const KArgs<double>& a) {
-  const bool dense = h->variant == 2 || (h->variant == 0 && h->T > TSAT_WIDE_MAX_T);
+  const bool dense = h->variant == 2 || (h->variant != 1 && h->T > TSAT_WIDE_MAX_T);
   if (dense) return tsat_launch_solve_dense(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream);
   hipLaunchKernelGGL(solve_variant(h, o), dim3((unsigned)h->T), dim3(64), 0, h->stream, a);
   return hipGetLastError();
@@ -321,6 +352,34 @@ KArgs<double> solve_args(const tsat_handle* h, const tsat_options* o) {
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
   return a;
 }
+
+// float mirrors of the inputs for the fp32 build, made once per upload (outside any timed region)
+int ensure_f32_mirrors(tsat_handle* h) {
+  if (h->f32_ready) return 0;
+  const size_t T = (size_t)h->T, nBT = (size_t)h->n_btab * h->n_tab * 4, nU0 = T * u0_stride<float>(h->N);
+  if (!h->P32 && hipMalloc((void**)&h->P32, T * PSTRIDE * sizeof(float)) != hipSuccess) return -10;
+  if (!h->BT32 && hipMalloc((void**)&h->BT32, nBT * sizeof(float)) != hipSuccess) return -10;
+  if (!h->U032 && hipMalloc((void**)&h->U032, (nU0 ? nU0 : 4) * sizeof(float)) != hipSuccess) return -10;
+  if (hipMemcpyAsync(h->P32, h->hP32.data(), T * PSTRIDE * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) return -10;
+  hipLaunchKernelGGL(tsat_narrow_kernel, dim3((unsigned)((nBT + 255) / 256)), dim3(256), 0, h->stream, (int64_t)nBT, h->BT, h->BT32);
+  if (nU0) hipLaunchKernelGGL(tsat_narrow_kernel, dim3((unsigned)((nU0 + 255) / 256)), dim3(256), 0, h->stream, (int64_t)nU0, h->U0, h->U032);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -10;
+  h->f32_ready = true;
+  return 0;
+}
+// the fp32 build on the solver's own arrays (allocated for doubles, used as floats)
+int launch_solve_f32(tsat_handle* h, const tsat_options* o) {
+  KArgs<float> a;
+  a.T = (int)h->T; a.N = h->N; a.n_tab = h->n_tab; a.max_ls = h->max_ls < NSTORE ? h->max_ls : NSTORE; a.opt = *o;
+  a.P = h->P32; a.BT = h->BT32; a.bidx = h->bidx; a.nk = h->ragged ? h->nk : nullptr; a.U0 = h->U032;
+  a.XU = (float*)h->XU; a.KD = (float*)h->KD; a.LAM = (float*)h->LAM; a.CAND = (float*)h->CAND;
+  a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
+  // build by batch size: the layout for two wavefronts per SIMD while the batch fits the GPU that way (256 CUs x 4 SIMDs x 2),
+  // else the one for four; tsat_set_kernel_variant(h, 12 | 13 | 14) forces one (tuning, tests)
+  const int occ = (h->variant >= 12 && h->variant <= 14) ? h->variant - 10 : (h->T <= 2048 ? 2 : 4);
+  auto fn = occ == 2 ? tsat_launch_solve_f32_o2 : (occ == 3 ? tsat_launch_solve_f32_o3 : tsat_launch_solve_f32_o4);
+  return fn(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream) == hipSuccess ? 0 : -10;
+}
 }  // namespace
 
 int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
@@ -331,18 +390,27 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
   TSAT_HIP(h, hipSetDevice(h->dev));
   const KArgs<double> a = solve_args(h, o);
   if (h->trace) TSAT_HIP(h, hipMemsetAsync(h->trace, 0, (size_t)h->T * h->trace_rows * 8 * sizeof(double), h->stream));
-  TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
-  TSAT_HIP(h, launch_solve(h, o, a));
+  if (o->precision == 32) {
+    // first fp32 run after an upload: the float mirrors are built before the events, so that kernel_ms is the solve alone
+    if (ensure_f32_mirrors(h)) return fail(h, -10, "device allocation or copy failed while preparing the fp32 inputs");
+    TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
+    if (launch_solve_f32(h, o)) return fail(h, -10, "launch of the fp32 solve kernel failed");
+  } else {
+    TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
+    TSAT_HIP(h, launch_solve(h, o, a));
+  }
   TSAT_HIP(h, hipEventRecord(h->ev1, h->stream));
   TSAT_HIP(h, hipStreamSynchronize(h->stream));
   if (kernel_ms) TSAT_HIP(h, hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
   h->solved = true;
+  h->solved_precision = o->precision;
   return 0;
 }
 
 int tsat_set_kernel_variant(tsat_handle* h, int32_t variant) {
   if (!h) return -1;
-  if (variant < 0 || variant > 2) return fail(h, -1, "variant must be 0 (automatic), 1 (wide) or 2 (dense)");
+  if (!((variant >= 0 && variant <= 2) || (variant >= 12 && variant <= 14)))
+    return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), or 12 / 13 / 14 (fp32 layouts for 2 / 3 / 4 waves per SIMD)");
   h->variant = variant;
   return 0;
 }
@@ -354,6 +422,7 @@ int tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t
   const std::string why = check_options(*o, h->N, h->n_tab, h->max_ls);
   if (!why.empty()) return fail(h, -1, why);
   if (n_steps < 1) return fail(h, -1, "n_steps must be >= 1");
+  if (o->precision != 64) return fail(h, -1, "tsat_mpc_run runs the fp64 build only (precision must be 64)");
   if (plant_integrator != 3 && plant_integrator != 4) return fail(h, -1, "plant_integrator must be 3 (rk3) or 4 (rk4)");
   if (!X_hist || !U_hist) return fail(h, -1, "null array");
   TSAT_HIP(h, hipSetDevice(h->dev));
@@ -390,7 +459,16 @@ int tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t
     for (int i = 0; i < 7; ++i) h->hx0[7 * t + i] = Pb[t * PSTRIDE + P_X0 + i];
     h->htau0[t] = Pb[t * PSTRIDE + P_TAU0];
   }
+  // the float mirrors of the fp32 build describe the UPLOADED x0 / tau0 / U0: refresh them from the advanced state
+  for (size_t t = 0; t < T; ++t) {
+    float* p32 = h->hP32.data() + t * PSTRIDE;
+    for (int i = 0; i < 7; ++i) p32[P_X0 + i] = (float)Pb[t * PSTRIDE + P_X0 + i];
+    p32[P_TAU0] = (float)Pb[t * PSTRIDE + P_TAU0];
+    p32[P_TAU0L] = (float)(Pb[t * PSTRIDE + P_TAU0] - (double)p32[P_TAU0]);
+  }
+  h->f32_ready = false;
   h->solved = true;
+  h->solved_precision = 64;
   return 0;
 }
 
@@ -401,9 +479,14 @@ int tsat_batch_export_device(tsat_handle* h, void* X_dev, void* U_dev, void* K_d
   const int64_t n_rec = h->T * (int64_t)h->N;
   if (X_dev || U_dev || K_dev) {
     const unsigned blocks = (unsigned)((n_rec + 255) / 256);
-    hipLaunchKernelGGL(tsat_export_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, n_rec, h->N,
-                       h->ragged ? h->nk : nullptr, h->XU, h->KD,
-                       (double*)X_dev, (double*)U_dev, (double*)K_dev);
+    if (h->solved_precision == 32)
+      hipLaunchKernelGGL(tsat_export_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, n_rec, h->N,
+                         h->ragged ? h->nk : nullptr, (const float*)h->XU, (const float*)h->KD,
+                         (double*)X_dev, (double*)U_dev, (double*)K_dev);
+    else
+      hipLaunchKernelGGL(tsat_export_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, n_rec, h->N,
+                         h->ragged ? h->nk : nullptr, h->XU, h->KD,
+                         (double*)X_dev, (double*)U_dev, (double*)K_dev);
     TSAT_HIP(h, hipGetLastError());
   }
   if (stats_dev)
@@ -561,7 +644,19 @@ int tsat_tvlqr_resident(tsat_handle* h, const tsat_tvlqr_options* o, const doubl
   double* dP = (double*)ws_get(h, tsat_handle::WS_TV_P, P.size() * 8);
   if (!dP) return fail(h, -10, "device allocation failed in tsat_tvlqr_resident");
   int rc = hipMemcpy(dP, P.data(), P.size() * 8, hipMemcpyHostToDevice) == hipSuccess ? 0 : -10;
-  if (!rc) rc = run_tvlqr(h, &oo, T, h->N, h->n_tab, h->inertia_class, dP, h->BT, h->bidx, h->ragged ? h->nk : nullptr, h->XU,
+  const double* dXUR = h->XU;
+  if (!rc && h->solved_precision == 32) {   // the tracking kernel is fp64: widen the fp32 build's records into a workspace
+    const int64_t n_rec = T * (int64_t)h->N;
+    double* w = (double*)ws_get(h, tsat_handle::WS_TVB_XUR, (size_t)n_rec * XUW * 8);
+    if (!w) rc = -10;
+    if (!rc) {
+      hipLaunchKernelGGL(tsat_widen_records_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, h->stream, n_rec, h->N,
+                         (const float*)h->XU, w);
+      if (hipGetLastError() != hipSuccess) rc = -10;
+      dXUR = w;
+    }
+  }
+  if (!rc) rc = run_tvlqr(h, &oo, T, h->N, h->n_tab, h->inertia_class, dP, h->BT, h->bidx, h->ragged ? h->nk : nullptr, dXUR,
                           noise, noise_id, X_sim, U_sim, K_lqr, stats);
   if (rc) h->err = "device allocation, copy or launch failed in tsat_tvlqr_resident";
   return rc;
@@ -697,8 +792,12 @@ int tsat_sweep_allgather(tsat_handle* h, void* X_all, void* U_all, void* stats_a
   }
   const int64_t n_rec = h->T * (int64_t)h->N;
   if (dX || dU) {
-    hipLaunchKernelGGL(tsat_export_kernel<double>, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, h->stream, n_rec, h->N,
-                       h->ragged ? h->nk : nullptr, h->XU, h->KD, dX, dU, (double*)nullptr);
+    if (h->solved_precision == 32)
+      hipLaunchKernelGGL(tsat_export_kernel<float>, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, h->stream, n_rec, h->N,
+                         h->ragged ? h->nk : nullptr, (const float*)h->XU, (const float*)h->KD, dX, dU, (double*)nullptr);
+    else
+      hipLaunchKernelGGL(tsat_export_kernel<double>, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, h->stream, n_rec, h->N,
+                         h->ragged ? h->nk : nullptr, h->XU, h->KD, dX, dU, (double*)nullptr);
     TSAT_HIP(h, hipGetLastError());
   }
   if (dS) TSAT_HIP(h, hipMemcpyAsync(dS, h->stats, nS, hipMemcpyDeviceToDevice, h->stream));
