@@ -20,6 +20,9 @@ void* lds() { return g_lds; }
 }  // namespace tsat_emu
 
 #include "../../tortoisesat.jl_amd/csrc/tsat_host_pack.hpp"
+#ifdef TSAT_PACKED
+#include "../../tortoisesat.jl_amd/csrc/tsat_packed.hpp"   // PK_G trajectories per emulated wavefront
+#endif
 
 using namespace tsat;
 
@@ -35,7 +38,11 @@ static void run_block(const KArgs<R>& a, int traj) {
   for (int l = 0; l < WAVE; ++l)
     th.emplace_back([&, l]() {
       tsat_emu::g_lane = l;
+#ifdef TSAT_PACKED
+      solve_group<R, INTEG, DIAGJ, ES>(a, traj);      // `traj` = wave index
+#else
       solve_trajectory<R, INTEG, DIAGJ, ES>(a, traj);
+#endif
     });
   for (auto& t : th) t.join();
 }
@@ -69,7 +76,11 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
       {{run_block<3, 0, 0>, run_block<3, 0, 1>}, {run_block<3, 1, 0>, run_block<3, 1, 1>}, {run_block<3, 2, 0>, run_block<3, 2, 1>}},
       {{run_block<4, 0, 0>, run_block<4, 0, 1>}, {run_block<4, 1, 0>, run_block<4, 1, 1>}, {run_block<4, 2, 0>, run_block<4, 2, 1>}}};
   const blk_t blk = variants[o->integrator == 4 ? 1 : 0][cls][o->error_state ? 1 : 0];
+#ifdef TSAT_PACKED
+  for (int w = 0; w * PK_G < (int)T; ++w) blk(a, w);
+#else
   for (int t = 0; t < (int)T; ++t) blk(a, t);
+#endif
   for (int64_t e = 0; e < T * (int64_t)N; ++e) export_record<R>(e, N, n_knots, XU.data(), KD.data(), X, U, K);
   return 0;
 }

@@ -16,6 +16,8 @@ using namespace tsat;
 
 // the dense build of the solve kernel lives in its own translation unit (tsat_kernels_dense.hip)
 hipError_t tsat_launch_solve_dense(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+// the packed build — 8 trajectories per wavefront share the forward sweeps (tsat_kernels_packed.hip, tsat_packed.hpp)
+hipError_t tsat_launch_solve_packed(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 // the fp32 build (options.precision = 32) likewise (tsat_kernels_f32.hip)
 hipError_t tsat_launch_solve_f32_o2(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_f32_o3(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
@@ -335,9 +337,14 @@ solve_kern_t solve_variant(const tsat_handle* h, const tsat_options* o) {
   return variants[o->integrator == 4 ? 1 : 0][h->inertia_class][o->error_state ? 1 : 0];
 }
 
-// One wave per SIMD (wide build) as long as the batch fits the GPU that way — 256 CUs x 4 SIMDs — else two (dense build)
+// One wave per SIMD (wide build) as long as the batch fits the GPU that way — 256 CUs x 4 SIMDs — else two (dense build);
+// from 8 trajectories per resident wavefront slot on (2048 slots at two waves per SIMD) the packed build, whose wavefronts
+// own 8 trajectories each and still fill the machine
 constexpr int64_t TSAT_WIDE_MAX_T = 1024;
+constexpr int64_t TSAT_PACKED_MIN_T = 8192;
 hipError_t launch_solve(const tsat_handle* h, const tsat_options* o, const KArgs<double>& a) {
+  const bool packed = h->variant == 3 || (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T);
+  if (packed) return tsat_launch_solve_packed(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream);
   const bool dense = h->variant == 2 || (h->variant != 1 && h->T > TSAT_WIDE_MAX_T);
   if (dense) return tsat_launch_solve_dense(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream);
   hipLaunchKernelGGL(solve_variant(h, o), dim3((unsigned)h->T), dim3(64), 0, h->stream, a);
@@ -409,8 +416,8 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
 
 int tsat_set_kernel_variant(tsat_handle* h, int32_t variant) {
   if (!h) return -1;
-  if (!((variant >= 0 && variant <= 2) || (variant >= 12 && variant <= 14)))
-    return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), or 12 / 13 / 14 (fp32 layouts for 2 / 3 / 4 waves per SIMD)");
+  if (!((variant >= 0 && variant <= 3) || (variant >= 12 && variant <= 14)))
+    return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), 3 (packed), or 12 / 13 / 14 (fp32 layouts for 2 / 3 / 4 waves per SIMD)");
   h->variant = variant;
   return 0;
 }

@@ -1,0 +1,32 @@
+// tsat_kernels_packed.hip — the "packed" build of the solve kernel for batches several times larger than the machine:
+// PK_G = 8 trajectories per wavefront share every forward sweep (tsat_packed.hpp), on the dense build's LDS / register budget
+// (two wavefronts per SIMD). Bit-identical results to the wide and dense builds. Separate translation unit because LDS size
+// and register budget are per-kernel compile-time facts.
+#define TSAT_DENSE 1
+#include <hip/hip_runtime.h>
+#include "tsat_packed.hpp"
+
+using namespace tsat;
+
+template <typename real, int INTEG, int DIAGJ, int ES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void tsat_solve_kernel_packed(KArgs<real> a) {
+  const int wave = blockIdx.x;
+  if (wave * PK_G >= a.T) return;
+  solve_group<real, INTEG, DIAGJ, ES>(a, wave);
+}
+
+// called by tsat_kernels.hip; same variant axes as the other builds: integrator x inertia class x error-state mode
+hipError_t tsat_launch_solve_packed(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream) {
+  using kern_t = void (*)(KArgs<double>);
+  static const kern_t variants[2][3][2] = {
+      {{tsat_solve_kernel_packed<double, 3, 0, 0>, tsat_solve_kernel_packed<double, 3, 0, 1>},
+       {tsat_solve_kernel_packed<double, 3, 1, 0>, tsat_solve_kernel_packed<double, 3, 1, 1>},
+       {tsat_solve_kernel_packed<double, 3, 2, 0>, tsat_solve_kernel_packed<double, 3, 2, 1>}},
+      {{tsat_solve_kernel_packed<double, 4, 0, 0>, tsat_solve_kernel_packed<double, 4, 0, 1>},
+       {tsat_solve_kernel_packed<double, 4, 1, 0>, tsat_solve_kernel_packed<double, 4, 1, 1>},
+       {tsat_solve_kernel_packed<double, 4, 2, 0>, tsat_solve_kernel_packed<double, 4, 2, 1>}}};
+  const unsigned waves = (unsigned)((a.T + PK_G - 1) / PK_G);
+  hipLaunchKernelGGL(variants[rk4 ? 1 : 0][inertia_class][error_state ? 1 : 0], dim3(waves), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+int tsat_packed_group(void) { return PK_G; }
