@@ -134,6 +134,18 @@ def emu_dense(pkg):
     return Emu(pkg._abi, "libtsat_emu_dense.so")
 
 
+@pytest.fixture(scope="session")
+def emu_packed(pkg):
+    """the packed build (PK_G trajectories per wavefront share the forward sweeps and the Riccati recursion), -DTSAT_PACKED"""
+    return Emu(pkg._abi, "libtsat_emu_packed.so")
+
+
+@pytest.fixture(scope="session")
+def emu_f32(pkg):
+    """the fp32 build of the solve kernel (options.precision = 32): float storage and arithmetic, double costs, -DTSAT_F32"""
+    return Emu(pkg._abi, "libtsat_emu_f32.so")
+
+
 def oracle_options(ol, **kw):
     o = ol.default_options()
     for k, v in kw.items():

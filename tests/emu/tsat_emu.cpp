@@ -67,6 +67,9 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
       LAM((size_t)T * lam_stride<R>(N), (R)0), CAND((size_t)T * max_ls * xu_stride<R>(N), (R)0);
   KArgs<R> a;
   a.T = (int)T; a.N = N; a.n_tab = n_tab; a.max_ls = max_ls; a.opt = *o;
+#ifdef TSAT_PACKED
+  a.max_ls = max_ls < PK_STORE ? max_ls : PK_STORE;      // as tsat_launch_solve_packed does
+#endif
   a.P = P.data(); a.BT = BT.data(); a.bidx = bidx.data(); a.nk = n_knots; a.U0 = U0r.data();
   a.XU = XU.data(); a.KD = KD.data(); a.LAM = LAM.data(); a.CAND = CAND.data();
   a.stats = stats; a.trace = trace; a.trace_rows = trace_rows;

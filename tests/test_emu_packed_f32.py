@@ -1,0 +1,87 @@
+"""CPU tier: the packed and fp32 builds of the solve kernel on the lane emulator (tests/emu, the very source hipcc compiles).
+
+packed (tsat_packed.hpp, -DTSAT_PACKED): PK_G trajectories per wavefront — bit-identical to the one-trajectory builds, whatever
+the group is made of (partial last group, ragged horizons, trajectories that finish early, fail or diverge next to healthy ones).
+fp32 (-DTSAT_F32, options.precision = 32): float storage / arithmetic with double costs — against the fp64 oracle at the bar of
+SURVEY.md §8(d) for fp32 (1e-3 + status agreement), on solves short enough that fp32 and fp64 follow the same iteration path.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_same_solution, oracle_options
+
+
+def _same_bits(a, b):
+    for k in ("X", "U", "K"):
+        assert np.array_equal(a[k], b[k]), k
+    for f in a["stats"].dtype.names:      # n_forward counts executed sweeps: a packed sweep carries PK_C candidates, not 64
+        if f != "n_forward":
+            assert np.array_equal(a["stats"][f], b["stats"][f]), f
+
+
+@pytest.mark.parametrize("T,N,es,integ", [(1, 30, 0, 3), (3, 41, 1, 3), (4, 26, 0, 4), (5, 37, 1, 3), (9, 23, 1, 4)])
+def test_packed_build_is_the_same_solve(pkg, ol, emu, emu_packed, T, N, es, integ):
+    """full and partial groups around the chunk boundaries: equal to the oracle, bit-identical to the wide build"""
+    b = pkg.slew_setup.workload_monte_carlo(T=T, N=N, seed=500 + 7 * T + N, random_orbit=(T == 5))
+    o = oracle_options(ol, max_outer=3, max_inner=5, dj_counter_limit=1, error_state=es, integrator=integ)
+    wide, packed = emu.solve(b, o), emu_packed.solve(b, o)
+    assert_same_solution(ol.solve_batch(b, o), packed)
+    _same_bits(wide, packed)
+
+
+@pytest.mark.parametrize("es", [0, 1])
+def test_packed_build_ragged_groups(pkg, ol, emu, emu_packed, es):
+    """every trajectory of a group has its own horizon (t_total[i] = 0:0.2:t_final[i], src/monte_carlo.jl:140-145)"""
+    ss = pkg.slew_setup
+    b = ss.workload_monte_carlo(T=6, N=47, seed=77)
+    b.n_knots = np.array([47, 2, 19, 33, 3, 46], dtype=np.int32)
+    o = oracle_options(ol, max_outer=2, max_inner=4, dj_counter_limit=1, error_state=es)
+    wide, packed = emu.solve(b, o), emu_packed.solve(b, o)
+    assert_same_solution(ol.solve_batch(b, o), packed)
+    _same_bits(wide, packed)
+    for t, n in enumerate(b.n_knots):
+        assert np.all(packed["X"][t, n:] == 0) and np.all(packed["U"][t, n - 1:] == 0)
+
+
+def test_packed_build_mixed_fates_in_one_group(pkg, ol, emu, emu_packed):
+    """a diverging rollout, a regularisation failure (with restarts on the way), a long line search and healthy neighbours
+    inside the same wavefront: nobody's arithmetic depends on the others"""
+    ss, abi = pkg.slew_setup, pkg._abi
+    b = ss.workload_monte_carlo(T=4, N=36, seed=9)
+    b.U0[1] = 1e12                   # DIVERGED
+    b.Rd[2] = -1e-4                  # Quu indefinite: restarts, then REG_FAIL (reg_max small)
+    o = oracle_options(ol, max_outer=3, max_inner=4, reg_max=1e-6)
+    wide, packed, ref = emu.solve(b, o), emu_packed.solve(b, o), ol.solve_batch(b, o)
+    assert ref["stats"]["status"][1] == abi.TSAT_DIVERGED and ref["stats"]["status"][2] == abi.TSAT_REG_FAIL
+    assert np.array_equal(ref["stats"]["status"], packed["stats"]["status"])
+    _same_bits(wide, packed)
+    for t in (0, 3):
+        assert np.max(np.abs(ref["X"][t] - packed["X"][t])) < 1e-9
+    # restarts that succeed: negative R, large reg_max
+    b2 = ss.workload_monte_carlo(T=3, N=36, seed=10)
+    b2.Rd[1] = -1e-4
+    o2 = oracle_options(ol, max_outer=2, max_inner=3)
+    w2, p2, r2 = emu.solve(b2, o2), emu_packed.solve(b2, o2), ol.solve_batch(b2, o2)
+    assert r2["stats"]["bp_restarts"][1] > 0
+    assert_same_solution(r2, p2)
+    _same_bits(w2, p2)
+    # deep line search (forced by a tiny acceptance window) and a failed one
+    o3 = oracle_options(ol, max_outer=2, max_inner=3, ls_lower=0.999999, ls_upper=1.000001, max_linesearch=20)
+    w3, p3 = emu.solve(b, o3), emu_packed.solve(b, o3)
+    _same_bits(w3, p3)
+
+
+def test_fp32_build_against_the_fp64_oracle(pkg, ol, emu_f32):
+    """precision = 32 on short solves: same statuses and iteration counts as the fp64 oracle, |dX| < 1e-3, |dU| < 1e-3 of
+    the control scale (fp32 bar 1e-3 + status agreement)"""
+    assert emu_f32.lib.emu_lds_bytes() <= 20480
+    for es in (0, 1):
+        b = pkg.slew_setup.workload_monte_carlo(T=3, N=60, seed=40 + es)
+        o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1, error_state=es)
+        ref, got = ol.solve_batch(b, o), emu_f32.solve(b, o)
+        assert np.array_equal(ref["stats"]["status"], got["stats"]["status"])
+        assert np.array_equal(ref["stats"]["inner_iters"], got["stats"]["inner_iters"])
+        assert np.max(np.abs(ref["X"] - got["X"])) < 1e-3
+        scale = np.maximum(1.0, np.max(np.abs(ref["U"]), axis=(1, 2)))
+        assert np.max(np.max(np.abs(ref["U"] - got["U"]), axis=(1, 2)) / scale) < 1e-3
+        np.testing.assert_allclose(got["stats"]["cost"], ref["stats"]["cost"], rtol=1e-4)

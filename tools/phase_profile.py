@@ -7,19 +7,33 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from tsat_loader import load_package
 pkg = load_package()
-pkg._abi.LIB_NAME = "libtortoise_hip_prof.so"
+pkg._abi.LIB_NAME = os.environ.get("TSAT_PROF_LIB", "libtortoise_hip_prof.so")
 from tortoisesat_jl_amd import trajopt as to, slew_setup as ss
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-b = ss.workload_monte_carlo(T=T, N=N)
+variant = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 0 auto, 1 wide, 2 dense, 3 packed (PK_G trajectories per wave)
+es = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+base = ss.workload_monte_carlo(T=min(T, 1024), N=N)
+if T > 1024:       # larger batches re-use the 1024 draws (tiling) so that host-side setup stays cheap
+    k = T // 1024
+    rep = lambda a: np.ascontiguousarray(np.concatenate([a] * k))
+    b = ss.SlewBatch(base.N, base.n_tab, rep(base.x0), rep(base.xf), base.Btab, rep(base.btab_idx), rep(base.tau0), rep(base.dtau),
+                     rep(base.dt), rep(base.Jmat), rep(base.Qd), rep(base.Qfd), rep(base.Rd), rep(base.ulo), rep(base.uhi), rep(base.U0))
+    T = b.T
+else:
+    b = base
 opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = 5
 opts.opts_uncon.iterations = 10; opts.opts_uncon.dJ_counter_limit = 1
 solver = to.AugmentedLagrangianSolver(None, opts)
-o = opts.to_abi(b.N, b.n_tab, 3)
+o = opts.to_abi(b.N, b.n_tab, 3, error_state=es)
+solver.set_kernel_variant(variant)
 solver.upload(b, o.max_linesearch); solver.trace(1)
 ms = solver.run(o); ms = solver.run(o)
 tr = solver.trace_download()[:, 0, :]
+if variant == 3 or (variant == 0 and T >= 8192):   # the packed build stamps one row per wavefront (its first trajectory): sums over
+    tr = tr[::int(os.environ.get("TSAT_PK_G", "4"))]   # its PK_G trajectories
+print(f"T = {T}, variant {variant}, error_state {es}: {len(tr)} stamped wavefronts")
 it = tr[:, 4]; nb = tr[:, 5]
 tot = tr[:, :4].sum(1)
 print(f"kernel {ms:.2f} ms (stamped build); mean inner its {it.mean():.1f}")

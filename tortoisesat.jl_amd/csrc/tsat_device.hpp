@@ -199,7 +199,12 @@ constexpr int L_FWD = L_UNION;
 constexpr int L_FWD_END = L_FWD + FWD_NBUF * FB_SIZE;
 constexpr int L_BWD_END = L_REC + (BwdCfg<0>::CHB * BwdCfg<0>::RECS > BwdCfg<1>::CHB * BwdCfg<1>::RECS
                                     ? BwdCfg<0>::CHB * BwdCfg<0>::RECS : BwdCfg<1>::CHB * BwdCfg<1>::RECS);
+#if defined(TSAT_PACKED)
+// packed build (tsat_packed.hpp): its own carve-up behind L_UNION, sized to the 20 480 B of two wavefronts per SIMD
+constexpr int LDS_REALS = 20480 / (int)sizeof(cfg_real);
+#else
 constexpr int LDS_REALS = (L_FWD_END > L_BWD_END ? L_FWD_END : L_BWD_END);
+#endif
 
 // The wavefront's LDS block: a STATIC module-level __shared__ array. Declared at namespace scope so that every phase
 // function addresses it as LDS (address space 3) at a link-time constant address — a generic pointer argument would
@@ -255,6 +260,7 @@ TSAT_DEV float fabs_(float a) { return std::fabs(a); }
 TSAT_DEV float fmax_(float a, float b) { return a > b ? a : b; }
 TSAT_DEV float fmaxabs_(float a, float b) { const float c = std::fabs(b); return a > c ? a : c; }
 TSAT_DEV float rcp_(float a) { return 1.0f / a; }
+TSAT_DEV float fma_(float a, float b, float c) { return std::fma(a, b, c); }
 #else
 // v_rsq_f64 seed (rel. error <= 5.3e-8, profiles/r01/rsq_rcp_accuracy.txt) + ONE third-order step:
 // y (1 + e/2 + 3e^2/8), e = 1 - s y^2  ->  error O(e^3) ~ 1e-22, i.e. rounding only; 5 instructions instead of the 8
@@ -292,7 +298,13 @@ TSAT_DEV float fabs_(float a) { return __builtin_fabsf(a); }
 TSAT_DEV float fmax_(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 TSAT_DEV float fmaxabs_(float a, float b) { float r; asm("v_max_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
 TSAT_DEV float rcp_(float a) { return __builtin_amdgcn_rcpf(a); }   // 1 ulp
+TSAT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 #endif
+// a b - c d with the rounding spelled out (one product rounded, then fused): a compiler is free to contract either product of
+// the plain expression, and the builds of the solve kernel must agree to the last bit
+template <typename real> TSAT_DEV real dmm_(real a, real b, real c, real d) { return fma_(a, b, -(c * d)); }
+// a0 b0 + a1 b1 + a2 b2, left to right, likewise
+template <typename real> TSAT_DEV real dot3_(real a0, real b0, real a1, real b1, real a2, real b2) { return fma_(a2, b2, fma_(a1, b1, a0 * b0)); }
 
 // phase timing for the diagnostic build (-DTSAT_PROFILE): shader-clock stamps accumulated per phase and written to
 // the trace buffer's row 0 of each trajectory; the production build compiles all of it away.
@@ -390,8 +402,7 @@ struct Traj {
 // The constants live in the wave's LDS block (written once by stage_traj); every phase function re-reads the
 // ones it uses, so they sit in VGPRs local to that phase instead of in SGPRs spilled across the whole kernel.
 template <typename real>
-TSAT_DEV Traj<real> load_traj(int N, int n_tab, const TSAT_GLOBAL real* bt) {
-  const real* t = lds_base<real>() + L_TR;
+TSAT_DEV Traj<real> load_traj_at(const real* t, int N, int n_tab, const TSAT_GLOBAL real* bt) {
   Traj<real> tr;
   for (int i = 0; i < 7; ++i) { tr.xf[i] = t[P_XF + i]; tr.Qd[i] = t[P_QD + i]; tr.Qfd[i] = t[P_QFD + i]; }
   for (int i = 0; i < 3; ++i) { tr.Rd[i] = t[P_RD + i]; tr.ulo[i] = t[P_ULO + i]; tr.uhi[i] = t[P_UHI + i]; }
@@ -400,6 +411,10 @@ TSAT_DEV Traj<real> load_traj(int N, int n_tab, const TSAT_GLOBAL real* bt) {
   tr.tau0 = (double)t[P_TAU0] + (double)t[P_TAU0L]; tr.dtau = (double)t[P_DTAU] + (double)t[P_DTAUL];
   tr.N = N; tr.n_tab = n_tab; tr.bt = bt;
   return tr;
+}
+template <typename real>
+TSAT_DEV Traj<real> load_traj(int N, int n_tab, const TSAT_GLOBAL real* bt) {
+  return load_traj_at<real>(lds_base<real>() + L_TR, N, n_tab, bt);
 }
 // copy the parameter record into LDS and append the derived constants (all lanes; wave-uniform values)
 template <typename real>
@@ -540,9 +555,11 @@ TSAT_DEV void rk_step(const Traj<real>& tr, const real x[7], const real u[3], co
 
 // discrete Jacobians of one RK step, column by column, written to LDS record `F` (column stride 8).
 // Equivalent of ForwardDiff.jacobian! over the discretised dynamics (src/attitude_controller.jl:95-119).
+// Columns c_lo .. c_hi - 1 only (each column is its own tangent pass, so splitting the columns over lanes — the packed
+// build's Jacobian lanes, tsat_packed.hpp — leaves every column's arithmetic untouched).
 template <typename real, int INTEG, int DIAGJ, int ES>
-TSAT_DEV void rk_jacobian(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3],
-                          const real b1[3], const real b2[3], real* F) {
+TSAT_DEV void rk_jacobian_cols(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3],
+                               const real b1[3], const real b2[3], real* F, int c_lo, int c_hi) {
   const real us[3] = {u[0] * tr.us, u[1] * tr.us, u[2] * tr.us};
   real k1[7], k2[7], k3[7], t[7];
   StageBase<real> s1, s2, s3, s4;
@@ -562,7 +579,7 @@ TSAT_DEV void rk_jacobian(const Traj<real>& tr, const real x[7], const real u[3]
 #ifndef TSAT_EMU
 #pragma unroll 1
 #endif
-  for (int c = 0; c < 10; ++c) {
+  for (int c = c_lo; c < c_hi; ++c) {
     real ex[7], du[3];
     for (int i = 0; i < 7; ++i) ex[i] = (i == c) ? (real)1 : (real)0;
     for (int a = 0; a < 3; ++a) du[a] = (c == 7 + a) ? tr.us : (real)0;
@@ -583,6 +600,11 @@ TSAT_DEV void rk_jacobian(const Traj<real>& tr, const real x[7], const real u[3]
       for (int i = 0; i < 7; ++i) F[c * FS + i] = ex[i] + (v1[i] + 2 * v2[i] + 2 * v3[i] + v4[i]) * (real)(1.0 / 6.0);
     }
   }
+}
+template <typename real, int INTEG, int DIAGJ, int ES>
+TSAT_DEV void rk_jacobian(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3],
+                          const real b1[3], const real b2[3], real* F) {
+  rk_jacobian_cols<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, F, 0, 10);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -659,6 +681,45 @@ TSAT_DEV void glds_put(real* dst, const TSAT_GLOBAL real* src) {
   typedef __attribute__((address_space(1))) const void* gp_t;
   typedef __attribute__((address_space(3))) void* lp_t;
   __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)(dst - RPU * TSAT_LANE()), 16, 0, 0);
+#endif
+}
+// One (x,u) knot record to HBM as exactly FIVE store instructions (16-byte pieces of the 80-byte double record, 8-byte
+// pieces of the 40-byte float record; both are aligned that way by construction). The packed forward sweep counts on the
+// number: it waits for its LDS copies with s_waitcnt vmcnt(5 x knots) so that these stores stay in flight (tsat_packed.hpp).
+constexpr int REC_STORES = 5;
+template <typename real>
+TSAT_DEV void store_record5(TSAT_GLOBAL real* cr, const real x[7], const real u[3]) {
+#ifdef TSAT_EMU
+  for (int i = 0; i < 7; ++i) cr[i] = x[i];
+  for (int c = 0; c < 3; ++c) cr[7 + c] = u[c];
+#else
+  typedef real v2 __attribute__((ext_vector_type(2)));
+  typedef TSAT_GLOBAL v2* gv2;
+  v2 a = {x[0], x[1]}, b = {x[2], x[3]}, c = {x[4], x[5]}, d = {x[6], u[0]}, e = {u[1], u[2]};
+  ((gv2)cr)[0] = a; ((gv2)cr)[1] = b; ((gv2)cr)[2] = c; ((gv2)cr)[3] = d; ((gv2)cr)[4] = e;
+#endif
+}
+// wait until all but the `n` youngest vector-memory operations of the wave have completed (loads, stores and LDS copies count
+// together, in issue order), then order LDS traffic between the lanes; the emulator synchronises fully
+#ifdef TSAT_EMU
+#define TSAT_SYNC_OLDER_THAN(n) (tsat_emu::sync())
+#else
+#define TSAT_SYNC_OLDER_THAN(n)                               \
+  do {                                                        \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory"); \
+    TSAT_SYNC_LDS();                                          \
+  } while (0)
+#endif
+// the same with the instruction's wave-uniform LDS base given directly: this lane's unit lands at base + RPU * lane
+template <typename real>
+TSAT_DEV void glds_put_at(real* base, const TSAT_GLOBAL real* src) {
+  static_assert(sizeof(real) == sizeof(cfg_real), "16-byte copy units are RPU reals");
+#ifdef TSAT_EMU
+  for (int i = 0; i < RPU; ++i) base[RPU * TSAT_LANE() + i] = src[i];
+#else
+  typedef __attribute__((address_space(1))) const void* gp_t;
+  typedef __attribute__((address_space(3))) void* lp_t;
+  __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)base, 16, 0, 0);
 #endif
 }
 // the three field rows of step kk of a staged chunk (rows at tau, tau + dtau/2, tau + dtau)
@@ -835,9 +896,26 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
 template <typename real>
 TSAT_DEV void gt_apply(const real q[4], real r0, real r1, real r2, real r3, real o[3]) {
   const real s = q[0], v0 = q[1], v1 = q[2], v2 = q[3];
-  o[0] = (-v0 * r0 + s * r1) + (v2 * r2 - v1 * r3);
-  o[1] = (-v1 * r0 - v2 * r1) + (s * r2 + v0 * r3);
-  o[2] = (-v2 * r0 + v1 * r1) + (-v0 * r2 + s * r3);
+  // (two-product terms with the rounding spelled out, see dmm_: every build of the kernel rounds them the same way)
+  o[0] = dmm_(s, r1, v0, r0) + dmm_(v2, r2, v1, r3);
+  o[1] = fma_(s, r2, v0 * r3) - fma_(v2, r1, v1 * r0);
+  o[2] = dmm_(v1, r1, v2, r0) + dmm_(s, r3, v0, r2);
+}
+
+// control gradient and Hessian diagonal of one knot with the AL terms of the control box: lu = R u + (lambda+ + I mu c+) -
+// (lambda- + I mu c-), luu = R + I+ mu + I- mu, row active iff c > 0 or lambda > 0. The fused operations are spelled out
+// (see dmm_): the Jacobian lanes of every build round them the same way.
+template <typename real>
+TSAT_DEV void al_control_terms(const Traj<real>& tr, const real u[3], const real lam[6], real mu, real* lu_out, real* luu_out) {
+  for (int c = 0; c < 3; ++c) {
+    const real chi = u[c] - tr.uhi[c], clo = tr.ulo[c] - u[c];
+    const real mhi = (chi > 0 || lam[c] > 0) ? mu : (real)0;
+    const real mlo = (clo > 0 || lam[3 + c] > 0) ? mu : (real)0;
+    real lu = fma_(tr.Rd[c], u[c], fma_(mhi, chi, lam[c]));
+    lu = lu - fma_(mlo, clo, lam[3 + c]);
+    lu_out[c] = lu;
+    luu_out[c] = (tr.Rd[c] + mhi) + mlo;
+  }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -897,19 +975,7 @@ TSAT_PHASE void jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, 
           }
       }
     }
-    for (int c = 0; c < 3; ++c) {
-      real lu = tr.Rd[c] * u[c], luu = tr.Rd[c];
-      real cc = u[c] - tr.uhi[c], lm = lam[c];
-      bool act = (cc > 0 || lm > 0);
-      lu += lm + (act ? mu * cc : (real)0);
-      luu += act ? mu : (real)0;
-      cc = tr.ulo[c] - u[c]; lm = lam[3 + c];
-      act = (cc > 0 || lm > 0);
-      lu -= lm + (act ? mu * cc : (real)0);
-      luu += act ? mu : (real)0;
-      rc[R_LU + c] = lu;
-      rc[R_LUU + c] = luu;
-    }
+    al_control_terms(tr, u, lam, mu, rc + R_LU, rc + R_LUU);
   }
 }
 
@@ -1004,7 +1070,7 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
       for (int m = 0; m < NH; ++m) sv[m] = lds[s1_st + m];
       TSAT_SCHED_FENCE();
       real acc = 0, acc2 = 0;
-      for (int m = 0; m < NH; ++m) { acc += sv[m] * fa1[m]; acc2 += sv[m] * fb1[m]; }
+      for (int m = 0; m < NH; ++m) { acc = fma_(sv[m], fa1[m], acc); acc2 = fma_(sv[m], fb1[m], acc2); }
       role_store(lds, s1_oa, L_SINK, acc);
       role_store(lds, s1_ob, L_SINK, acc2);
     }
@@ -1015,7 +1081,7 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
       for (int m = 0; m < NH; ++m) wb[m] = lds[s2_b + m];
       TSAT_SCHED_FENCE();
       real acc = s2_diag + ini2;
-      for (int m = 0; m < NH; ++m) acc += fa2[m] * wb[m];
+      for (int m = 0; m < NH; ++m) acc = fma_(fa2[m], wb[m], acc);
       role_store(lds, s2_o1, L_SINK, acc);
       role_store(lds, s2_o2, L_SINK, acc);
     }
@@ -1036,20 +1102,20 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
       TSAT_SCHED_FENCE();
       const real q00 = hu[0] + rho, q11 = hu[4] + rho, q22 = hu[8] + rho;
       const real q10 = hu[1], q20 = hu[2], q21 = hu[5];
-      const real c00 = q11 * q22 - q21 * q21;
-      const real c01 = q20 * q21 - q10 * q22;
-      const real c02 = q10 * q21 - q20 * q11;
-      const real c11 = q00 * q22 - q20 * q20;
-      const real c12 = q10 * q20 - q00 * q21;
-      const real c22 = q00 * q11 - q10 * q10;
-      const real det = q00 * c00 + q10 * c01 + q20 * c02;
+      const real c00 = dmm_(q11, q22, q21, q21);
+      const real c01 = dmm_(q20, q21, q10, q22);
+      const real c02 = dmm_(q10, q21, q20, q11);
+      const real c11 = dmm_(q00, q22, q20, q20);
+      const real c12 = dmm_(q10, q20, q00, q21);
+      const real c22 = dmm_(q00, q11, q10, q10);
+      const real det = dot3_(q00, c00, q10, c01, q20, c02);
       if (!(q00 > 0 && c22 > 0 && det > 0)) pd_ok = false;
       const real nid = -rcp_(det);
       // row a3 of the inverse (negated)
       const real Qi0 = ((a3c == 0) ? c00 : (a3c == 1 ? c01 : c02)) * nid;
       const real Qi1 = ((a3c == 0) ? c01 : (a3c == 1 ? c11 : c12)) * nid;
       const real Qi2 = ((a3c == 0) ? c02 : (a3c == 1 ? c12 : c22)) * nid;
-      const real vv = Qi0 * h0 + Qi1 * h1 + Qi2 * h2;
+      const real vv = dot3_(Qi0, h0, Qi1, h1, Qi2, h2);
       const real v = s3_live ? vv : (real)0;
       role_store(lds, s3_o, L_SINK, v);
       if (s3_slot >= 0) KDg[(size_t)(k0 + l) * KDW + s3_slot] = v;   // stays in flight: no vmcnt wait in this loop
@@ -1070,16 +1136,16 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
       }
       TSAT_SCHED_FENCE();
       // dV1 += d'Qu ; dV2 += 0.5 d'Quu d. With d = -Quu_reg^-1 Qu: Quu d = -Qu - rho d, so d'Quu d = -(d'Qu + rho d'd)
-      const real dqu = d0 * qu0 + d1 * qu1 + d2 * qu2;
+      const real dqu = dot3_(d0, qu0, d1, qu1, d2, qu2);
       dV1 += (acc_t)dqu;
-      dV2 -= (acc_t)((real)0.5 * (dqu + rho * (d0 * d0 + d1 * d1 + d2 * d2)));
+      dV2 -= (acc_t)((real)0.5 * fma_(rho, dot3_(d0, d0, d1, d1, d2, d2), dqu));
       real acc = b1 + b2;
       real sy = 0, kk = 0;
       for (int c = 0; c < 3; ++c) {
-        sy += hi[c] * kj[c] + hj[c] * ki[c];
-        kk += ki[c] * kj[c];
+        sy += fma_(hi[c], kj[c], hj[c] * ki[c]);
+        kk = fma_(ki[c], kj[c], kk);
       }
-      acc += (real)0.5 * sy - rho * kk;
+      acc += dmm_((real)0.5, sy, rho, kk);
       role_store(lds, s4_o1, L_SINK, acc);
       role_store(lds, s4_o2, L_SINK, acc);
     }
@@ -1092,10 +1158,13 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
   return out;
 }
 
-template <typename real, int INTEG, int DIAGJ, int ES>
-TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu, real rho, int term_mask) {
+// terminal cost-to-go into the Riccati scratch S~ (L_ST, row stride 9; row NH = s'): reads the staged trajectory constants
+// (L_TR) and terminal multipliers (L_NU)
+template <typename real, int ES>
+TSAT_DEV void terminal_cost_to_go(const TSAT_GLOBAL real* XUg, int N, real mu, int term_mask) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
+  struct { const TSAT_GLOBAL real* XU; } p = {XUg};
   // terminal cost-to-go: Sxx = Qf + mu*mask, Sx = Qf e + mask (nu + mu e)   (Appendix A backward); in error
   // coordinates both are projected through E(q_N): E'SxxE, E'Sx (src/quaternion_toolbox.jl:38-50)
   {
@@ -1111,7 +1180,7 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
         if (r1 < 7) {
           if (r1 == c1) v = qf + (m ? mu : (real)0);
         } else {
-          v = qf * e + (m ? (lds[L_NU + c1] + mu * e) : (real)0);
+          v = fma_(qf, e, m ? fma_(mu, e, lds[L_NU + c1]) : (real)0);   // fused operations spelled out, see dmm_
         }
         lds[L_ST + r1 * 9 + c1] = v;
       }
@@ -1125,22 +1194,32 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
         const real e = xN[m] - lds[L_TR + P_XF + m];
         const bool msk = (term_mask >> m) & 1;
         const real sd = qf + (msk ? mu : (real)0);
-        const real sf = qf * e + (msk ? (lds[L_NU + m] + mu * e) : (real)0);
-        real ec = 0, er = 0;   // E[m][c1], E[m][r1]
+        const real sf = fma_(qf, e, msk ? fma_(mu, e, lds[L_NU + m]) : (real)0);
+        // (r, c) taken in the order (min, max) on the matrix rows: the projected S is symmetric to the last bit, whichever
+        // triangle a reader takes (the packed build keeps only the upper one)
+        const int ra = (r1 < NH && r1 > c1) ? c1 : r1, ca = (r1 < NH && r1 > c1) ? r1 : c1;
+        real ec = 0, er = 0;   // E[m][ca], E[m][ra]
         for (int t = 0; t < 3; ++t) {
           const real em = (m < 3) ? ((m == t) ? (real)1 : (real)0) : (real)0;
           const real gm = (m >= 3) ? G[m >= 3 ? m - 3 : 0][t] : (real)0;
-          if (c1 == t) ec = em;
-          if (c1 == 3 + t) ec = gm;
-          if (r1 == t) er = em;
-          if (r1 == 3 + t) er = gm;
+          if (ca == t) ec = em;
+          if (ca == 3 + t) ec = gm;
+          if (ra == t) er = em;
+          if (ra == 3 + t) er = gm;
         }
-        acc += (r1 < NH) ? (er * sd * ec) : (sf * ec);
+        acc = fma_((r1 < NH) ? er * sd : sf, ec, acc);
       }
       lds[L_ST + r1 * 9 + c1] = acc;
     }
     if (lane == 0) { lds[L_ZERO] = 0; lds[L_SINK] = 0; }
   }
+}
+
+template <typename real, int INTEG, int DIAGJ, int ES>
+TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu, real rho, int term_mask) {
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE();
+  terminal_cost_to_go<real, ES>(p.XU, N, mu, term_mask);
   BwdOut<real> acc;
   acc.dV1 = 0; acc.dV2 = 0; acc.pd_ok = 1;
   TSAT_SYNC();

@@ -3,6 +3,7 @@
 // (two wavefronts per SIMD). Bit-identical results to the wide and dense builds. Separate translation unit because LDS size
 // and register budget are per-kernel compile-time facts.
 #define TSAT_DENSE 1
+#define TSAT_PACKED 1
 #include <hip/hip_runtime.h>
 #include "tsat_packed.hpp"
 
@@ -26,7 +27,12 @@ hipError_t tsat_launch_solve_packed(const KArgs<double>& a, int rk4, int inertia
        {tsat_solve_kernel_packed<double, 4, 1, 0>, tsat_solve_kernel_packed<double, 4, 1, 1>},
        {tsat_solve_kernel_packed<double, 4, 2, 0>, tsat_solve_kernel_packed<double, 4, 2, 1>}}};
   const unsigned waves = (unsigned)((a.T + PK_G - 1) / PK_G);
-  hipLaunchKernelGGL(variants[rk4 ? 1 : 0][inertia_class][error_state ? 1 : 0], dim3(waves), dim3(64), 0, stream, a);
+  // Stored line-search candidates per sweep: PK_STORE instead of NSTORE = 12. On the Monte-Carlo workloads the accepted step is
+  // alpha = 2^-j with j <= 5 in 99.8 % of the iterations; a deeper winner costs the wave one more sweep (shift += n_store),
+  // while every stored candidate costs 80 B per knot and sweep of HBM writes whether it wins or not.
+  KArgs<double> b = a;
+  b.max_ls = a.max_ls < PK_STORE ? a.max_ls : PK_STORE;
+  hipLaunchKernelGGL(variants[rk4 ? 1 : 0][inertia_class][error_state ? 1 : 0], dim3(waves), dim3(64), 0, stream, b);
   return hipGetLastError();
 }
 int tsat_packed_group(void) { return PK_G; }

@@ -20,29 +20,73 @@
 namespace tsat {
 
 #ifndef TSAT_PK_G
-#define TSAT_PK_G 8
+#define TSAT_PK_G 4
 #endif
 #ifndef TSAT_PK_CK
 #define TSAT_PK_CK 4
 #endif
 #ifndef TSAT_PK_NBUF
-#define TSAT_PK_NBUF 1
+#define TSAT_PK_NBUF 2
 #endif
+#ifndef TSAT_PK_STORE
+#define TSAT_PK_STORE 6
+#endif
+constexpr int PK_STORE = TSAT_PK_STORE;     // line-search candidates per trajectory whose rollouts a sweep keeps in HBM
 constexpr int PK_G = TSAT_PK_G;             // trajectories per wavefront
-constexpr int PK_C = WAVE / PK_G;           // line-search candidates per trajectory and sweep
+constexpr int PK_C = WAVE / PK_G;           // lanes (line-search candidates) per trajectory
 constexpr int PK_CK = TSAT_PK_CK;           // knots per forward chunk and trajectory
-constexpr int PK_NBUF = TSAT_PK_NBUF;
+constexpr int PK_NBUF = TSAT_PK_NBUF;       // 2: the next chunk is copied while this one is rolled out
 static_assert(PK_G * PK_C == WAVE && (PK_C & (PK_C - 1)) == 0, "PK_G must be a power of two");
-// chunk record of one trajectory (reals): gains, multipliers, (x,u) records, 3 field rows per knot (4 reals each), gates
-constexpr int PK_KD = 0, PK_LM = PK_KD + PK_CK * KDW, PK_XU = PK_LM + PK_CK * LMW, PK_B = PK_XU + PK_CK * XUW,
-              PK_GT = PK_B + PK_CK * 12, PK_END = PK_GT + PK_CK * LMW;
-static_assert(PK_LM % RPU == 0 && PK_XU % RPU == 0 && PK_B % RPU == 0 && PK_GT % RPU == 0, "segments start on 16-byte units");
-// stride between the trajectories' records: 16 bytes past a multiple of 256 bytes, so that the PK_G addresses of one broadcast
-// read (same offset, different trajectory) fall into different LDS banks
-constexpr int PK_STRIDE = ((PK_END - RPU + 16 * RPU - 1) / (16 * RPU)) * (16 * RPU) + RPU;
-constexpr int PK_U_KD = PK_LM / RPU, PK_U_LM = PK_XU / RPU, PK_U_XU = PK_B / RPU;   // cumulative unit boundaries
-constexpr int PK_UNITS = PK_U_XU + PK_CK * 3 * BROW_UNITS;                          // 16-byte units copied per trajectory and chunk
-static_assert(L_FWD + PK_NBUF * PK_G * PK_STRIDE <= LDS_REALS, "packed forward buffers fit the wave's LDS block");
+// Forward chunk buffer (reals): one region per array, each [trajectory][units of the chunk + ONE 16-byte pad unit] (field rows:
+// + one pad row). global_load_lds fills LDS lane-linearly, so a region is linear in (trajectory, unit) and a copy
+// instruction simply covers 64 consecutive units of it; the pad makes the trajectories' sub-blocks start 16 bytes (field rows:
+// 160 bytes) past a multiple of 256 bytes... in effect at different LDS banks, so that the PK_G-address broadcast reads of
+// the roll-out (same offset, different trajectory) do not conflict.
+constexpr int PK_UKD = PK_CK * KDW / RPU, PK_ULM = PK_CK * LMW / RPU, PK_UXU = PK_CK * XUW / RPU;   // units per trajectory
+static_assert((PK_CK * KDW) % RPU == 0 && (PK_CK * LMW) % RPU == 0 && (PK_CK * XUW) % RPU == 0, "chunks are whole 16-byte units");
+constexpr int PK_SKD = (PK_UKD + 1) * RPU, PK_SLM = (PK_ULM + 1) * RPU, PK_SXU = (PK_UXU + 1) * RPU;   // strides in reals
+constexpr int PK_BROWS = PK_CK * 3 + 1;                          // field rows per trajectory incl. the pad row
+constexpr int PK_SB = PK_BROWS * 4, PK_SGT = PK_SLM;
+constexpr int PK_R_KD = 0, PK_R_LM = PK_R_KD + PK_G * PK_SKD, PK_R_XU = PK_R_LM + PK_G * PK_SLM, PK_R_B = PK_R_XU + PK_G * PK_SXU,
+              PK_R_GT = PK_R_B + PK_G * PK_SB, PK_FB = PK_R_GT + PK_G * PK_SGT;
+// copy instructions per region (64 units each)
+constexpr int PK_NI_KD = (PK_G * (PK_UKD + 1) + WAVE - 1) / WAVE, PK_NI_LM = (PK_G * (PK_ULM + 1) + WAVE - 1) / WAVE,
+              PK_NI_XU = (PK_G * (PK_UXU + 1) + WAVE - 1) / WAVE, PK_NI_B = (PK_G * PK_BROWS * BROW_UNITS + WAVE - 1) / WAVE;
+// a region's last instruction may run past the region: the buffer keeps one instruction's worth of slack at its end
+static_assert(L_FWD + PK_NBUF * PK_FB + GLDS <= LDS_REALS, "packed forward buffers fit the wave's LDS block");
+
+// ---- joint backward sweep: carve-up behind L_UNION (the forward chunk buffers overlay all of it between backward sweeps) -----
+// The PK_G trajectories of the wave run their backward sweeps TOGETHER, PK_CHG knots of each per chunk:
+//   Jacobian lanes   lane = (trajectory, knot of the chunk, quarter): the quarter owns tangent columns {0-2 | 3-5 | 6,7 | 8,9}
+//                    of [A|B] (each column is its own pass through the RK stages), so all 64 lanes linearise although a
+//                    trajectory has only PK_CHG knots in LDS;
+//   Riccati lanes    PK_C = 16 lanes per trajectory, lane j < NH + 3 owns COLUMN j of [A|B]: it keeps S~ in registers, forms
+//                    column j of W~ = S~ F and of F'W~ (the rows the recursion needs), its gain column and column j of the new
+//                    cost-to-go; three small exchanges per knot go through the trajectory's block in LDS (Quu / Qu, the
+//                    gain columns, the new S~). Element by element the operations — and their order — are those of
+//                    riccati_chunk (tsat_device.hpp): the results are bit-identical to the one-trajectory builds.
+#ifndef TSAT_PK_CHG
+#define TSAT_PK_CHG 4
+#endif
+constexpr int PK_CHG = TSAT_PK_CHG;               // knots per trajectory and backward chunk
+static_assert(PK_C == 16 && PK_CHG * 4 == PK_C, "Jacobian lanes: 16 lanes of a trajectory = PK_CHG knots x 4 column quarters");
+constexpr int PK_RECS = 83;                       // knot record: F = [A|B] column-major (70), lx (7), lu (3), luu (3); error-state
+constexpr int PK_R_QQ = 9 * FS;                   //   mode keeps G'QG (6) in F's column 9, which the reduction has vacated
+constexpr int PK_GTRW = 88;                       // per-trajectory constants: staged parameter record (76), nu (8), pad
+constexpr int PK_GT_NU = 76;
+constexpr int PK_GXW = 88;                        // per-trajectory exchange block of the Riccati lanes:
+constexpr int GX_S = 0;                           //   S~ as packed upper triangle (<= 28) + s (<= 7)
+constexpr int GX_QU = 36;                         //   Quu (0,0)(0,1)(0,2)(1,1)(1,2)(2,2), Qu (3)
+constexpr int GX_XK = 46;                         //   per state column i: Qux(:,i) (3), K(:,i) (3)
+static_assert(GX_XK + 7 * 6 <= PK_GXW && PK_GXW % 2 == 0 && GX_XK % 2 == 0, "exchange block layout");
+constexpr int L_GTR = L_UNION;
+constexpr int L_GX = L_GTR + PK_G * PK_GTRW;
+constexpr int L_GREC = L_GX + PK_G * PK_GXW;
+constexpr int PK_GRS = PK_CHG * PK_RECS;          // stride between the trajectories' record blocks (2656 B: 96 B past a multiple of
+                                                  // 256 B, so the four trajectories' broadcast reads fall into different banks)
+static_assert(L_GREC + PK_G * PK_GRS <= LDS_REALS, "joint backward sweep fits the wave's LDS block");
+// packed index of (i <= j) in an n x n upper triangle, row by row
+constexpr int sym_ut(int i, int j, int n) { return i * n - (i * (i - 1)) / 2 + (j - i); }
 
 // per-trajectory position in the AL-iLQR iteration; lives in the registers of the trajectory's PK_C lanes and is made
 // wave-uniform (through LDS) for the phases that work on one trajectory at a time
@@ -51,7 +95,7 @@ struct GState {
   acc_t Jprev, dV1, dV2, Jw;
   real mu, rho, drho, grad, rho_used, nu[7];
   int N, active, status, outer, it, inner_iters, ls_trials, n_backward, n_forward, bp_restarts, fp_fails, djz, trow, regfail,
-      found, jw, slot;
+      found, jw, slot, need_bwd;
 };
 
 template <typename real>
@@ -81,10 +125,12 @@ TSAT_DEV TPtrs<real> group_ptrs(const KArgs<real>& a, int traj) {
 // `live`: this lane's trajectory takes part; N, mu, nu: its horizon, penalty and terminal multipliers. Same per-knot
 // arithmetic as forward_sweep (tsat_device.hpp); the knot records of all PK_G trajectories are staged through LDS in
 // PK_CK-knot chunks (global_load_lds, lane = 16-byte unit) and read back as PK_G-address broadcasts.
-#ifdef TSAT_PK_FWD_NOINLINE
-#define TSAT_PK_FWD TSAT_PHASE
-#else
+// its own (non-inlined) function: the sweep gets a register allocation of its own — no scratch traffic in its loop — instead of
+// sharing one with the driver's per-trajectory state (-DTSAT_PK_FWD_INLINE: measured 4 % slower)
+#ifdef TSAT_PK_FWD_INLINE
 #define TSAT_PK_FWD TSAT_FWD
+#else
+#define TSAT_PK_FWD TSAT_PHASE
 #endif
 template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, int closed, int shift, int n_store, bool live, int N,
@@ -129,44 +175,82 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
   acc_t J = 0;
   real amax = 0;
 
-  // copy of chunk k0 into buffer `fb`: per trajectory, lane = 16-byte unit of its [gains | multipliers | records | field rows]
+  // ---- static roles of this lane in the copy instructions (fixed for the whole sweep): source pointer of chunk 0 and the
+  // last chunk start for which the lane has something to copy (k0 < lim); a lane of a pad unit, of a trajectory that does not
+  // take part, or past the region's end never copies
+  constexpr int NEVER = -0x40000000;
+  const TSAT_GLOBAL real* kd_src[PK_NI_KD]; int kd_lim[PK_NI_KD];
+  const TSAT_GLOBAL real* lm_src[PK_NI_LM]; int lm_lim[PK_NI_LM];
+  const TSAT_GLOBAL real* xu_src[PK_NI_XU]; int xu_lim[PK_NI_XU];
+  const TSAT_GLOBAL real* b_src[PK_NI_B]; int b_lim[PK_NI_B]; int b_kk[PK_NI_B]; double b_t0[PK_NI_B], b_dt[PK_NI_B], b_st[PK_NI_B];
+  auto role = [&](int i, int units, int W, const real* base, size_t stride, const TSAT_GLOBAL real*& src, int& lim) {
+    const int g = i / (units + 1), e = i - g * (units + 1);
+    const int tg = (traj0 + g <= tmax) ? traj0 + g : tmax;
+    const int Ng = (g < PK_G) ? pk_n[g] : 0;
+    src = (const TSAT_GLOBAL real*)(base + (size_t)tg * stride + (size_t)e * RPU);
+    lim = (g < PK_G && e < units && Ng > 0) ? Ng - 1 - (e * RPU) / W : NEVER;
+  };
+#ifndef TSAT_EMU
+#pragma unroll
+#endif
+  for (int j = 0; j < PK_NI_KD; ++j) {
+    role(lane + WAVE * j, PK_UKD, KDW, a.KD, kd_stride<real>(a.N), kd_src[j], kd_lim[j]);
+    if (!closed) kd_lim[j] = NEVER;
+  }
+#ifndef TSAT_EMU
+#pragma unroll
+#endif
+  for (int j = 0; j < PK_NI_LM; ++j) role(lane + WAVE * j, PK_ULM, LMW, a.LAM, lam_stride<real>(a.N), lm_src[j], lm_lim[j]);
+#ifndef TSAT_EMU
+#pragma unroll
+#endif
+  for (int j = 0; j < PK_NI_XU; ++j) role(lane + WAVE * j, PK_UXU, XUW, a.XU, xu_stride<real>(a.N), xu_src[j], xu_lim[j]);
+#ifndef TSAT_EMU
+#pragma unroll
+#endif
+  for (int j = 0; j < PK_NI_B; ++j) {
+    const int i = lane + WAVE * j;
+    const int g = i / (PK_BROWS * BROW_UNITS), rem = i - g * (PK_BROWS * BROW_UNITS), r = rem / BROW_UNITS, part = rem - r * BROW_UNITS;
+    const int tg = (traj0 + g <= tmax) ? traj0 + g : tmax;
+    const int Ng = (g < PK_G) ? pk_n[g] : 0;
+    const int kk = r / 3;
+    b_src[j] = (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[tg] * n_tab * 4 + (size_t)part * RPU);
+    b_lim[j] = (g < PK_G && r < PK_CK * 3 && Ng > 0) ? Ng - 1 - kk : NEVER;
+    b_kk[j] = kk; b_st[j] = 0.5 * (double)(r - 3 * kk);
+    b_t0[j] = pk_tau0[g < PK_G ? g : 0]; b_dt[j] = pk_dtau[g < PK_G ? g : 0];
+  }
+  // copy of chunk k0 into buffer `fb`
   auto issue = [&](real* fb, int k0) {
-    for (int g = 0; g < PK_G; ++g) {
-      const int Ng = pk_n[g];
-      const int nk = (Ng - 1 - k0 < PK_CK) ? (Ng - 1 - k0) : PK_CK;     // knots of this trajectory in the chunk (<= 0: none)
-      if (nk <= 0) continue;
-      const int tg = (traj0 + g <= tmax) ? traj0 + g : tmax;
-      const TPtrs<real> pg = group_ptrs<real>(a, tg);
-      const double tau0 = pk_tau0[g], dtau = pk_dtau[g];
-      real* fbg = fb + g * PK_STRIDE;
-      for (int j = 0; j < (PK_UNITS + WAVE - 1) / WAVE; ++j) {
-        const int i = lane + WAVE * j;
-        const TSAT_GLOBAL real* src = nullptr;
-        if (i < PK_U_KD) {
-          if (closed && i * RPU < nk * KDW) src = pg.KD + (size_t)k0 * KDW + (size_t)i * RPU;
-        } else if (i < PK_U_LM) {
-          const int e = i - PK_U_KD;
-          if (e * RPU < nk * LMW) src = pg.LAM + (size_t)k0 * LMW + (size_t)e * RPU;
-        } else if (i < PK_U_XU) {
-          const int e = i - PK_U_LM;
-          if (e * RPU < nk * XUW) src = pg.XU + (size_t)k0 * XUW + (size_t)e * RPU;
-        } else if (i < PK_UNITS) {
-          const int e = i - PK_U_XU, r = e / BROW_UNITS, part = e - r * BROW_UNITS, kk = r / 3, st = r - 3 * kk;
-          if (kk < nk) {
-            const double rr = floor_(fma_((double)(k0 + kk) + 0.5 * (double)st, dtau, tau0));
-            const int row = (rr >= 0.0) ? (rr > (double)(n_tab - 1) ? n_tab - 1 : (int)rr) : 0;
-            src = pg.bt + (size_t)row * 4 + (size_t)part * RPU;
-          }
-        }
-        if (src) glds_put<real>(fbg + (size_t)i * RPU, src);
+#ifndef TSAT_EMU
+#pragma unroll
+#endif
+    for (int j = 0; j < PK_NI_KD; ++j)
+      if (k0 < kd_lim[j]) glds_put_at<real>(fb + PK_R_KD + GLDS * j, kd_src[j] + (size_t)k0 * KDW);
+#ifndef TSAT_EMU
+#pragma unroll
+#endif
+    for (int j = 0; j < PK_NI_LM; ++j)
+      if (k0 < lm_lim[j]) glds_put_at<real>(fb + PK_R_LM + GLDS * j, lm_src[j] + (size_t)k0 * LMW);
+#ifndef TSAT_EMU
+#pragma unroll
+#endif
+    for (int j = 0; j < PK_NI_XU; ++j)
+      if (k0 < xu_lim[j]) glds_put_at<real>(fb + PK_R_XU + GLDS * j, xu_src[j] + (size_t)k0 * XUW);
+#ifndef TSAT_EMU
+#pragma unroll
+#endif
+    for (int j = 0; j < PK_NI_B; ++j)
+      if (k0 < b_lim[j]) {
+        // floor(fma(k + c, dtau, tau0)) clamped — the reference's B_ECI[floor(Int, t*N + 1), :] (src/DerivFunction.jl:28)
+        const double rr = floor_(fma_((double)(k0 + b_kk[j]) + b_st[j], b_dt[j], b_t0[j]));
+        const int row = (rr >= 0.0) ? (rr > (double)(n_tab - 1) ? n_tab - 1 : (int)rr) : 0;
+        glds_put_at<real>(fb + PK_R_B + GLDS * j, b_src[j] + (size_t)row * 4);
       }
-    }
   };
   auto gates = [&](real* fb) {
     for (int e = lane; e < PK_G * PK_CK * LMW; e += WAVE) {
       const int g = e / (PK_CK * LMW), r = e - g * (PK_CK * LMW);
-      real* fbg = fb + g * PK_STRIDE;
-      fbg[PK_GT + r] = (fbg[PK_LM + r] > 0) ? -inf_<real>() : (real)0;
+      fb[PK_R_GT + g * PK_SGT + r] = (fb[PK_R_LM + g * PK_SLM + r] > 0) ? -inf_<real>() : (real)0;
     }
   };
   int cur = 0;
@@ -177,17 +261,16 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
   for (int k0 = 0; k0 < nmax - 1; k0 += PK_CK) {
     const int kn = k0 + PK_CK;
     const bool more = kn < nmax - 1;
-    real* fb = lds + L_FWD + cur * PK_G * PK_STRIDE;
-    real* fbn = lds + L_FWD + ((PK_NBUF == 2) ? (1 - cur) : 0) * PK_G * PK_STRIDE;
+    real* fb = lds + L_FWD + cur * PK_FB;
+    real* fbn = lds + L_FWD + ((PK_NBUF == 2) ? (1 - cur) : 0) * PK_FB;
     if (PK_NBUF == 2 && more) issue(fbn, kn);
-    const real* fbg = fb + myg * PK_STRIDE;
     for (int kk = 0; kk < PK_CK; ++kk) {
       const int k = k0 + kk;
       if (live && k < N - 1) {
-        const real* xu = fbg + PK_XU + kk * XUW;
+        const real* xu = fb + PK_R_XU + myg * PK_SXU + kk * XUW;
         real u[3] = {xu[7], xu[8], xu[9]};
         if (closed) {
-          const real* kd = fbg + PK_KD + kk * KDW;
+          const real* kd = fb + PK_R_KD + myg * PK_SKD + kk * KDW;
           real dx[7];
           if (ES) {
             // quaternion_error(new, nominal) = [dw; MRP(q_nom^-1 (x) q_new)]  (src/quaternion_toolbox.jl:58-75)
@@ -211,13 +294,13 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
         }
         for (int i = 0; i < 7; ++i) amax = fmaxabs_(amax, x[i]);
         for (int c = 0; c < 3; ++c) amax = fmaxabs_(amax, u[c]);
-        J += (acc_t)stage_cost_gated(tr, hw, x, u, fbg + PK_LM + kk * LMW, fbg + PK_GT + kk * LMW);
-        if (store) {
-          TSAT_GLOBAL real* cr = Cg + (size_t)k * XUW;
-          for (int i = 0; i < 7; ++i) cr[i] = x[i];
-          for (int c = 0; c < 3; ++c) cr[7 + c] = u[c];
-        }
-        const real* br = fbg + PK_B + kk * 12;
+        J += (acc_t)stage_cost_gated(tr, hw, x, u, fb + PK_R_LM + myg * PK_SLM + kk * LMW, fb + PK_R_GT + myg * PK_SGT + kk * LMW);
+#ifdef TSAT_PK_EXPERIMENT_NOSTORE   /* timing experiment only: results are wrong without the candidate records */
+        if (store && k == 0) store_record5<real>(Cg + (size_t)k * XUW, x, u);
+#else
+        if (store) store_record5<real>(Cg + (size_t)k * XUW, x, u);   // REC_STORES store instructions (counted below)
+#endif
+        const real* br = fb + PK_R_B + myg * PK_SB + kk * 12;
         const real b0[3] = {br[0], br[1], br[2]}, b1[3] = {br[4], br[5], br[6]}, b2[3] = {br[8], br[9], br[10]};
         real xn[7];
         rk_step<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, xn);
@@ -229,7 +312,13 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
         TSAT_SYNC_LDS();
         issue(fbn, kn);
       }
-      TSAT_SYNC();                 // vmcnt(0): the copy has landed
+      // The copy of the next chunk has to have landed; the candidate stores need not. Double-buffered, the copy was issued
+      // BEFORE this chunk's PK_CK x REC_STORES candidate stores (every knot of a chunk that has a successor is live for at
+      // least one trajectory, so all of them were issued), and vector-memory operations retire in issue order: waiting for all
+      // but that many youngest ones covers the copy and leaves the stores in flight — a full drain would expose the write
+      // acknowledge latency of the scattered candidate stores at every chunk boundary (measured: 1.8x per knot).
+      if (PK_NBUF == 2) TSAT_SYNC_OLDER_THAN(PK_CK * REC_STORES);
+      else TSAT_SYNC();
       gates(fbn);
       TSAT_SYNC_LDS();
       if (PK_NBUF == 2) cur = 1 - cur;
@@ -245,6 +334,262 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
   FwdOut<real> out;
   out.J = J;
   out.ok = ((amax <= max_state) && (J == J)) ? 1 : 0;
+  return out;
+}
+
+// --------------------------------------------------------------------------------------------------
+// joint backward sweep, Jacobian lanes: knots k0 .. k0 + PK_CHG - 1 of every trajectory that takes part (`need`, group-uniform;
+// N, mu: the lane's own trajectory). Leaves [A|B], lx, lu, luu (error-state mode: reduced to error coordinates, G'QG in column 9)
+// in the trajectory's record block. Same per-knot arithmetic as jacobian_chunk (tsat_device.hpp).
+// --------------------------------------------------------------------------------------------------
+template <typename real, int INTEG, int DIAGJ, int ES>
+TSAT_PHASE void jacobian_group(const KArgs<real>& a, int traj0, int k0, bool need, int N, real mu) {
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE(), g = lane / PK_C, kk = (lane % PK_C) >> 2, qtr = lane & 3;
+  const int k = k0 + kk;
+  const bool valid = need && k < N - 1;
+  real* rc = lds + L_GREC + g * PK_GRS + kk * PK_RECS;
+  real* F = rc + R_F;
+  real qk[4] = {1, 0, 0, 0}, qn[4] = {1, 0, 0, 0};
+  if (valid) {
+    const int tmax = a.T - 1;
+    const int traj = (traj0 + g <= tmax) ? traj0 + g : tmax;
+    const TPtrs<real> p = group_ptrs<real>(a, traj);
+    const Traj<real> tr = load_traj_at<real>(lds + L_GTR + g * PK_GTRW, N, a.n_tab, p.bt);
+    const TSAT_GLOBAL real* xu = p.XU + (size_t)k * XUW;
+    real x[7], u[3], b0[3], b1[3], b2[3];
+    for (int i = 0; i < 7; ++i) x[i] = xu[i];
+    for (int c = 0; c < 3; ++c) u[c] = xu[7 + c];
+    const TSAT_GLOBAL real* p0 = tr.bt + (size_t)brow_index(tr, k, 0.0) * 4;
+    const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
+    const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
+    for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
+    const int c_lo = (qtr == 0) ? 0 : (qtr == 1 ? 3 : (qtr == 2 ? 6 : 8));
+    const int c_hi = (qtr == 0) ? 3 : (qtr == 1 ? 6 : (qtr == 2 ? 8 : 10));
+    rk_jacobian_cols<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, F, c_lo, c_hi);
+    if (ES)
+      for (int i = 0; i < 4; ++i) { qk[i] = x[3 + i]; qn[i] = xu[XUW + 3 + i]; }
+    if (qtr == 2) {          // state gradient (error-state mode: lx^ = E(q_k)' lx)
+      real lx[7];
+      for (int i = 0; i < 7; ++i) lx[i] = tr.Qd[i] * (x[i] - tr.xf[i]);
+      if (ES) {
+        real o[3];
+        gt_apply(qk, lx[3], lx[4], lx[5], lx[6], o);
+        lx[3] = o[0]; lx[4] = o[1]; lx[5] = o[2];
+      }
+      for (int i = 0; i < 7; ++i) rc[R_LX + i] = lx[i];
+    }
+    if (qtr == 3) {          // control gradient and Hessian diagonal with the AL terms of the control box
+      real lam[6];
+      for (int c = 0; c < 6; ++c) lam[c] = p.LAM[(size_t)k * LMW + c];
+      al_control_terms(tr, u, lam, mu, rc + R_LU, rc + R_LUU);
+    }
+  }
+  if (ES) {
+    // reduction to error coordinates, in place: A^ = E(q_{k+1})' A E(q_k), B^ = E(q_{k+1})' B (src/attitude_controller.jl:59-81),
+    // Qxx^ = E(q_k)' Q E(q_k) (src/quaternion_toolbox.jl:15-36). First the columns 3..6 of A -> 3 error columns, rows split over
+    // the quarters; then, per destination column (B moves from 7..9 to 6..8), the rows 3..6 -> 3 error rows. The quarter that
+    // moves B (sources 7, 8, 9, in that order) writes G'QG into the vacated column 9 afterwards.
+    TSAT_SYNC_LDS();
+    if (valid)
+      for (int i = qtr; i < 7; i += 4) {
+        real o[3];
+        gt_apply(qk, F[3 * FS + i], F[4 * FS + i], F[5 * FS + i], F[6 * FS + i], o);
+        F[3 * FS + i] = o[0]; F[4 * FS + i] = o[1]; F[5 * FS + i] = o[2];
+      }
+    TSAT_SYNC_LDS();
+    if (valid) {
+      const int d_lo = (qtr < 3) ? 2 * qtr : 6, d_hi = (qtr < 3) ? 2 * qtr + 2 : 9;
+      for (int c = d_lo; c < d_hi; ++c) {
+        const int src = (c < 6) ? c : c + 1;
+        real v[7], o[3];
+        for (int i = 0; i < 7; ++i) v[i] = F[src * FS + i];
+        gt_apply(qn, v[3], v[4], v[5], v[6], o);
+        for (int i = 0; i < 3; ++i) { F[c * FS + i] = v[i]; F[c * FS + 3 + i] = o[i]; }
+      }
+      if (qtr == 3) {  // G' diag(Qd[3:7]) G, upper triangle (0,0)(0,1)(0,2)(1,1)(1,2)(2,2); G rows: [-v'; s I + hat(v)]
+        const real* Qd = lds + L_GTR + g * PK_GTRW + P_QD;
+        const real sq = qk[0], v0 = qk[1], v1 = qk[2], v2 = qk[3];
+        const real G[4][3] = {{-v0, -v1, -v2}, {sq, -v2, v1}, {v2, sq, -v0}, {-v1, v0, sq}};
+        int idx = 0;
+        for (int j = 0; j < 3; ++j)
+          for (int l = j; l < 3; ++l) {
+            real acc = 0;
+            for (int r = 0; r < 4; ++r) acc += G[r][j] * Qd[3 + r] * G[r][l];
+            rc[PK_R_QQ + idx++] = acc;
+          }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// joint backward sweep, Riccati lanes: the recursion over one chunk (last knot first) for the PK_G trajectories at once.
+// Lane j (of the trajectory's 16) owns column j of F = [A|B]; S~ = [S; s'] is replicated in the registers of the trajectory's
+// lanes and re-read from its exchange block after every knot. Per output element the operations are those of riccati_chunk.
+// `ok`: no Quu_reg of this trajectory has failed the PD test so far (group-uniform); returned updated.
+// --------------------------------------------------------------------------------------------------
+template <typename real> struct GBwd { acc_t dV1, dV2; int ok; };
+
+template <typename real, int NH>
+TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, int k0, bool need, int N, real rho, acc_t dV1, acc_t dV2, int ok_in) {
+  constexpr int ES = (NH == 6) ? 1 : 0;
+  constexpr int NC = NH + 3;
+  constexpr int NP = NH * (NH + 1) / 2;
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE(), g = lane / PK_C, j = lane % PK_C;
+  const int jc = (j < NC) ? j : NC - 1;          // lanes without a column compute on the last one and commit nothing
+  const int jx = (j < NH) ? j : NH - 1;          // state column (clamped)
+  const int jb = (j >= NH && j < NC) ? j - NH : 0;   // control column (clamped)
+  const bool xlane = j < NH, ulane = j >= NH && j < NC;
+  real* gx = lds + L_GX + g * PK_GXW;
+  const real* Qd = lds + L_GTR + g * PK_GTRW + P_QD;
+  const real* recs = lds + L_GREC + g * PK_GRS;
+  const int tmax = a.T - 1;
+  const int traj = (traj0 + g <= tmax) ? traj0 + g : tmax;
+  TSAT_GLOBAL real* KDg = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * kd_stride<real>(a.N));
+  bool ok = ok_in != 0;
+  real Ss[NP], sv[NH];
+  for (int e = 0; e < NP; ++e) Ss[e] = gx[GX_S + e];
+  for (int m = 0; m < NH; ++m) sv[m] = gx[GX_S + NP + m];
+  // Qxx(i, j) starts from the stage Hessian: diag(Qd) (error-state mode: diag(Qd[0:3]) on the rates, G'QG on the attitude block)
+  real qdiag[NH];
+  for (int i = 0; i < NH; ++i) qdiag[i] = (i == j && (!ES || i < 3)) ? Qd[i] : (real)0;
+  for (int l = PK_CHG - 1; l >= 0; --l) {
+    const int k = k0 + l;
+    bool act = need && ok && k < N - 1;
+    const real* rc = recs + l * PK_RECS;
+    // step 1: column jc of W~ = [S; s'] F
+    real f[NH], W[NH + 1];
+    for (int m = 0; m < NH; ++m) f[m] = rc[jc * FS + m];
+    for (int r = 0; r < NH; ++r) {
+      real acc = 0;
+      for (int m = 0; m < NH; ++m) acc = fma_(Ss[(r <= m) ? sym_ut(r, m, NH) : sym_ut(m, r, NH)], f[m], acc);
+      W[r] = acc;
+    }
+    {
+      real acc = 0;
+      for (int m = 0; m < NH; ++m) acc = fma_(sv[m], f[m], acc);
+      W[NH] = acc;
+    }
+    // step 2: column jc of F'W~ — rows i < NH: Qxx(i, j) (used for i <= j); rows NH + a: Qux(a, j) on a state lane,
+    // Quu(a, b) (used for a <= b) on the control lane b; Qu(b) = lu + B(:, b)' s on the control lanes
+    real Q[NC];
+    for (int i = 0; i < NH; ++i) {
+      real ini = 0;
+      if (ES && i >= 3) {
+        const int aa = i - 3, bb = (jx >= 3) ? jx - 3 : 0;
+        const real qq = rc[PK_R_QQ + (aa == 0 ? bb : (aa == 1 ? 2 + bb : 5))];
+        ini = (jx >= i) ? qq : (real)0;
+      }
+      real acc = qdiag[i] + ini;
+      for (int m = 0; m < NH; ++m) acc = fma_(rc[i * FS + m], W[m], acc);
+      Q[i] = acc;
+    }
+    for (int aa = 0; aa < 3; ++aa) {
+      const real luu = rc[R_LUU + aa];
+      real acc = (real)0 + ((ulane && jb == aa) ? luu : (real)0);
+      for (int m = 0; m < NH; ++m) acc = fma_(rc[(NH + aa) * FS + m], W[m], acc);
+      Q[NH + aa] = acc;
+    }
+    real Qu;
+    {
+      real acc = (real)0 + rc[R_LU + jb];
+      for (int m = 0; m < NH; ++m) acc = fma_(f[m], sv[m], acc);
+      Qu = acc;
+    }
+    if (act && ulane) {
+      for (int aa = 0; aa < 3; ++aa)
+        if (aa <= jb) gx[GX_QU + ((aa == 0) ? jb : (aa == 1 ? 2 + jb : 5))] = Q[NH + aa];
+      gx[GX_QU + 6 + jb] = Qu;
+    }
+    TSAT_SYNC_LDS();
+    // step 3: regularise, PD test (Sylvester), adjugate inverse, K(:, j) = -Quu_reg^-1 Qux(:, j), d = -Quu_reg^-1 Qu
+    real Kc[3], d[3], qu[3];
+    {
+      const real h00 = gx[GX_QU + 0], h01 = gx[GX_QU + 1], h02 = gx[GX_QU + 2], h11 = gx[GX_QU + 3], h12 = gx[GX_QU + 4],
+                 h22 = gx[GX_QU + 5];
+      for (int c = 0; c < 3; ++c) qu[c] = gx[GX_QU + 6 + c];
+      const real q00 = h00 + rho, q11 = h11 + rho, q22 = h22 + rho;
+      const real q10 = h01, q20 = h02, q21 = h12;
+      const real c00 = dmm_(q11, q22, q21, q21);
+      const real c01 = dmm_(q20, q21, q10, q22);
+      const real c02 = dmm_(q10, q21, q20, q11);
+      const real c11 = dmm_(q00, q22, q20, q20);
+      const real c12 = dmm_(q10, q20, q00, q21);
+      const real c22 = dmm_(q00, q11, q10, q10);
+      const real det = dot3_(q00, c00, q10, c01, q20, c02);
+      const bool pd = (q00 > 0 && c22 > 0 && det > 0);
+      const real nid = -rcp_(det);
+      const real h0 = Q[NH + 0], h1 = Q[NH + 1], h2 = Q[NH + 2];
+      for (int aa = 0; aa < 3; ++aa) {
+        const real Qi0 = ((aa == 0) ? c00 : (aa == 1 ? c01 : c02)) * nid;
+        const real Qi1 = ((aa == 0) ? c01 : (aa == 1 ? c11 : c12)) * nid;
+        const real Qi2 = ((aa == 0) ? c02 : (aa == 1 ? c12 : c22)) * nid;
+        Kc[aa] = dot3_(Qi0, h0, Qi1, h1, Qi2, h2);
+        d[aa] = dot3_(Qi0, qu[0], Qi1, qu[1], Qi2, qu[2]);
+      }
+      if (act) {
+        if (xlane) {
+          for (int c = 0; c < 3; ++c) { gx[GX_XK + j * 6 + c] = Q[NH + c]; gx[GX_XK + j * 6 + 3 + c] = Kc[c]; }
+        }
+        // K,d record of the knot: lanes 0..6 their gain column (zero beyond NH), lane 7 the feed-forward; stays in flight
+        if (j < 8)
+          for (int c = 0; c < 3; ++c) {
+            const real v = (j < NH) ? Kc[c] : ((j == 7) ? d[c] : (real)0);
+            KDg[(size_t)k * KDW + ((j < 7) ? (c * 7 + j) : (21 + c))] = v;
+          }
+        if (!pd) ok = false;
+      }
+      act = act && ok;
+    }
+    TSAT_SYNC_LDS();
+    // step 4: cost-to-go. With K = -Quu_reg^-1 Qux: Sxx = Qxx + sym(Qux'K) - rho K'K ; Sx = Qx + sym(Qux'd, Qu'K) - rho K'd
+    {
+      const real dqu = dot3_(d[0], qu[0], d[1], qu[1], d[2], qu[2]);
+      if (act) {
+        dV1 += (acc_t)dqu;
+        dV2 -= (acc_t)((real)0.5 * fma_(rho, dot3_(d[0], d[0], d[1], d[1], d[2], d[2]), dqu));
+      }
+      const real* xk = gx + GX_XK;
+      real hj[3], kj[3];
+      for (int c = 0; c < 3; ++c) { hj[c] = Q[NH + c]; kj[c] = Kc[c]; }
+      real Sn[NH];
+      for (int i = 0; i < NH; ++i) {
+        real hi[3], ki[3];
+        for (int c = 0; c < 3; ++c) { hi[c] = xk[i * 6 + c]; ki[c] = xk[i * 6 + 3 + c]; }
+        real acc = Q[i] + (real)0;
+        real sy = 0, kk = 0;
+        for (int c = 0; c < 3; ++c) {
+          sy += fma_(hi[c], kj[c], hj[c] * ki[c]);
+          kk = fma_(ki[c], kj[c], kk);
+        }
+        acc += dmm_((real)0.5, sy, rho, kk);
+        Sn[i] = acc;
+      }
+      real sn;
+      {   // s(j): the same formula with "column 7": hi = Qux(:, j), hj = Qu, ki = K(:, j), kj = d
+        real acc = rc[R_LX + jx] + W[NH];
+        real sy = 0, kk = 0;
+        for (int c = 0; c < 3; ++c) {
+          sy += fma_(hj[c], d[c], qu[c] * kj[c]);
+          kk = fma_(kj[c], d[c], kk);
+        }
+        acc += dmm_((real)0.5, sy, rho, kk);
+        sn = acc;
+      }
+      if (act && xlane) {
+        for (int i = 0; i < NH; ++i)
+          if (i <= j) gx[GX_S + sym_ut(i, (j < NH ? j : NH - 1), NH)] = Sn[i];
+        gx[GX_S + NP + j] = sn;
+      }
+    }
+    TSAT_SYNC_LDS();
+    for (int e = 0; e < NP; ++e) Ss[e] = gx[GX_S + e];
+    for (int m = 0; m < NH; ++m) sv[m] = gx[GX_S + NP + m];
+  }
+  GBwd<real> out;
+  out.dV1 = dV1; out.dV2 = dV2; out.ok = ok ? 1 : 0;
   return out;
 }
 
@@ -271,7 +616,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
   mine.N = mine.active ? (a.nk ? a.nk[traj0 + myg] : NS) : 2;
   mine.status = TSAT_MAX_OUTER; mine.outer = 0; mine.it = 0; mine.inner_iters = 0; mine.ls_trials = 0; mine.n_backward = 0;
   mine.n_forward = 0; mine.bp_restarts = 0; mine.fp_fails = 0; mine.djz = 0; mine.trow = 0; mine.regfail = 0;
-  mine.found = 0; mine.jw = 0; mine.slot = 0;
+  mine.found = 0; mine.jw = 0; mine.slot = 0; mine.need_bwd = 0;
 
   // initial_controls!(prob, U0) (src/TortoiseSat.jl:191) + zero multipliers, trajectory by trajectory (lanes = knots)
   for (int g = 0; g < ntr; ++g) {
@@ -290,32 +635,12 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
   TSAT_SYNC();
 
   // ---- per-trajectory pieces of the driver; `u` is the wave-uniform copy of the state of the trajectory being advanced ---
-  auto backward_for = [&](const TPtrs<real>& p, GState<real>& u) {   // backward sweep with regularisation restarts
-    BwdOut<real> bw;
-    bw.dV1 = 0; bw.dV2 = 0; bw.pd_ok = 0;
-    for (;;) {
-      u.n_backward++;
-      bw = backward_sweep<real, INTEG, DIAGJ, ES>(p, u.N, n_tab, u.mu, u.rho, tmask);
-      if (bw.pd_ok) break;
-      u.bp_restarts++;
-      u.drho = (u.drho * (real)o.reg_scale > (real)o.reg_scale) ? u.drho * (real)o.reg_scale : (real)o.reg_scale;
-      u.rho = (u.rho * u.drho > (real)o.reg_min) ? u.rho * u.drho : (real)o.reg_min;
-      if (u.rho > (real)o.reg_max) { u.regfail = 1; break; }
-    }
-    if (u.regfail) return;
-    u.dV1 = bw.dV1; u.dV2 = bw.dV2;
-    u.rho_used = u.rho;
-    const real inv = (real)1 / (real)o.reg_scale;    // regularisation decrease
-    u.drho = (u.drho / (real)o.reg_scale < inv) ? u.drho / (real)o.reg_scale : inv;
-    const real r = u.rho * u.drho;
-    u.rho = (r > (real)o.reg_min) ? r : (real)0;
+  // trajectory constants + terminal multipliers into the wave's LDS block: what the per-trajectory phase functions read
+  auto stage_for = [&](int g, const GState<real>& u) {
     TSAT_SYNC();
-  };
-  auto start_outer = [&](const TPtrs<real>& p, GState<real>& u, int outer) {   // AL cost of the nominal, fresh regularisation, backward
-    u.outer = outer;
-    u.Jprev = nominal_cost<real>(p, u.N, u.mu, tmask, 1);
-    u.rho = (real)o.reg_init; u.drho = 0; u.djz = 0; u.regfail = 0; u.it = 1;
-    backward_for(p, u);
+    stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)(traj0 + g) * PSTRIDE), (real)o.u_scale);
+    if (lane < 7) lds[L_NU + lane] = u.nu[lane];
+    TSAT_SYNC();
   };
   auto finish = [&](int g, const TPtrs<real>& p, GState<real>& u) {   // final statistics of trajectory g
     TSAT_SYNC();
@@ -328,83 +653,161 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       st.n_backward = u.n_backward; st.n_forward = u.n_forward; st.bp_restarts = u.bp_restarts; st.fp_fails = u.fp_fails;
       st.cost = (double)cost; st.cost_al = (double)cost_al; st.c_max = (double)cmax; st.grad = (double)u.grad;
     }
-    u.active = 0;
+    u.active = 0; u.need_bwd = 0;
+  };
+  // first step of an outer iteration: AL cost of the nominal, fresh regularisation; the backward sweep follows (joint_backward)
+  auto start_outer = [&](const TPtrs<real>& p, GState<real>& u, int outer) {
+    u.outer = outer;
+    u.Jprev = nominal_cost<real>(p, u.N, u.mu, tmask, 1);
+    u.rho = (real)o.reg_init; u.drho = 0; u.djz = 0; u.regfail = 0; u.it = 1;
+    u.need_bwd = 1;
+  };
+  // end of an inner loop (budget, tolerance or a regularisation failure): outer-loop bookkeeping; the trajectory is finished or
+  // starts its next outer iteration
+  auto end_inner = [&](int g, const TPtrs<real>& p, GState<real>& u) {
+    TSAT_SYNC();
+    const real cmax = violation_and_duals<real>(p, u.N, u.mu, tmask, 0, (real)o.dual_max);
+    if (u.regfail) { u.status = TSAT_REG_FAIL; finish(g, p, u); return; }
+    if (cmax < (real)o.constraint_tol) { u.status = TSAT_CONVERGED; finish(g, p, u); return; }
+    if (u.outer == o.max_outer) { finish(g, p, u); return; }
+    (void)violation_and_duals<real>(p, u.N, u.mu, tmask, 1, (real)o.dual_max);   // dual update of the control box
+    if (lane < 7 && ((tmask >> lane) & 1)) {
+      const real dmax = (real)o.dual_max;
+      real v = lds[L_NU + lane] + u.mu * (p.XU[(size_t)(u.N - 1) * XUW + lane] - lds[L_TR + P_XF + lane]);
+      v = v > -dmax ? v : -dmax; v = v < dmax ? v : dmax;
+      lds[L_NU + lane] = v;
+    }
+    u.mu = (u.mu * (real)o.penalty_scale < (real)o.penalty_max) ? u.mu * (real)o.penalty_scale : (real)o.penalty_max;
+    TSAT_SYNC();
+    for (int i = 0; i < 7; ++i) u.nu[i] = lds[L_NU + i];
+    start_outer(p, u, u.outer + 1);
   };
   // Advance trajectory g from "a forward sweep has just been evaluated" (after_forward) or from the very start to the point
-  // where it needs the next forward sweep (u.active stays 1, gains of a fresh backward sweep in HBM) or is finished.
+  // where it needs its next backward sweep (u.need_bwd) or is finished.
   auto advance = [&](int g, GState<real>& u, bool after_forward) {
     const int traj = traj0 + g;
     const TPtrs<real> p = group_ptrs<real>(a, traj);
     double* trace = a.trace ? a.trace + (size_t)traj * a.trace_rows * 8 : nullptr;
-    // trajectory constants + terminal multipliers into the wave's LDS block: what the per-trajectory phase functions read
-    TSAT_SYNC();
-    stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)traj * PSTRIDE), (real)o.u_scale);
-    if (lane < 7) lds[L_NU + lane] = u.nu[lane];
-    TSAT_SYNC();
-    bool inner_over = false;
+    stage_for(g, u);
     if (!after_forward) {
       (void)adopt_and_gradient<real>(p, u.N, 0);        // the open-loop rollout becomes the nominal trajectory
       TSAT_SYNC();
       start_outer(p, u, 1);
-      inner_over = u.regfail != 0;
+      return;
+    }
+    acc_t J;
+    if (u.found) {
+      J = u.Jw;
+      u.ls_trials += u.jw + 1;
+      u.grad = adopt_and_gradient<real>(p, u.N, u.slot);
     } else {
-      acc_t J;
-      if (u.found) {
-        J = u.Jw;
-        u.ls_trials += u.jw + 1;
-        u.grad = adopt_and_gradient<real>(p, u.N, u.slot);
-      } else {
-        J = u.Jprev;
-        u.ls_trials += max_ls;
-        u.fp_fails++;
-        u.drho = (u.drho * (real)o.reg_scale > (real)o.reg_scale) ? u.drho * (real)o.reg_scale : (real)o.reg_scale;
-        u.rho = (u.rho * u.drho > (real)o.reg_min) ? u.rho * u.drho : (real)o.reg_min;
-        u.rho += (real)o.reg_fp;
-        u.grad = adopt_and_gradient<real>(p, u.N, -1);
+      J = u.Jprev;
+      u.ls_trials += max_ls;
+      u.fp_fails++;
+      u.drho = (u.drho * (real)o.reg_scale > (real)o.reg_scale) ? u.drho * (real)o.reg_scale : (real)o.reg_scale;
+      u.rho = (u.rho * u.drho > (real)o.reg_min) ? u.rho * u.drho : (real)o.reg_min;
+      u.rho += (real)o.reg_fp;
+      u.grad = adopt_and_gradient<real>(p, u.N, -1);
+    }
+    TSAT_SYNC();
+    acc_t dJ = J - u.Jprev;
+    dJ = dJ < 0 ? -dJ : dJ;
+    if (trace && lane == 0 && u.trow < a.trace_rows) {
+      double* r = trace + 8 * u.trow;
+      r[0] = u.outer; r[1] = u.it; r[2] = (double)u.Jprev; r[3] = (double)J; r[4] = u.found ? u.jw : -1;
+      r[5] = (double)u.rho_used; r[6] = (double)u.dV1; r[7] = (double)u.dV2;
+    }
+    u.trow++;
+    u.Jprev = J;
+    u.djz = (dJ == 0) ? u.djz + 1 : 0;
+    u.inner_iters++;
+    const bool inner_over = (0 < dJ && dJ < (acc_t)o.cost_tol) || (u.grad < (real)o.grad_tol) || (u.djz > o.dj_counter_limit) ||
+                            (u.it >= o.max_inner);
+    if (!inner_over) {
+      u.it++;
+      u.need_bwd = 1;
+      return;
+    }
+    end_inner(g, p, u);
+  };
+  unsigned long long pc_jac = 0, pc_ric = 0;   // diagnostic build: shader clocks in the Jacobian lanes / the Riccati lanes
+  // Backward sweeps of all trajectories that need one (mine.need_bwd), together, with their regularisation restarts:
+  // a trajectory whose Quu_reg was not positive definite raises its rho and takes part in the next round.
+  auto joint_backward = [&]() {
+    constexpr int NH = BwdCfg<ES>::NH, NP = NH * (NH + 1) / 2;
+    for (;;) {
+      const bool need = mine.need_bwd != 0;
+      int* ng = reinterpret_cast<int*>(lds + L_RED);        // horizons of the trajectories that take part (0: does not)
+      TSAT_SYNC_LDS();
+      if (myc == 0) ng[myg] = need ? mine.N : 0;
+      TSAT_SYNC_LDS();
+      int nmax = 0, ngl[PK_G];
+      for (int g = 0; g < PK_G; ++g) { ngl[g] = ng[g]; nmax = (ngl[g] > nmax) ? ngl[g] : nmax; }
+      TSAT_SYNC_LDS();
+      if (nmax == 0) break;
+      // constants and terminal cost-to-go of every trajectory that takes part, into its blocks
+      for (int g = 0; g < ntr; ++g) {
+        if (ngl[g] == 0) continue;
+        const GState<real> u = gstate_bcast(mine, g * PK_C);
+        stage_for(g, u);
+        real* gt = lds + L_GTR + g * PK_GTRW;
+        for (int e = lane; e < PK_GT_NU + 8; e += WAVE) gt[e] = lds[L_TR + e];     // L_NU follows L_TR
+        const TSAT_GLOBAL real* XUg = (const TSAT_GLOBAL real*)(a.XU + (size_t)(traj0 + g) * xu_stride<real>(NS));
+        terminal_cost_to_go<real, ES>(XUg, u.N, u.mu, tmask);
+        TSAT_SYNC_LDS();
+        real* gx = lds + L_GX + g * PK_GXW;
+        for (int e = lane; e < NP + NH; e += WAVE) {
+          int i = NH, j = e - NP;
+          if (e < NP) pair_ut(e, NH, i, j);
+          gx[GX_S + e] = lds[L_ST + i * 9 + j];
+        }
+        TSAT_SYNC_LDS();
       }
-      TSAT_SYNC();
-      acc_t dJ = J - u.Jprev;
-      dJ = dJ < 0 ? -dJ : dJ;
-      if (trace && lane == 0 && u.trow < a.trace_rows) {
-        double* r = trace + 8 * u.trow;
-        r[0] = u.outer; r[1] = u.it; r[2] = (double)u.Jprev; r[3] = (double)J; r[4] = u.found ? u.jw : -1;
-        r[5] = (double)u.rho_used; r[6] = (double)u.dV1; r[7] = (double)u.dV2;
+      GBwd<real> bw;
+      bw.dV1 = 0; bw.dV2 = 0; bw.ok = 1;
+      const int nch = (nmax - 1 + PK_CHG - 1) / PK_CHG;
+      for (int ch = nch - 1; ch >= 0; --ch) {
+        const int k0 = ch * PK_CHG;
+        const unsigned long long t0 = tick_();
+        jacobian_group<real, INTEG, DIAGJ, ES>(a, traj0, k0, need && bw.ok, mine.N, mine.mu);
+        TSAT_SYNC_LDS();
+        const unsigned long long t1 = tick_();
+        bw = riccati_group<real, NH>(a, traj0, k0, need, mine.N, mine.rho, bw.dV1, bw.dV2, bw.ok);
+        TSAT_SYNC_LDS();
+        pc_jac += t1 - t0; pc_ric += tick_() - t1;
       }
-      u.trow++;
-      u.Jprev = J;
-      u.djz = (dJ == 0) ? u.djz + 1 : 0;
-      u.inner_iters++;
-      inner_over = (0 < dJ && dJ < (acc_t)o.cost_tol) || (u.grad < (real)o.grad_tol) || (u.djz > o.dj_counter_limit) ||
-                   (u.it >= o.max_inner);
-      if (!inner_over) {
-        u.it++;
-        backward_for(p, u);
-        inner_over = u.regfail != 0;
+      if (need) {
+        mine.n_backward++;
+        if (bw.ok) {
+          mine.dV1 = bw.dV1; mine.dV2 = bw.dV2;
+          mine.rho_used = mine.rho;
+          const real inv = (real)1 / (real)o.reg_scale;    // regularisation decrease
+          mine.drho = (mine.drho / (real)o.reg_scale < inv) ? mine.drho / (real)o.reg_scale : inv;
+          const real r = mine.rho * mine.drho;
+          mine.rho = (r > (real)o.reg_min) ? r : (real)0;
+          mine.need_bwd = 0;
+        } else {
+          mine.bp_restarts++;
+          mine.drho = (mine.drho * (real)o.reg_scale > (real)o.reg_scale) ? mine.drho * (real)o.reg_scale : (real)o.reg_scale;
+          mine.rho = (mine.rho * mine.drho > (real)o.reg_min) ? mine.rho * mine.drho : (real)o.reg_min;
+          if (mine.rho > (real)o.reg_max) { mine.regfail = 1; mine.need_bwd = 0; }
+        }
       }
     }
-    while (inner_over) {      // end of an inner loop: outer-loop bookkeeping, possibly straight into the next outer iteration
-      inner_over = false;
-      TSAT_SYNC();
-      const real cmax = violation_and_duals<real>(p, u.N, u.mu, tmask, 0, (real)o.dual_max);
-      if (u.regfail) { u.status = TSAT_REG_FAIL; finish(g, p, u); break; }
-      if (cmax < (real)o.constraint_tol) { u.status = TSAT_CONVERGED; finish(g, p, u); break; }
-      if (u.outer == o.max_outer) { finish(g, p, u); break; }
-      (void)violation_and_duals<real>(p, u.N, u.mu, tmask, 1, (real)o.dual_max);   // dual update of the control box
-      if (lane < 7 && ((tmask >> lane) & 1)) {
-        const real dmax = (real)o.dual_max;
-        real v = lds[L_NU + lane] + u.mu * (p.XU[(size_t)(u.N - 1) * XUW + lane] - lds[L_TR + P_XF + lane]);
-        v = v > -dmax ? v : -dmax; v = v < dmax ? v : dmax;
-        lds[L_NU + lane] = v;
+    TSAT_SYNC();      // the gains are in HBM before a forward sweep reads them
+    // a trajectory whose regularisation ran out ends here (status REG_FAIL)
+    for (int g = 0; g < ntr; ++g) {
+      GState<real> u = gstate_bcast(mine, g * PK_C);
+      if (u.active && u.regfail) {
+        stage_for(g, u);
+        end_inner(g, group_ptrs<real>(a, traj0 + g), u);
       }
-      u.mu = (u.mu * (real)o.penalty_scale < (real)o.penalty_max) ? u.mu * (real)o.penalty_scale : (real)o.penalty_max;
-      TSAT_SYNC();
-      for (int i = 0; i < 7; ++i) u.nu[i] = lds[L_NU + i];
-      start_outer(p, u, u.outer + 1);
-      inner_over = u.regfail != 0;
+      if (myg == g) mine = u;
     }
   };
   auto any_lane = [&](bool f) { return wave_first<real>(f, lds + L_RED) < WAVE; };
 
+  unsigned long long pc_fwd = 0, pc_adv = 0;   // diagnostic build (-DTSAT_PROFILE): shader clocks in forward sweeps / everything else
   // ---- open-loop rollout of U0 for every trajectory of the wave, then the first backward sweeps ------------------------
   {
     const FwdOut<real> f0 = forward_sweep_packed<real, INTEG, DIAGJ, ES>(a, traj0, 0, 0, 1, mine.active != 0, mine.N, mine.mu, mine.nu,
@@ -429,6 +832,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       }
       if (myg == g) mine = u;
     }
+    joint_backward();
   }
   // ---- main loop: one forward sweep for all trajectories that are still iterating, then each of them moves on ------------
   while (any_lane(mine.active != 0)) {
@@ -437,8 +841,10 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       const bool live = mine.active && !mine.found;
       if (!any_lane(live)) break;
       TSAT_SYNC();
+      const unsigned long long t_f0 = tick_();
       const FwdOut<real> fw = forward_sweep_packed<real, INTEG, DIAGJ, ES>(a, traj0, 1, shift, n_store, live, mine.N, mine.mu, mine.nu,
                                                                            tmask, max_state);
+      pc_fwd += tick_() - t_f0;
       if (live) mine.n_forward++;
       // first accepted candidate of each trajectory (sequential backtracking picks exactly this one)
       const int ci = myc + shift;
@@ -467,12 +873,32 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       if (live && jl < PK_C) { mine.found = 1; mine.jw = shift + jl; mine.slot = jl; mine.Jw = Jwin; }
     }
     TSAT_SYNC();
+    const unsigned long long t_a0 = tick_();
     for (int g = 0; g < ntr; ++g) {
       GState<real> u = gstate_bcast(mine, g * PK_C);
       if (u.active) advance(g, u, true);
       if (myg == g) mine = u;
     }
+    joint_backward();
+    pc_adv += tick_() - t_a0;
   }
+#ifdef TSAT_PROFILE
+  {   // row 0 of the wave's first trajectory carries the phase clocks of the whole wave (PK_G trajectories)
+    int its = 0, nb = 0;
+    for (int g = 0; g < ntr; ++g) {
+      const GState<real> u = gstate_bcast(mine, g * PK_C);
+      its += u.inner_iters; nb += u.n_backward;
+    }
+    if (a.trace && a.trace_rows > 0 && lane == 0) {
+      double* trace = a.trace + (size_t)traj0 * a.trace_rows * 8;
+      const double jac = (double)pc_jac, ric = (double)pc_ric;
+      trace[0] = (double)pc_fwd; trace[1] = jac; trace[2] = ric; trace[3] = (double)pc_adv - jac - ric;
+      trace[4] = (double)its; trace[5] = (double)nb;
+    }
+  }
+#else
+  (void)pc_fwd; (void)pc_adv; (void)pc_jac; (void)pc_ric;
+#endif
 }
 
 }  // namespace tsat
