@@ -146,6 +146,12 @@ def emu_f32(pkg):
     return Emu(pkg._abi, "libtsat_emu_f32.so")
 
 
+@pytest.fixture(scope="session")
+def emu_packed_f32(pkg):
+    """the fp32 packed build (tsat_kernels_packed_f32.hip)"""
+    return Emu(pkg._abi, "libtsat_emu_packed_f32.so")
+
+
 def oracle_options(ol, **kw):
     o = ol.default_options()
     for k, v in kw.items():

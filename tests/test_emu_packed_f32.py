@@ -85,3 +85,13 @@ def test_fp32_build_against_the_fp64_oracle(pkg, ol, emu_f32):
         scale = np.maximum(1.0, np.max(np.abs(ref["U"]), axis=(1, 2)))
         assert np.max(np.max(np.abs(ref["U"] - got["U"]), axis=(1, 2)) / scale) < 1e-3
         np.testing.assert_allclose(got["stats"]["cost"], ref["stats"]["cost"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("T,N,es", [(5, 37, 1), (4, 26, 0)])
+def test_fp32_packed_build_is_the_fp32_solve(pkg, ol, emu_f32, emu_packed_f32, T, N, es):
+    """precision = 32 on large batches takes the packed build: bit-identical to the one-trajectory fp32 build"""
+    assert emu_packed_f32.lib.emu_lds_bytes() <= 20480            # two wavefronts per SIMD
+    b = pkg.slew_setup.workload_monte_carlo(T=T, N=N, seed=900 + N)
+    b.n_knots = np.array([N, max(2, N // 3), N - 1, N, 5][:T], dtype=np.int32)
+    o = oracle_options(ol, max_outer=3, max_inner=4, dj_counter_limit=1, error_state=es)
+    _same_bits(emu_f32.solve(b, o), emu_packed_f32.solve(b, o))

@@ -47,9 +47,10 @@ def _errors(ref, got):
     return dX, dU
 
 
-@pytest.mark.parametrize("variant", [12, 13, 14])
+@pytest.mark.parametrize("variant", [12, 13, 14, 3])
 def test_gpu_fp32_short_solves_agree_outright(pkg, ol, solver, variant):
-    """the three LDS layouts of the fp32 build (2 / 3 / 4 wavefronts per SIMD) on short solves: oracle's statuses and counts"""
+    """the three LDS layouts of the fp32 build (2 / 3 / 4 wavefronts per SIMD) and the fp32 packed build (variant 3, taken
+    automatically from 8192 trajectories on) on short solves: oracle's statuses and counts"""
     b = pkg.slew_setup.workload_monte_carlo(T=16, N=120, seed=31)
     o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1, error_state=1)
     ref, got = ol.solve_batch(b, o, nthreads=8), _run32(pkg, solver, b, o, variant)
@@ -67,7 +68,7 @@ def test_gpu_fp32_configs2_inputs_1000_knots(pkg, ol, solver):
     o = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, error_state=1)
     ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False)
     layouts = {}
-    for variant in (12, 14):
+    for variant in (12, 14, 3):
         got = layouts[variant] = _run32(pkg, solver, b, o, variant)
         rs, gs = ref["stats"], got["stats"]
         dX, dU = _errors(ref, got)

@@ -22,4 +22,18 @@ python3 tools/phase_profile.py > "$OUT/phase_clocks.txt" 2> "$OUT/phase_clocks.e
 python3 tools/monte_carlo_timing.py 1024 1024 > "$OUT/monte_carlo.txt" 2> "$OUT/monte_carlo.err"
 python3 tools/large_batch.py > "$OUT/large_batch.txt" 2> "$OUT/large_batch.err"
 { python3 tools/mpc_timing.py 512 500; python3 tools/mpc_timing.py 4096 200; } > "$OUT/mpc_timing.txt" 2> "$OUT/mpc_timing.err"
+# larger configurations on this one GPU: configs[2] shape in fp64 (packed build) and as quoted (fp32), a configs[3] shard of
+# 8192 trajectories per GPU (what each of 8 GPUs gets), configs[4]; kernel statistics and PMC passes of the fp64 16384 run
+python3 bench.py --config 2 --precision 64 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c2_fp64.json" 2> "$OUT/bench_c2_fp64.err"
+python3 bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c2_fp32.json" 2> "$OUT/bench_c2_fp32.err"
+python3 bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
+cd /tmp
+C2="python3 $ROOT/bench.py --config 2 --precision 64 --steps 2 --warmup 1 --no-cpu-baseline --gather none"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -o run -- $C2 > /dev/null 2> "$OUT/stats_c2.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_c2" -o run -- $C2 > /dev/null 2> "$OUT/pmc_fetch_c2.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c2" -o run -- $C2 > /dev/null 2> "$OUT/pmc_write_c2.err"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
+  --output-format csv -d "$OUT/pmc_sq_c2" -o run -- $C2 > /dev/null 2> "$OUT/pmc_sq_c2.err"
+cd "$ROOT"
+TSAT_PK_G=4 python3 tools/phase_profile.py 16384 1000 3 1 > "$OUT/phase_clocks_packed.txt" 2> "$OUT/phase_clocks_packed.err"
 echo done

@@ -200,8 +200,12 @@ constexpr int L_FWD_END = L_FWD + FWD_NBUF * FB_SIZE;
 constexpr int L_BWD_END = L_REC + (BwdCfg<0>::CHB * BwdCfg<0>::RECS > BwdCfg<1>::CHB * BwdCfg<1>::RECS
                                     ? BwdCfg<0>::CHB * BwdCfg<0>::RECS : BwdCfg<1>::CHB * BwdCfg<1>::RECS);
 #if defined(TSAT_PACKED)
-// packed build (tsat_packed.hpp): its own carve-up behind L_UNION, sized to the 20 480 B of two wavefronts per SIMD
-constexpr int LDS_REALS = 20480 / (int)sizeof(cfg_real);
+// packed build (tsat_packed.hpp): its own carve-up behind L_UNION, sized to the 20 480 B of two wavefronts per SIMD (fp64) or
+// to TSAT_PK_LDS_BYTES (the fp32 packed build: three wavefronts per SIMD, tsat_kernels_packed_f32.hip)
+#ifndef TSAT_PK_LDS_BYTES
+#define TSAT_PK_LDS_BYTES 20480
+#endif
+constexpr int LDS_REALS = (TSAT_PK_LDS_BYTES - ((sizeof(cfg_real) == 8) ? 0 : 64 * 8)) / (int)sizeof(cfg_real);
 #else
 constexpr int LDS_REALS = (L_FWD_END > L_BWD_END ? L_FWD_END : L_BWD_END);
 #endif

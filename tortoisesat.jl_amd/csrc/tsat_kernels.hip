@@ -19,6 +19,7 @@ hipError_t tsat_launch_solve_dense(const KArgs<double>& a, int rk4, int inertia_
 // the packed build — 8 trajectories per wavefront share the forward sweeps (tsat_kernels_packed.hip, tsat_packed.hpp)
 hipError_t tsat_launch_solve_packed(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 // the fp32 build (options.precision = 32) likewise (tsat_kernels_f32.hip)
+hipError_t tsat_launch_solve_packed_f32(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_f32_o2(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_f32_o3(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_f32_o4(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
@@ -383,6 +384,9 @@ int launch_solve_f32(tsat_handle* h, const tsat_options* o) {
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
   // build by batch size: the layout for two wavefronts per SIMD while the batch fits the GPU that way (256 CUs x 4 SIMDs x 2),
   // else the one for four; tsat_set_kernel_variant(h, 12 | 13 | 14) forces one (tuning, tests)
+  // batches several times larger than the machine: the packed build (tsat_kernels_packed_f32.hip), as in fp64
+  if (h->variant == 3 || (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T))
+    return tsat_launch_solve_packed_f32(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream) == hipSuccess ? 0 : -10;
   const int occ = (h->variant >= 12 && h->variant <= 14) ? h->variant - 10 : (h->T <= 2048 ? 2 : 4);
   auto fn = occ == 2 ? tsat_launch_solve_f32_o2 : (occ == 3 ? tsat_launch_solve_f32_o3 : tsat_launch_solve_f32_o4);
   return fn(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream) == hipSuccess ? 0 : -10;

@@ -836,24 +836,30 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
   }
   // ---- main loop: one forward sweep for all trajectories that are still iterating, then each of them moves on ------------
   while (any_lane(mine.active != 0)) {
+    // Line search of every iterating trajectory: a sweep rolls out its PK_C candidates alpha = 2^-(shift + c) and keeps the
+    // rollouts of the first n_store in HBM. The first accepted candidate wins (exactly what sequential backtracking picks); if
+    // its rollout was not kept (index >= n_store: 0.2 % of the iterations on the Monte-Carlo workloads) the trajectory rolls
+    // out that one alpha again in the next sweep of the wave, into slot 0; if none of the PK_C was accepted and candidates are
+    // left (max_linesearch > shift + PK_C), the next sweep takes the next PK_C.
     mine.found = 0;
-    for (int shift = 0; shift < max_ls; shift += n_store) {   // n_store candidates alpha = 2^-(shift + c) per sweep
-      const bool live = mine.active && !mine.found;
+    int g_shift = 0, g_mode = 0;              // per trajectory: 0 searching, 1 re-roll of the winner pending, 2 search over
+    for (;;) {
+      const bool live = mine.active && !mine.found && g_mode != 2;
       if (!any_lane(live)) break;
       TSAT_SYNC();
       const unsigned long long t_f0 = tick_();
-      const FwdOut<real> fw = forward_sweep_packed<real, INTEG, DIAGJ, ES>(a, traj0, 1, shift, n_store, live, mine.N, mine.mu, mine.nu,
-                                                                           tmask, max_state);
+      const FwdOut<real> fw = forward_sweep_packed<real, INTEG, DIAGJ, ES>(a, traj0, 1, g_shift, (g_mode == 1) ? 1 : n_store, live, mine.N,
+                                                                           mine.mu, mine.nu, tmask, max_state);
       pc_fwd += tick_() - t_f0;
       if (live) mine.n_forward++;
-      // first accepted candidate of each trajectory (sequential backtracking picks exactly this one)
-      const int ci = myc + shift;
+      // first accepted candidate of each searching trajectory
+      const int ci = myc + g_shift;
       acc_t alpha = 1;
       for (int j = 0; j < ci && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (acc_t)0.5;
       const acc_t Jc = fw.J;
       const acc_t expected = -alpha * (mine.dV1 + alpha * mine.dV2);
       const acc_t z = (expected > 0) ? (mine.Jprev - Jc) / expected : (acc_t)-1;
-      const bool acc = live && (ci < max_ls) && (myc < n_store) && fw.ok &&
+      const bool acc = live && g_mode == 0 && (ci < max_ls) && fw.ok &&
                        ((z > (acc_t)o.ls_lower && z <= (acc_t)o.ls_upper) || Jc < mine.Jprev);
       real* red = lds + L_RED;
       acc_t* r64 = red64();
@@ -870,7 +876,18 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       TSAT_SYNC_LDS();
       const acc_t Jwin = r64[myg * PK_C + (jl < PK_C ? jl : 0)];
       TSAT_SYNC_LDS();
-      if (live && jl < PK_C) { mine.found = 1; mine.jw = shift + jl; mine.slot = jl; mine.Jw = Jwin; }
+      if (live) {
+        if (g_mode == 1) {                       // the winner's rollout is in slot 0 now
+          mine.found = 1; mine.slot = 0;
+        } else if (jl < PK_C) {
+          mine.jw = g_shift + jl; mine.Jw = Jwin;
+          if (jl < n_store) { mine.found = 1; mine.slot = jl; }
+          else { g_mode = 1; g_shift = mine.jw; }
+        } else {
+          g_shift += PK_C;
+          if (g_shift >= max_ls) g_mode = 2;     // no candidate accepted: the line search has failed
+        }
+      }
     }
     TSAT_SYNC();
     const unsigned long long t_a0 = tick_();

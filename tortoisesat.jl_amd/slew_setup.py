@@ -115,49 +115,6 @@ def bryson_weights(w_guess, J, dt, alpha, beta, degenerate_rd=None):
     return Qd, Qfd, Rd
 
 
-def bryson_weights_ragged(x0, xf, n_knots, t0, dt, J, alpha, beta, block=64):
-    """(Qd (T,7), Qfd (T,7), Rd (T,3)) of T trials whose eigen-axis guesses differ only in the horizon: what
-    ``bryson_weights(eigen_axis_slew(x0, xf, t0 + dt*arange(n))[0], J, dt, alpha, beta)`` returns for every n in ``n_knots``,
-    element for element (same operations on the same numbers — checked bit for bit by tests/test_host.py), computed on
-    blocks of similar horizons instead of one Python iteration per trial (src/monte_carlo.jl:161-176 in the loop body)."""
-    x0 = np.asarray(x0, dtype=np.float64); xf = np.asarray(xf, dtype=np.float64)
-    n_knots = np.asarray(n_knots, dtype=np.int64)
-    T = n_knots.shape[0]
-    q_e = qmult(xf[3:7], x0[3:7])
-    theta_f = 2.0 * np.arccos(np.clip(q_e[0], -1.0, 1.0))
-    if not np.sin(theta_f / 2.0) > 0.0:
-        raise ValueError("eigen_axis_slew: zero-angle slew (q0 and qf coincide): the guess has no rotation axis")
-    if np.any(n_knots < 3):
-        raise ValueError("bryson_weights: a guess of fewer than three knots has no acceleration sample (tau_max <= 0)")
-    axis = -q_e[1:4] / np.sin(theta_f / 2.0)
-    J = np.asarray(J, dtype=np.float64)
-    w_max = np.empty(T); tau_max = np.empty(T)
-    order = np.argsort(n_knots, kind="stable")
-    for b0 in range(0, T, block):
-        idx = order[b0:b0 + block]
-        n = n_knots[idx]
-        nmax = int(n.max())
-        t = t0 + dt * np.arange(nmax)
-        a = np.pi / t[n - 1]
-        theta = theta_f * 0.5 * (1.0 - np.cos(a[:, None] * t[None, :]))
-        d = np.diff(theta, axis=1) / (t[1] - t[0])                       # (B, nmax-1); row j is valid for k < n_j - 1
-        k = np.arange(nmax - 1)[None, :]
-        valid = k < (n - 1)[:, None]
-        w_max[idx] = np.max(np.abs(np.where(valid, d, 0.0)[:, :, None] * axis[None, None, :]), axis=(1, 2))
-        # dw = diff of [w_0 .. w_{n-2}, w_{n-2}] (the guess repeats its last rate, src/eigen_axis_slew.jl:30): n-1 rows, last zero
-        w = d[:, :, None] * axis[None, None, :]
-        dw = np.zeros((len(idx), nmax - 1, 3))
-        dw[:, :-1] = w[:, 1:] - w[:, :-1]
-        dw[~(k < (n - 2)[:, None])] = 0.0
-        tau = (dw @ J.T) / dt                                             # (J dw_k) per knot, as (J @ dw.T).T
-        tau_max[idx] = np.max(np.where((k < (n - 1)[:, None])[:, :, None], tau, -np.inf), axis=(1, 2))
-    if not np.all(w_max > 0.0) or not np.all(tau_max > 0.0):
-        raise ValueError("bryson_weights: degenerate guess (w_max = 0 or tau_max <= 0)")
-    m_max = tau_max / 1.0e-5 * 1.0e2
-    Qd = np.concatenate([np.repeat((alpha / w_max**2)[:, None], 3, axis=1), np.full((T, 4), alpha * beta)], axis=1)
-    return Qd, 10.0 * Qd, np.repeat((1.0 / m_max**2)[:, None], 3, axis=1)
-
-
 # --------------------------------------------------------------------------------------------------
 # synthetic B tables (SURVEY.md §8d: tilted-dipole surrogate until the IGRF row §8f-1 exists)
 # --------------------------------------------------------------------------------------------------
