@@ -147,6 +147,12 @@ def emu_f32(pkg):
 
 
 @pytest.fixture(scope="session")
+def emu_packed8(pkg):
+    """the packed build with eight trajectories per wavefront (tsat_kernels_packed8.hip)"""
+    return Emu(pkg._abi, "libtsat_emu_packed8.so")
+
+
+@pytest.fixture(scope="session")
 def emu_packed_f32(pkg):
     """the fp32 packed build (tsat_kernels_packed_f32.hip)"""
     return Emu(pkg._abi, "libtsat_emu_packed_f32.so")

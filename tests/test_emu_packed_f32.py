@@ -29,6 +29,17 @@ def test_packed_build_is_the_same_solve(pkg, ol, emu, emu_packed, T, N, es, inte
     _same_bits(wide, packed)
 
 
+@pytest.mark.parametrize("T,N,es,integ", [(9, 26, 0, 4), (11, 37, 1, 3), (17, 23, 1, 4)])
+def test_packed8_build_is_the_same_solve(pkg, ol, emu, emu_packed8, T, N, es, integ):
+    """eight trajectories per wavefront (two backward passes of four, two-knot forward chunks), ragged horizons, partial groups"""
+    b = pkg.slew_setup.workload_monte_carlo(T=T, N=N, seed=500 + 7 * T + N, random_orbit=(T == 11))
+    b.n_knots = np.array([N, 2, max(3, N // 2), N - 1, 3, N, N - 2, 7, N, N, 5, N, 4, N, N, 9, N][:T], dtype=np.int32)
+    o = oracle_options(ol, max_outer=3, max_inner=5, dj_counter_limit=1, error_state=es, integrator=integ)
+    wide, packed = emu.solve(b, o), emu_packed8.solve(b, o)
+    assert_same_solution(ol.solve_batch(b, o), packed)
+    _same_bits(wide, packed)
+
+
 @pytest.mark.parametrize("es", [0, 1])
 def test_packed_build_ragged_groups(pkg, ol, emu, emu_packed, es):
     """every trajectory of a group has its own horizon (t_total[i] = 0:0.2:t_final[i], src/monte_carlo.jl:140-145)"""

@@ -1,0 +1,27 @@
+"""Developer tool: dense vs packed build by batch size (where should the automatic choice switch?)  python tools/threshold_timing.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from tsat_loader import load_package
+load_package()
+from tortoisesat_jl_amd import trajopt as to, slew_setup as ss
+base = ss.workload_monte_carlo(T=1024, N=1000, seed=20190531, random_orbit=True)
+for T in (1024, 2048, 3072, 4096, 6144, 8192):
+    k = T // 1024
+    rep = lambda a: np.ascontiguousarray(np.concatenate([a] * k))
+    b = ss.SlewBatch(base.N, base.n_tab, rep(base.x0), rep(base.xf), base.Btab, rep(base.btab_idx), rep(base.tau0), rep(base.dtau),
+                     rep(base.dt), rep(base.Jmat), rep(base.Qd), rep(base.Qfd), rep(base.Rd), rep(base.ulo), rep(base.uhi), rep(base.U0))
+    opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = 5
+    opts.opts_uncon.iterations = 10; opts.opts_uncon.dJ_counter_limit = 1
+    s = to.AugmentedLagrangianSolver(None, opts)
+    o = opts.to_abi(b.N, b.n_tab, 3, error_state=1)
+    s.upload(b, o.max_linesearch)
+    out = []
+    for name, prec, var in (("wide", 64, 1), ("dense", 64, 2), ("packed", 64, 3), ("fp32 2w", 32, 12), ("fp32 4w", 32, 14), ("fp32 packed", 32, 3)):
+        o.precision = prec
+        s.set_kernel_variant(var)
+        ms = [s.run(o) for _ in range(2)][1:]
+        out.append(f"{name} {np.mean(ms):.1f} ms ({T/(np.mean(ms)*1e-3):.0f}/s)")
+    print(f"T={T}: " + "; ".join(out), flush=True)
+    s.close()

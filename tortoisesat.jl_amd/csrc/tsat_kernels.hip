@@ -20,6 +20,8 @@ hipError_t tsat_launch_solve_dense(const KArgs<double>& a, int rk4, int inertia_
 hipError_t tsat_launch_solve_packed(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 // the fp32 build (options.precision = 32) likewise (tsat_kernels_f32.hip)
 hipError_t tsat_launch_solve_packed_f32(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+hipError_t tsat_launch_solve_packed8(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+hipError_t tsat_launch_solve_packed_f328(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_f32_o2(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_f32_o3(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_f32_o4(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
@@ -338,12 +340,16 @@ solve_kern_t solve_variant(const tsat_handle* h, const tsat_options* o) {
   return variants[o->integrator == 4 ? 1 : 0][h->inertia_class][o->error_state ? 1 : 0];
 }
 
-// One wave per SIMD (wide build) as long as the batch fits the GPU that way — 256 CUs x 4 SIMDs — else two (dense build);
-// from 8 trajectories per resident wavefront slot on (2048 slots at two waves per SIMD) the packed build, whose wavefronts
-// own 8 trajectories each and still fill the machine
+// Build by batch size (measured on one MI355X, profiles/r02/build_by_batch_size.txt): one wave per SIMD (wide build) while the
+// batch fits the GPU that way — 256 CUs x 4 SIMDs; two waves per SIMD (dense build) up to about three times that; from there
+// the packed build, four trajectories per wavefront, and eight once eight per wavefront still fill the machine's 2048 slots.
 constexpr int64_t TSAT_WIDE_MAX_T = 1024;
-constexpr int64_t TSAT_PACKED_MIN_T = 8192;
+constexpr int64_t TSAT_PACKED_MIN_T = 3072;
+constexpr int64_t TSAT_PACKED8_MIN_T = 16384;
+constexpr int64_t TSAT_PACKED_F32_MIN_T = 4096;     // below it the one-trajectory float build (two waves per SIMD) is faster
 hipError_t launch_solve(const tsat_handle* h, const tsat_options* o, const KArgs<double>& a) {
+  const bool packed8 = h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED8_MIN_T);
+  if (packed8) return tsat_launch_solve_packed8(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream);
   const bool packed = h->variant == 3 || (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T);
   if (packed) return tsat_launch_solve_packed(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream);
   const bool dense = h->variant == 2 || (h->variant != 1 && h->T > TSAT_WIDE_MAX_T);
@@ -385,9 +391,12 @@ int launch_solve_f32(tsat_handle* h, const tsat_options* o) {
   // build by batch size: the layout for two wavefronts per SIMD while the batch fits the GPU that way (256 CUs x 4 SIMDs x 2),
   // else the one for four; tsat_set_kernel_variant(h, 12 | 13 | 14) forces one (tuning, tests)
   // batches several times larger than the machine: the packed build (tsat_kernels_packed_f32.hip), as in fp64
-  if (h->variant == 3 || (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T))
+  if (h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED8_MIN_T))
+    return tsat_launch_solve_packed_f328(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream) == hipSuccess ? 0 : -10;
+  if (h->variant == 3 || (h->variant == 0 && h->T >= TSAT_PACKED_F32_MIN_T))
     return tsat_launch_solve_packed_f32(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream) == hipSuccess ? 0 : -10;
-  const int occ = (h->variant >= 12 && h->variant <= 14) ? h->variant - 10 : (h->T <= 2048 ? 2 : 4);
+  // one trajectory per wavefront: the two-waves-per-SIMD layout is the fastest at every batch size measured; 13 / 14 force the others
+  const int occ = (h->variant >= 12 && h->variant <= 14) ? h->variant - 10 : 2;
   auto fn = occ == 2 ? tsat_launch_solve_f32_o2 : (occ == 3 ? tsat_launch_solve_f32_o3 : tsat_launch_solve_f32_o4);
   return fn(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream) == hipSuccess ? 0 : -10;
 }
@@ -420,8 +429,8 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
 
 int tsat_set_kernel_variant(tsat_handle* h, int32_t variant) {
   if (!h) return -1;
-  if (!((variant >= 0 && variant <= 3) || (variant >= 12 && variant <= 14)))
-    return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), 3 (packed), or 12 / 13 / 14 (fp32 layouts for 2 / 3 / 4 waves per SIMD)");
+  if (!((variant >= 0 && variant <= 4) || (variant >= 12 && variant <= 14)))
+    return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), 3 (packed, 4 trajectories per wavefront), 4 (packed, 8), or 12 / 13 / 14 (fp32 layouts for 2 / 3 / 4 waves per SIMD)");
   h->variant = variant;
   return 0;
 }

@@ -2,30 +2,37 @@
 // PK_G = 8 trajectories per wavefront share every forward sweep (tsat_packed.hpp), on the dense build's LDS / register budget
 // (two wavefronts per SIMD). Bit-identical results to the wide and dense builds. Separate translation unit because LDS size
 // and register budget are per-kernel compile-time facts.
+//
+// Compiled twice: itself (PK_G = 4 trajectories per wavefront, from TSAT_PACKED_MIN_T trajectories on) and through
+// tsat_kernels_packed8.hip (PK_G = 8, two-knot forward chunks: one forward sweep serves eight trajectories, eight line-search
+// candidates each; pays once eight trajectories per wavefront still fill the machine, from 16384 trajectories on).
 #define TSAT_DENSE 1
 #define TSAT_PACKED 1
+#ifndef TSAT_PK_NAME
+#define TSAT_PK_NAME(base) base
+#endif
 #include <hip/hip_runtime.h>
 #include "tsat_packed.hpp"
 
 using namespace tsat;
 
 template <typename real, int INTEG, int DIAGJ, int ES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void tsat_solve_kernel_packed(KArgs<real> a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void TSAT_PK_NAME(tsat_solve_kernel_packed)(KArgs<real> a) {
   const int wave = blockIdx.x;
   if (wave * PK_G >= a.T) return;
   solve_group<real, INTEG, DIAGJ, ES>(a, wave);
 }
 
 // called by tsat_kernels.hip; same variant axes as the other builds: integrator x inertia class x error-state mode
-hipError_t tsat_launch_solve_packed(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream) {
+hipError_t TSAT_PK_NAME(tsat_launch_solve_packed)(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream) {
   using kern_t = void (*)(KArgs<double>);
   static const kern_t variants[2][3][2] = {
-      {{tsat_solve_kernel_packed<double, 3, 0, 0>, tsat_solve_kernel_packed<double, 3, 0, 1>},
-       {tsat_solve_kernel_packed<double, 3, 1, 0>, tsat_solve_kernel_packed<double, 3, 1, 1>},
-       {tsat_solve_kernel_packed<double, 3, 2, 0>, tsat_solve_kernel_packed<double, 3, 2, 1>}},
-      {{tsat_solve_kernel_packed<double, 4, 0, 0>, tsat_solve_kernel_packed<double, 4, 0, 1>},
-       {tsat_solve_kernel_packed<double, 4, 1, 0>, tsat_solve_kernel_packed<double, 4, 1, 1>},
-       {tsat_solve_kernel_packed<double, 4, 2, 0>, tsat_solve_kernel_packed<double, 4, 2, 1>}}};
+      {{TSAT_PK_NAME(tsat_solve_kernel_packed)<double, 3, 0, 0>, TSAT_PK_NAME(tsat_solve_kernel_packed)<double, 3, 0, 1>},
+       {TSAT_PK_NAME(tsat_solve_kernel_packed)<double, 3, 1, 0>, TSAT_PK_NAME(tsat_solve_kernel_packed)<double, 3, 1, 1>},
+       {TSAT_PK_NAME(tsat_solve_kernel_packed)<double, 3, 2, 0>, TSAT_PK_NAME(tsat_solve_kernel_packed)<double, 3, 2, 1>}},
+      {{TSAT_PK_NAME(tsat_solve_kernel_packed)<double, 4, 0, 0>, TSAT_PK_NAME(tsat_solve_kernel_packed)<double, 4, 0, 1>},
+       {TSAT_PK_NAME(tsat_solve_kernel_packed)<double, 4, 1, 0>, TSAT_PK_NAME(tsat_solve_kernel_packed)<double, 4, 1, 1>},
+       {TSAT_PK_NAME(tsat_solve_kernel_packed)<double, 4, 2, 0>, TSAT_PK_NAME(tsat_solve_kernel_packed)<double, 4, 2, 1>}}};
   const unsigned waves = (unsigned)((a.T + PK_G - 1) / PK_G);
   // Stored line-search candidates per sweep: PK_STORE instead of NSTORE = 12. On the Monte-Carlo workloads the accepted step is
   // alpha = 2^-j with j <= 5 in 99.8 % of the iterations; a deeper winner costs the wave one more sweep (shift += n_store),
@@ -35,4 +42,4 @@ hipError_t tsat_launch_solve_packed(const KArgs<double>& a, int rk4, int inertia
   hipLaunchKernelGGL(variants[rk4 ? 1 : 0][inertia_class][error_state ? 1 : 0], dim3(waves), dim3(64), 0, stream, b);
   return hipGetLastError();
 }
-int tsat_packed_group(void) { return PK_G; }
+int TSAT_PK_NAME(tsat_packed_group)(void) { return PK_G; }

@@ -2,7 +2,8 @@
 // Riccati recursion) in float storage / arithmetic with double costs: options.precision = 32 on batches several times larger
 // than the machine (BASELINE.json configs[2]: 16384 trajectories, "fp32"). Two wavefronts per SIMD like the fp64 packed build (the
 // float carve-up would fit three, the registers do not). Same semantics as the one-trajectory fp32 build (tsat_kernels_f32.hip); separate translation unit
-// because LDS size and register budget are per-kernel compile-time facts.
+// because LDS size and register budget are per-kernel compile-time facts. Compiled twice, like tsat_kernels_packed.hip: itself
+// (four trajectories per wavefront) and through tsat_kernels_packed8_f32.hip (eight).
 #define TSAT_F32 1
 #define TSAT_OCC 2          /* chunk constants of the one-trajectory code paths this build does not use */
 #define TSAT_DENSE 1
@@ -10,27 +11,30 @@
 #ifndef TSAT_PKF_WAVES
 #define TSAT_PKF_WAVES 2    /* three fit the LDS (-DTSAT_PK_LDS_BYTES=13568) but not the registers: 168 spill into the hot loops (measured 1.75x slower) */
 #endif
+#ifndef TSAT_PK_NAME
+#define TSAT_PK_NAME(base) base
+#endif
 #include <hip/hip_runtime.h>
 #include "tsat_packed.hpp"
 
 using namespace tsat;
 
 template <int INTEG, int DIAGJ, int ES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TSAT_PKF_WAVES, TSAT_PKF_WAVES))) void tsat_solve_kernel_packed_f32(KArgs<float> a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TSAT_PKF_WAVES, TSAT_PKF_WAVES))) void TSAT_PK_NAME(tsat_solve_kernel_packed_f32)(KArgs<float> a) {
   const int wave = blockIdx.x;
   if (wave * PK_G >= a.T) return;
   solve_group<float, INTEG, DIAGJ, ES>(a, wave);
 }
 
-hipError_t tsat_launch_solve_packed_f32(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream) {
+hipError_t TSAT_PK_NAME(tsat_launch_solve_packed_f32)(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream) {
   using kern_t = void (*)(KArgs<float>);
   static const kern_t variants[2][3][2] = {
-      {{tsat_solve_kernel_packed_f32<3, 0, 0>, tsat_solve_kernel_packed_f32<3, 0, 1>},
-       {tsat_solve_kernel_packed_f32<3, 1, 0>, tsat_solve_kernel_packed_f32<3, 1, 1>},
-       {tsat_solve_kernel_packed_f32<3, 2, 0>, tsat_solve_kernel_packed_f32<3, 2, 1>}},
-      {{tsat_solve_kernel_packed_f32<4, 0, 0>, tsat_solve_kernel_packed_f32<4, 0, 1>},
-       {tsat_solve_kernel_packed_f32<4, 1, 0>, tsat_solve_kernel_packed_f32<4, 1, 1>},
-       {tsat_solve_kernel_packed_f32<4, 2, 0>, tsat_solve_kernel_packed_f32<4, 2, 1>}}};
+      {{TSAT_PK_NAME(tsat_solve_kernel_packed_f32)<3, 0, 0>, TSAT_PK_NAME(tsat_solve_kernel_packed_f32)<3, 0, 1>},
+       {TSAT_PK_NAME(tsat_solve_kernel_packed_f32)<3, 1, 0>, TSAT_PK_NAME(tsat_solve_kernel_packed_f32)<3, 1, 1>},
+       {TSAT_PK_NAME(tsat_solve_kernel_packed_f32)<3, 2, 0>, TSAT_PK_NAME(tsat_solve_kernel_packed_f32)<3, 2, 1>}},
+      {{TSAT_PK_NAME(tsat_solve_kernel_packed_f32)<4, 0, 0>, TSAT_PK_NAME(tsat_solve_kernel_packed_f32)<4, 0, 1>},
+       {TSAT_PK_NAME(tsat_solve_kernel_packed_f32)<4, 1, 0>, TSAT_PK_NAME(tsat_solve_kernel_packed_f32)<4, 1, 1>},
+       {TSAT_PK_NAME(tsat_solve_kernel_packed_f32)<4, 2, 0>, TSAT_PK_NAME(tsat_solve_kernel_packed_f32)<4, 2, 1>}}};
   const unsigned waves = (unsigned)((a.T + PK_G - 1) / PK_G);
   KArgs<float> b = a;
   b.max_ls = a.max_ls < PK_STORE ? a.max_ls : PK_STORE;      // stored candidates per sweep, as in tsat_kernels_packed.hip

@@ -52,8 +52,9 @@ constexpr int PK_R_KD = 0, PK_R_LM = PK_R_KD + PK_G * PK_SKD, PK_R_XU = PK_R_LM 
 // copy instructions per region (64 units each)
 constexpr int PK_NI_KD = (PK_G * (PK_UKD + 1) + WAVE - 1) / WAVE, PK_NI_LM = (PK_G * (PK_ULM + 1) + WAVE - 1) / WAVE,
               PK_NI_XU = (PK_G * (PK_UXU + 1) + WAVE - 1) / WAVE, PK_NI_B = (PK_G * PK_BROWS * BROW_UNITS + WAVE - 1) / WAVE;
-// a region's last instruction may run past the region: the buffer keeps one instruction's worth of slack at its end
-static_assert(L_FWD + PK_NBUF * PK_FB + GLDS <= LDS_REALS, "packed forward buffers fit the wave's LDS block");
+// (the lanes of a region's last copy instruction that lie past the region never copy — their `lim` is NEVER — so a buffer
+// needs no slack behind it)
+static_assert(L_FWD + PK_NBUF * PK_FB <= LDS_REALS, "packed forward buffers fit the wave's LDS block");
 
 // ---- joint backward sweep: carve-up behind L_UNION (the forward chunk buffers overlay all of it between backward sweeps) -----
 // The PK_G trajectories of the wave run their backward sweeps TOGETHER, PK_CHG knots of each per chunk:
@@ -69,7 +70,9 @@ static_assert(L_FWD + PK_NBUF * PK_FB + GLDS <= LDS_REALS, "packed forward buffe
 #define TSAT_PK_CHG 4
 #endif
 constexpr int PK_CHG = TSAT_PK_CHG;               // knots per trajectory and backward chunk
-static_assert(PK_C == 16 && PK_CHG * 4 == PK_C, "Jacobian lanes: 16 lanes of a trajectory = PK_CHG knots x 4 column quarters");
+constexpr int PK_BC = 16;                         // lanes per trajectory in a backward pass
+constexpr int PK_BG = WAVE / PK_BC;               // trajectories per backward pass (4); a wave of PK_G trajectories takes PK_G / PK_BG passes
+static_assert(PK_G % PK_BG == 0 && PK_CHG * 4 == PK_BC, "Jacobian lanes: 16 lanes of a trajectory = PK_CHG knots x 4 column quarters");
 constexpr int PK_RECS = 83;                       // knot record: F = [A|B] column-major (70), lx (7), lu (3), luu (3); error-state
 constexpr int PK_R_QQ = 9 * FS;                   //   mode keeps G'QG (6) in F's column 9, which the reduction has vacated
 constexpr int PK_GTRW = 88;                       // per-trajectory constants: staged parameter record (76), nu (8), pad
@@ -80,11 +83,17 @@ constexpr int GX_QU = 36;                         //   Quu (0,0)(0,1)(0,2)(1,1)(
 constexpr int GX_XK = 46;                         //   per state column i: Qux(:,i) (3), K(:,i) (3)
 static_assert(GX_XK + 7 * 6 <= PK_GXW && PK_GXW % 2 == 0 && GX_XK % 2 == 0, "exchange block layout");
 constexpr int L_GTR = L_UNION;
-constexpr int L_GX = L_GTR + PK_G * PK_GTRW;
-constexpr int L_GREC = L_GX + PK_G * PK_GXW;
+constexpr int L_GX = L_GTR + PK_BG * PK_GTRW;
+constexpr int L_GREC = L_GX + PK_BG * PK_GXW;
 constexpr int PK_GRS = PK_CHG * PK_RECS;          // stride between the trajectories' record blocks (2656 B: 96 B past a multiple of
                                                   // 256 B, so the four trajectories' broadcast reads fall into different banks)
-static_assert(L_GREC + PK_G * PK_GRS <= LDS_REALS, "joint backward sweep fits the wave's LDS block");
+static_assert(L_GREC + PK_BG * PK_GRS <= LDS_REALS, "joint backward sweep fits the wave's LDS block");
+// hand-over between the trajectories' state lanes (PK_C per trajectory) and the lanes of a backward pass (PK_BC per trajectory),
+// in the part of the one-trajectory Riccati scratch the packed build does not use
+template <typename real> struct BwdIn { int N, need; real mu, rho; };
+template <typename real> struct BwdRes { acc_t dV1, dV2; int ok, pad; };
+constexpr int L_BWT = L_HXX;
+static_assert(L_BWT % 2 == 0, "hand-over tables are 8-byte aligned");
 // packed index of (i <= j) in an n x n upper triangle, row by row
 constexpr int sym_ut(int i, int j, int n) { return i * n - (i * (i - 1)) / 2 + (j - i); }
 
@@ -345,7 +354,7 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
 template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_PHASE void jacobian_group(const KArgs<real>& a, int traj0, int k0, bool need, int N, real mu) {
   real* lds = lds_base<real>();
-  const int lane = TSAT_LANE(), g = lane / PK_C, kk = (lane % PK_C) >> 2, qtr = lane & 3;
+  const int lane = TSAT_LANE(), g = lane / PK_BC, kk = (lane % PK_BC) >> 2, qtr = lane & 3;
   const int k = k0 + kk;
   const bool valid = need && k < N - 1;
   real* rc = lds + L_GREC + g * PK_GRS + kk * PK_RECS;
@@ -437,7 +446,7 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, int k0, boo
   constexpr int NC = NH + 3;
   constexpr int NP = NH * (NH + 1) / 2;
   real* lds = lds_base<real>();
-  const int lane = TSAT_LANE(), g = lane / PK_C, j = lane % PK_C;
+  const int lane = TSAT_LANE(), g = lane / PK_BC, j = lane % PK_BC;
   const int jc = (j < NC) ? j : NC - 1;          // lanes without a column compute on the last one and commit nothing
   const int jx = (j < NH) ? j : NH - 1;          // state column (clamped)
   const int jb = (j >= NH && j < NC) ? j - NH : 0;   // control column (clamped)
@@ -735,48 +744,62 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
   // a trajectory whose Quu_reg was not positive definite raises its rho and takes part in the next round.
   auto joint_backward = [&]() {
     constexpr int NH = BwdCfg<ES>::NH, NP = NH * (NH + 1) / 2;
+    BwdIn<real>* tin = reinterpret_cast<BwdIn<real>*>(lds + L_BWT);
+    BwdRes<real>* tres = reinterpret_cast<BwdRes<real>*>(tin + PK_G);
+    static_assert(L_BWT * sizeof(real) + PK_G * (sizeof(BwdIn<real>) + sizeof(BwdRes<real>)) <= L_UNION * sizeof(real), "hand-over tables fit");
+    const int bg = lane / PK_BC;                 // this lane's trajectory within a backward pass
     for (;;) {
       const bool need = mine.need_bwd != 0;
-      int* ng = reinterpret_cast<int*>(lds + L_RED);        // horizons of the trajectories that take part (0: does not)
       TSAT_SYNC_LDS();
-      if (myc == 0) ng[myg] = need ? mine.N : 0;
+      if (myc == 0) { tin[myg].N = mine.N; tin[myg].need = need ? 1 : 0; tin[myg].mu = mine.mu; tin[myg].rho = mine.rho; }
       TSAT_SYNC_LDS();
-      int nmax = 0, ngl[PK_G];
-      for (int g = 0; g < PK_G; ++g) { ngl[g] = ng[g]; nmax = (ngl[g] > nmax) ? ngl[g] : nmax; }
-      TSAT_SYNC_LDS();
-      if (nmax == 0) break;
-      // constants and terminal cost-to-go of every trajectory that takes part, into its blocks
-      for (int g = 0; g < ntr; ++g) {
-        if (ngl[g] == 0) continue;
-        const GState<real> u = gstate_bcast(mine, g * PK_C);
-        stage_for(g, u);
-        real* gt = lds + L_GTR + g * PK_GTRW;
-        for (int e = lane; e < PK_GT_NU + 8; e += WAVE) gt[e] = lds[L_TR + e];     // L_NU follows L_TR
-        const TSAT_GLOBAL real* XUg = (const TSAT_GLOBAL real*)(a.XU + (size_t)(traj0 + g) * xu_stride<real>(NS));
-        terminal_cost_to_go<real, ES>(XUg, u.N, u.mu, tmask);
-        TSAT_SYNC_LDS();
-        real* gx = lds + L_GX + g * PK_GXW;
-        for (int e = lane; e < NP + NH; e += WAVE) {
-          int i = NH, j = e - NP;
-          if (e < NP) pair_ut(e, NH, i, j);
-          gx[GX_S + e] = lds[L_ST + i * 9 + j];
+      int any = 0;
+      for (int g = 0; g < PK_G; ++g) any |= tin[g].need;
+      if (!any) break;
+      for (int t0 = 0; t0 < ntr; t0 += PK_BG) {      // a pass: trajectories t0 .. t0 + PK_BG - 1 of the wave
+        int nmax = 0;
+        for (int g = 0; g < PK_BG; ++g)
+          if (tin[t0 + g].need && tin[t0 + g].N > nmax) nmax = tin[t0 + g].N;
+        const BwdIn<real> in = tin[t0 + bg];
+        GBwd<real> bw;
+        bw.dV1 = 0; bw.dV2 = 0; bw.ok = 1;
+        if (nmax > 0) {
+          // constants and terminal cost-to-go of every trajectory that takes part, into its blocks
+          for (int g = 0; g < PK_BG && t0 + g < ntr; ++g) {
+            if (!tin[t0 + g].need) continue;
+            const GState<real> u = gstate_bcast(mine, (t0 + g) * PK_C);
+            stage_for(t0 + g, u);
+            real* gt = lds + L_GTR + g * PK_GTRW;
+            for (int e = lane; e < PK_GT_NU + 8; e += WAVE) gt[e] = lds[L_TR + e];     // L_NU follows L_TR
+            const TSAT_GLOBAL real* XUg = (const TSAT_GLOBAL real*)(a.XU + (size_t)(traj0 + t0 + g) * xu_stride<real>(NS));
+            terminal_cost_to_go<real, ES>(XUg, u.N, u.mu, tmask);
+            TSAT_SYNC_LDS();
+            real* gx = lds + L_GX + g * PK_GXW;
+            for (int e = lane; e < NP + NH; e += WAVE) {
+              int i = NH, j = e - NP;
+              if (e < NP) pair_ut(e, NH, i, j);
+              gx[GX_S + e] = lds[L_ST + i * 9 + j];
+            }
+            TSAT_SYNC_LDS();
+          }
+          const bool bneed = in.need != 0;
+          const int nch = (nmax - 1 + PK_CHG - 1) / PK_CHG;
+          for (int ch = nch - 1; ch >= 0; --ch) {
+            const int k0 = ch * PK_CHG;
+            const unsigned long long c0 = tick_();
+            jacobian_group<real, INTEG, DIAGJ, ES>(a, traj0 + t0, k0, bneed && bw.ok, in.N, in.mu);
+            TSAT_SYNC_LDS();
+            const unsigned long long c1 = tick_();
+            bw = riccati_group<real, NH>(a, traj0 + t0, k0, bneed, in.N, in.rho, bw.dV1, bw.dV2, bw.ok);
+            TSAT_SYNC_LDS();
+            pc_jac += c1 - c0; pc_ric += tick_() - c1;
+          }
         }
+        if (lane % PK_BC == 0) { tres[t0 + bg].dV1 = bw.dV1; tres[t0 + bg].dV2 = bw.dV2; tres[t0 + bg].ok = bw.ok; }
         TSAT_SYNC_LDS();
-      }
-      GBwd<real> bw;
-      bw.dV1 = 0; bw.dV2 = 0; bw.ok = 1;
-      const int nch = (nmax - 1 + PK_CHG - 1) / PK_CHG;
-      for (int ch = nch - 1; ch >= 0; --ch) {
-        const int k0 = ch * PK_CHG;
-        const unsigned long long t0 = tick_();
-        jacobian_group<real, INTEG, DIAGJ, ES>(a, traj0, k0, need && bw.ok, mine.N, mine.mu);
-        TSAT_SYNC_LDS();
-        const unsigned long long t1 = tick_();
-        bw = riccati_group<real, NH>(a, traj0, k0, need, mine.N, mine.rho, bw.dV1, bw.dV2, bw.ok);
-        TSAT_SYNC_LDS();
-        pc_jac += t1 - t0; pc_ric += tick_() - t1;
       }
       if (need) {
+        const BwdRes<real> bw = tres[myg];
         mine.n_backward++;
         if (bw.ok) {
           mine.dV1 = bw.dV1; mine.dV2 = bw.dV2;
