@@ -33,6 +33,9 @@ def _gpu(pkg, solver, b, o, variant=0):
 
 
 def _report(name, ref, got):
+    # the state box x in [-10, 10] of the reference's old-API scripts (src/monte_carlo.jl:180,186) is not modelled:
+    # on every trajectory of every BASELINE config it is nowhere near active — shown here, not argued
+    assert np.max(np.abs(got["X"])) < 1.5 and np.max(np.abs(ref["X"])) < 1.5, "state box |x| <= 10 would not be inactive"
     dX, dU = parity_errors(ref, got)
     print(f"[{name}] {len(dX)} trajectories: max|dX| {dX.max():.2e}, max|dU|/scale {dU.max():.2e}, "
           f"max|dU| {np.max(np.abs(ref['U'] - got['U'])):.2e}")

@@ -68,12 +68,19 @@ def test_trials_do_not_depend_on_chunking(pkg, ol):
     assert np.array_equal(one["slew_time"], whole["slew_time"]) and len(one["parts"]) == 2
 
 
-def test_result_files_round_trip(pkg, ol, tmp_path):
-    mc, rs = pkg.monte_carlo, pkg.results
+@pytest.mark.parametrize("fmt", ["h5", "npz"])
+def test_result_files_round_trip(pkg, ol, tmp_path, fmt):
+    """the script's file set (src/monte_carlo.jl:334-343): {n}_A.h5 and per trial states / control / B_N / t_total files, the
+    datasets named as there ("one_state" and "states" both hold sim_states[i]); HDF5 through the system's libhdf5"""
+    import shutil
+    import subprocess
+    mc, rs, h5 = pkg.monte_carlo, pkg.results, pkg.hdf5io
+    if fmt == "h5" and not h5.available():
+        pytest.skip("no libhdf5 in this image")
     out = mc.run_trials(OracleStages(ol), 21, 0, 2, small_setup(pkg))
-    files = rs.write_monte_carlo(str(tmp_path), out)
+    files = rs.write_monte_carlo(str(tmp_path), out, fmt=fmt)
     assert sorted(f.split("/")[-1] for f in files) == sorted(
-        ["2_A.npz"] + [f"2_{k}_{i}.npz" for k in ("states", "control", "B_N", "t_total") for i in (1, 2)])   # (:334-343)
+        [f"2_A.{fmt}"] + [f"2_{k}_{i}.{fmt}" for k in ("states", "control", "B_N", "t_total") for i in (1, 2)])   # (:334-343)
     back = rs.read_monte_carlo(str(tmp_path), 2)
     assert np.array_equal(back["A"], out["A"])
     for i in (1, 2):
@@ -81,6 +88,16 @@ def test_result_files_round_trip(pkg, ol, tmp_path):
         assert np.array_equal(back["control"][i], out["sim_control_inputs"][i - 1])
         assert np.array_equal(back["B_ECI"][i], out["B_ECI_total"][i - 1])
         assert np.array_equal(back["t_total"][i], out["t_total"][i - 1])
+    if fmt == "h5":
+        n1 = out["sim_states"][0].shape[1]
+        st = str(tmp_path / "2_states_1.h5")
+        # what HDF5.jl stores for the script's 7 x n array: an (n, 7) float64 dataset, under both names
+        assert h5.h5read(st, "states").shape == (n1, 7) and np.array_equal(h5.h5read(st, "one_state"), h5.h5read(st, "states"))
+        assert h5.h5read(str(tmp_path / "2_A.h5"), "A").shape == (6, 2)
+        dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if shutil.os.path.exists("/opt/conda/bin/h5dump") else None)
+        if dump:    # an independent reader of the format agrees
+            hdr = subprocess.run([dump, "-H", st], capture_output=True, text=True, check=True).stdout
+            assert 'DATASET "states"' in hdr and 'DATASET "one_state"' in hdr and "H5T_IEEE_F64LE" in hdr and f"( {n1}, 7 )" in hdr
 
 
 @pytest.mark.gpu

@@ -9,10 +9,11 @@ Only the hot path lives here: ``csrc/`` holds the hand-written H
   sweep       Monte-Carlo sharding over GPUs + RCCL all-gather (src/monte_carlo.jl:118-235)
   magnetic    orbit + IGRF-12 field tables (src/magnetic_toolbox.jl:33-106)
   horizon     Gramian-based horizon selection (src/magnetic_toolbox.jl:1-31)
-  monte_carlo the whole experiment of src/monte_carlo.jl:107-262 as a batch; results: its file set (:334-343)
+  monte_carlo the whole experiment of src/monte_carlo.jl:107-262 as a batch; results: its HDF5 file set (:334-343);
+              hdf5io: h5write / h5read over the system's libhdf5
   mpc         receding-horizon re-solve on the resident batch (BASELINE.json configs[4]; not in the reference)
   tracking    closed-loop TVLQR tracking + slew-time statistic (src/attitude_controller.jl:1-119)
 """
-from . import _abi, horizon, magnetic, monte_carlo, mpc, results, slew_setup, sweep, tracking, trajopt  # noqa: F401
+from . import _abi, hdf5io, horizon, magnetic, monte_carlo, mpc, results, slew_setup, sweep, tracking, trajopt  # noqa: F401
 
-__all__ = ["_abi", "horizon", "magnetic", "monte_carlo", "mpc", "results", "slew_setup", "sweep", "tracking", "trajopt"]
+__all__ = ["_abi", "hdf5io", "horizon", "magnetic", "monte_carlo", "mpc", "results", "slew_setup", "sweep", "tracking", "trajopt"]

@@ -445,12 +445,22 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, int k0, boo
   constexpr int ES = (NH == 6) ? 1 : 0;
   constexpr int NC = NH + 3;
   constexpr int NP = NH * (NH + 1) / 2;
+  constexpr int RMAX = (NH + 1) / 2;             // rows of the symmetric blocks a lane computes (the column's rows are split in two)
+  constexpr int GX_SINK = GX_S + NP + NH;        // a word of the exchange block nobody reads: target of the lanes without a role
+  static_assert(GX_SINK < GX_QU, "sink word inside the exchange block");
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE(), g = lane / PK_BC, j = lane % PK_BC;
-  const int jc = (j < NC) ? j : NC - 1;          // lanes without a column compute on the last one and commit nothing
-  const int jx = (j < NH) ? j : NH - 1;          // state column (clamped)
-  const int jb = (j >= NH && j < NC) ? j - NH : 0;   // control column (clamped)
-  const bool xlane = j < NH, ulane = j >= NH && j < NC;
+  // Lane roles. Lanes 0 .. NC-1 own the columns of F = [A|B] ("main" lanes: state columns j < NH, control columns after them).
+  // The symmetric blocks need rows i <= c of a state column c: the main lane takes the first (c + 2) / 2 of them and a HELPER
+  // lane (lanes NC .. : columns 1 .. NH-1) the rest — the helper repeats the main lane's W~ column and gain column (same
+  // operations on the same operands, for free: the lanes would idle otherwise) and contributes its rows of Qxx and of S.
+  const bool helper = j >= NC && (j - NC + 1) < NH;
+  const int col = (j < NC) ? j : (helper ? j - NC + 1 : NH - 1);     // column of F this lane works on
+  const bool xmain = j < NH, umain = j >= NH && j < NC;
+  const int cx = (col < NH) ? col : NH - 1;                          // state column (clamped on the control lanes)
+  const int jb = umain ? j - NH : 0;                                 // control column (clamped)
+  const int rmain = (cx + 2) / 2;
+  const int rlo = helper ? rmain : 0, rhi = helper ? cx + 1 : (xmain ? rmain : 0);
   real* gx = lds + L_GX + g * PK_GXW;
   const real* Qd = lds + L_GTR + g * PK_GTRW + P_QD;
   const real* recs = lds + L_GREC + g * PK_GRS;
@@ -458,19 +468,37 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, int k0, boo
   const int traj = (traj0 + g <= tmax) ? traj0 + g : tmax;
   TSAT_GLOBAL real* KDg = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * kd_stride<real>(a.N));
   bool ok = ok_in != 0;
+  // per row slot r of this lane: the row i = rlo + r, whether it is one of the lane's rows, where Qxx(i, col) starts from (the
+  // stage Hessian: diag(Qd); error-state mode: diag(Qd[0:3]) on the rates, G'QG of the knot record on the attitude block),
+  // and where S(i, col) goes
+  int ri[RMAX], qq_off[RMAX], s_off[RMAX];
+  bool rv[RMAX];
+  real qdiag[RMAX];
+  for (int r = 0; r < RMAX; ++r) {
+    const int i = (rlo + r < NH) ? rlo + r : NH - 1;
+    ri[r] = i;
+    rv[r] = rlo + r < rhi;
+    qdiag[r] = (i == cx && (!ES || i < 3)) ? Qd[i] : (real)0;
+    const int aa = i - 3, bb = cx - 3;
+    qq_off[r] = (ES && i >= 3 && cx >= i) ? PK_R_QQ + (aa == 0 ? bb : (aa == 1 ? 2 + bb : 5)) : -1;
+    s_off[r] = rv[r] ? GX_S + (i * NH - (i * (i - 1)) / 2 + (cx - i)) : GX_SINK;
+  }
+  // where the control lanes put Quu(a, jb), a <= jb, and Qu(jb)
+  int qu_off[3];
+  for (int aa = 0; aa < 3; ++aa) qu_off[aa] = (umain && aa <= jb) ? GX_QU + ((aa == 0) ? jb : (aa == 1 ? 2 + jb : 5)) : GX_SINK;
+  const int quu_off = umain ? GX_QU + 6 + jb : GX_SINK;
+  const int xk_off = xmain ? GX_XK + j * 6 : GX_SINK;
+  const int ss_off = xmain ? GX_S + NP + j : GX_SINK;
   real Ss[NP], sv[NH];
   for (int e = 0; e < NP; ++e) Ss[e] = gx[GX_S + e];
   for (int m = 0; m < NH; ++m) sv[m] = gx[GX_S + NP + m];
-  // Qxx(i, j) starts from the stage Hessian: diag(Qd) (error-state mode: diag(Qd[0:3]) on the rates, G'QG on the attitude block)
-  real qdiag[NH];
-  for (int i = 0; i < NH; ++i) qdiag[i] = (i == j && (!ES || i < 3)) ? Qd[i] : (real)0;
   for (int l = PK_CHG - 1; l >= 0; --l) {
     const int k = k0 + l;
     bool act = need && ok && k < N - 1;
     const real* rc = recs + l * PK_RECS;
-    // step 1: column jc of W~ = [S; s'] F
+    // step 1: column `col` of W~ = [S; s'] F
     real f[NH], W[NH + 1];
-    for (int m = 0; m < NH; ++m) f[m] = rc[jc * FS + m];
+    for (int m = 0; m < NH; ++m) f[m] = rc[col * FS + m];
     for (int r = 0; r < NH; ++r) {
       real acc = 0;
       for (int m = 0; m < NH; ++m) acc = fma_(Ss[(r <= m) ? sym_ut(r, m, NH) : sym_ut(m, r, NH)], f[m], acc);
@@ -481,25 +509,21 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, int k0, boo
       for (int m = 0; m < NH; ++m) acc = fma_(sv[m], f[m], acc);
       W[NH] = acc;
     }
-    // step 2: column jc of F'W~ — rows i < NH: Qxx(i, j) (used for i <= j); rows NH + a: Qux(a, j) on a state lane,
-    // Quu(a, b) (used for a <= b) on the control lane b; Qu(b) = lu + B(:, b)' s on the control lanes
-    real Q[NC];
-    for (int i = 0; i < NH; ++i) {
-      real ini = 0;
-      if (ES && i >= 3) {
-        const int aa = i - 3, bb = (jx >= 3) ? jx - 3 : 0;
-        const real qq = rc[PK_R_QQ + (aa == 0 ? bb : (aa == 1 ? 2 + bb : 5))];
-        ini = (jx >= i) ? qq : (real)0;
-      }
-      real acc = qdiag[i] + ini;
-      for (int m = 0; m < NH; ++m) acc = fma_(rc[i * FS + m], W[m], acc);
-      Q[i] = acc;
+    // step 2: this lane's rows of column `col` of F'W~ — Qxx(i, col) for its row slots; rows NH + a: Qux(a, col) on a state
+    // column, Quu(a, b) (used for a <= b) on the control lane b; Qu(b) = lu + B(:, b)' s on the control lanes
+    real Qx[RMAX], Qh[3];
+    for (int r = 0; r < RMAX; ++r) {
+      const real ini = rc[(qq_off[r] >= 0) ? qq_off[r] : R_LUU];        // (a finite word of the record when there is no G'QG term)
+      real acc = qdiag[r] + ((qq_off[r] >= 0) ? ini : (real)0);
+      const real* fi = rc + ri[r] * FS;
+      for (int m = 0; m < NH; ++m) acc = fma_(fi[m], W[m], acc);
+      Qx[r] = acc;
     }
     for (int aa = 0; aa < 3; ++aa) {
       const real luu = rc[R_LUU + aa];
-      real acc = (real)0 + ((ulane && jb == aa) ? luu : (real)0);
+      real acc = (real)0 + ((umain && jb == aa) ? luu : (real)0);
       for (int m = 0; m < NH; ++m) acc = fma_(rc[(NH + aa) * FS + m], W[m], acc);
-      Q[NH + aa] = acc;
+      Qh[aa] = acc;
     }
     real Qu;
     {
@@ -507,13 +531,10 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, int k0, boo
       for (int m = 0; m < NH; ++m) acc = fma_(f[m], sv[m], acc);
       Qu = acc;
     }
-    if (act && ulane) {
-      for (int aa = 0; aa < 3; ++aa)
-        if (aa <= jb) gx[GX_QU + ((aa == 0) ? jb : (aa == 1 ? 2 + jb : 5))] = Q[NH + aa];
-      gx[GX_QU + 6 + jb] = Qu;
-    }
+    for (int aa = 0; aa < 3; ++aa) role_store(gx, act ? qu_off[aa] : GX_SINK, GX_SINK, Qh[aa]);
+    role_store(gx, act ? quu_off : GX_SINK, GX_SINK, Qu);
     TSAT_SYNC_LDS();
-    // step 3: regularise, PD test (Sylvester), adjugate inverse, K(:, j) = -Quu_reg^-1 Qux(:, j), d = -Quu_reg^-1 Qu
+    // step 3: regularise, PD test (Sylvester), adjugate inverse, K(:, col) = -Quu_reg^-1 Qux(:, col), d = -Quu_reg^-1 Qu
     real Kc[3], d[3], qu[3];
     {
       const real h00 = gx[GX_QU + 0], h01 = gx[GX_QU + 1], h02 = gx[GX_QU + 2], h11 = gx[GX_QU + 3], h12 = gx[GX_QU + 4],
@@ -530,68 +551,57 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, int k0, boo
       const real det = dot3_(q00, c00, q10, c01, q20, c02);
       const bool pd = (q00 > 0 && c22 > 0 && det > 0);
       const real nid = -rcp_(det);
-      const real h0 = Q[NH + 0], h1 = Q[NH + 1], h2 = Q[NH + 2];
       for (int aa = 0; aa < 3; ++aa) {
         const real Qi0 = ((aa == 0) ? c00 : (aa == 1 ? c01 : c02)) * nid;
         const real Qi1 = ((aa == 0) ? c01 : (aa == 1 ? c11 : c12)) * nid;
         const real Qi2 = ((aa == 0) ? c02 : (aa == 1 ? c12 : c22)) * nid;
-        Kc[aa] = dot3_(Qi0, h0, Qi1, h1, Qi2, h2);
+        Kc[aa] = dot3_(Qi0, Qh[0], Qi1, Qh[1], Qi2, Qh[2]);
         d[aa] = dot3_(Qi0, qu[0], Qi1, qu[1], Qi2, qu[2]);
       }
-      if (act) {
-        if (xlane) {
-          for (int c = 0; c < 3; ++c) { gx[GX_XK + j * 6 + c] = Q[NH + c]; gx[GX_XK + j * 6 + 3 + c] = Kc[c]; }
+      const int xo = act ? xk_off : GX_SINK;
+      for (int c = 0; c < 3; ++c) { role_store(gx, (xo == GX_SINK) ? GX_SINK : xo + c, GX_SINK, Qh[c]); role_store(gx, (xo == GX_SINK) ? GX_SINK : xo + 3 + c, GX_SINK, Kc[c]); }
+      // K,d record of the knot: lanes 0..6 their gain column (zero beyond NH), lane 7 the feed-forward; stays in flight
+      if (act && j < 8)
+        for (int c = 0; c < 3; ++c) {
+          const real v = (j < NH) ? Kc[c] : ((j == 7) ? d[c] : (real)0);
+          KDg[(size_t)k * KDW + ((j < 7) ? (c * 7 + j) : (21 + c))] = v;
         }
-        // K,d record of the knot: lanes 0..6 their gain column (zero beyond NH), lane 7 the feed-forward; stays in flight
-        if (j < 8)
-          for (int c = 0; c < 3; ++c) {
-            const real v = (j < NH) ? Kc[c] : ((j == 7) ? d[c] : (real)0);
-            KDg[(size_t)k * KDW + ((j < 7) ? (c * 7 + j) : (21 + c))] = v;
-          }
-        if (!pd) ok = false;
-      }
+      ok = ok && (!act || pd);
       act = act && ok;
     }
     TSAT_SYNC_LDS();
     // step 4: cost-to-go. With K = -Quu_reg^-1 Qux: Sxx = Qxx + sym(Qux'K) - rho K'K ; Sx = Qx + sym(Qux'd, Qu'K) - rho K'd
     {
       const real dqu = dot3_(d[0], qu[0], d[1], qu[1], d[2], qu[2]);
-      if (act) {
-        dV1 += (acc_t)dqu;
-        dV2 -= (acc_t)((real)0.5 * fma_(rho, dot3_(d[0], d[0], d[1], d[1], d[2], d[2]), dqu));
-      }
+      dV1 += act ? (acc_t)dqu : (acc_t)0;
+      dV2 -= act ? (acc_t)((real)0.5 * fma_(rho, dot3_(d[0], d[0], d[1], d[1], d[2], d[2]), dqu)) : (acc_t)0;
       const real* xk = gx + GX_XK;
-      real hj[3], kj[3];
-      for (int c = 0; c < 3; ++c) { hj[c] = Q[NH + c]; kj[c] = Kc[c]; }
-      real Sn[NH];
-      for (int i = 0; i < NH; ++i) {
+      real Sn[RMAX];
+      for (int r = 0; r < RMAX; ++r) {
         real hi[3], ki[3];
-        for (int c = 0; c < 3; ++c) { hi[c] = xk[i * 6 + c]; ki[c] = xk[i * 6 + 3 + c]; }
-        real acc = Q[i] + (real)0;
+        for (int c = 0; c < 3; ++c) { hi[c] = xk[ri[r] * 6 + c]; ki[c] = xk[ri[r] * 6 + 3 + c]; }
+        real acc = Qx[r] + (real)0;
         real sy = 0, kk = 0;
         for (int c = 0; c < 3; ++c) {
-          sy += fma_(hi[c], kj[c], hj[c] * ki[c]);
-          kk = fma_(ki[c], kj[c], kk);
+          sy += fma_(hi[c], Kc[c], Qh[c] * ki[c]);
+          kk = fma_(ki[c], Kc[c], kk);
         }
         acc += dmm_((real)0.5, sy, rho, kk);
-        Sn[i] = acc;
+        Sn[r] = acc;
       }
       real sn;
-      {   // s(j): the same formula with "column 7": hi = Qux(:, j), hj = Qu, ki = K(:, j), kj = d
-        real acc = rc[R_LX + jx] + W[NH];
+      {   // s(col): the same formula with "column 7": hi = Qux(:, col), hj = Qu, ki = K(:, col), kj = d
+        real acc = rc[R_LX + cx] + W[NH];
         real sy = 0, kk = 0;
         for (int c = 0; c < 3; ++c) {
-          sy += fma_(hj[c], d[c], qu[c] * kj[c]);
-          kk = fma_(kj[c], d[c], kk);
+          sy += fma_(Qh[c], d[c], qu[c] * Kc[c]);
+          kk = fma_(Kc[c], d[c], kk);
         }
         acc += dmm_((real)0.5, sy, rho, kk);
         sn = acc;
       }
-      if (act && xlane) {
-        for (int i = 0; i < NH; ++i)
-          if (i <= j) gx[GX_S + sym_ut(i, (j < NH ? j : NH - 1), NH)] = Sn[i];
-        gx[GX_S + NP + j] = sn;
-      }
+      for (int r = 0; r < RMAX; ++r) role_store(gx, act ? s_off[r] : GX_SINK, GX_SINK, Sn[r]);
+      role_store(gx, act ? ss_off : GX_SINK, GX_SINK, sn);
     }
     TSAT_SYNC_LDS();
     for (int e = 0; e < NP; ++e) Ss[e] = gx[GX_S + e];

@@ -176,7 +176,7 @@ def run_trials(stages, seed, lo, hi, setup=None, keep_trajectories=True):
     out["fails"][sel] = tv["stats"]["failed"]
     out["solve_stats"], out["tracking_stats"] = res["stats"], tv["stats"]
     if keep_trajectories:
-        k = lambda a, j, n: np.ascontiguousarray(a[j, :n].T)
+        k = lambda a, j, n: a[j, :n].T      # Julia-shaped views (7 x n_i, 3 x (n_i - 1)) of the batch arrays, no copies
         out["t_total"] = [s.t0 + s.dt * np.arange(n) for n in n_knots]
         out["states"] = [k(res["X"], j, n) for j, n in enumerate(n_knots)]
         out["control_inputs"] = [k(res["U"], j, n - 1) for j, n in enumerate(n_knots)]
