@@ -330,6 +330,11 @@ typedef struct tsat_btable_options {
 } tsat_btable_options;
 
 void tsat_btable_default_options(tsat_btable_options* o);
+/* Resident field tables: with Btab = NULL, tsat_btable_batch leaves its tables on the device ([T][2 n_half][3], in the handle's
+ * workspace) instead of downloading them; tsat_horizon_batch with Btab = NULL (same T, n_rows = 2 n_half) reads them there,
+ * and tsat_batch_upload with Btab = NULL (n_btab = T, n_tab <= 2 n_half, btab_idx = NULL or identity) packs their first n_tab
+ * rows into the solver's tables device to device — the Monte-Carlo's chain magnetic_simulation -> condition_based_time ->
+ * magnetic_simulation -> solve! (src/monte_carlo.jl:134-196) without a table crossing PCIe. */
 int  tsat_btable_batch(tsat_handle* h, const tsat_btable_options* o, int64_t T, const double* kep, const double* t0,
                        const double* tf, double* Btab, double* pos);
 

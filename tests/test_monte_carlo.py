@@ -119,3 +119,24 @@ def test_gpu_experiment_matches_oracle_experiment(pkg, ol):
         assert np.max(np.abs(got["sim_states"][j] - ref["sim_states"][j])) < 1e-7
     assert np.array_equal(got["fails"], ref["fails"]) and np.array_equal(got["slew_time"], ref["slew_time"])
     solver.close()
+
+
+@pytest.mark.gpu
+def test_gpu_resident_tables_are_the_downloaded_ones(pkg, ol):
+    """field tables left on the device between the stages (Btab = NULL through the ABI) give the run the host round trip gives"""
+    mc, to = pkg.monte_carlo, pkg.trajopt
+    s = small_setup(pkg)
+    solver = to.AugmentedLagrangianSolver(None, None)
+
+    class HostTables(mc.GpuStages):
+        resident_tables = False
+
+    a = mc.run_trials(mc.GpuStages(solver), 5, 0, 5, s)
+    b = mc.run_trials(HostTables(solver), 5, 0, 5, s)
+    c = mc.run_trials(mc.GpuStages(solver), 5, 0, 5, s, keep_trajectories=False)
+    for k in ("tf_index", "n_knots", "slew_time", "fails"):
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
+    for j in range(len(a["selected"])):
+        assert np.array_equal(a["states"][j], b["states"][j]) and np.array_equal(a["sim_states"][j], b["sim_states"][j])
+        assert np.array_equal(a["B_ECI_total"][j], b["B_ECI_total"][j])
+    solver.close()

@@ -70,6 +70,16 @@ __global__ __launch_bounds__(256) void tsat_narrow_kernel(int64_t n, const doubl
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) dst[e] = (float)src[e];
 }
+// resident field tables [T][rows][3] (tsat_btable_batch) -> the solver's padded tables [T][n_tab][4], first n_tab rows
+__global__ __launch_bounds__(256) void tsat_pack_tables_kernel(int64_t n, int rows, int n_tab, const double* B, double* BT) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int64_t t = e / n_tab;
+  const int r = (int)(e - t * n_tab);
+  const double* src = B + ((size_t)t * rows + r) * 3;
+  double* dst = BT + (size_t)e * 4;
+  dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = 0.0;
+}
 __global__ __launch_bounds__(256) void tsat_widen_records_kernel(int64_t n_rec, int N, const float* XU32, double* XU64) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_rec) return;
@@ -117,6 +127,8 @@ struct tsat_handle {
   float *P32 = nullptr, *BT32 = nullptr, *U032 = nullptr;
   bool f32_ready = false;
   int solved_precision = 64;
+  int64_t bt_T = 0;      // field tables left on the device by the last tsat_btable_batch: [bt_T][bt_rows][3] in slot WS_BT_B
+  int bt_rows = 0;
   // grow-only device workspaces of the stages around the solve (tracking, horizon, field tables, MPC history, export):
   // allocated on first use and kept for the life of the handle, so repeated calls pay no hipMalloc / hipFree
   enum { WS_TV_NZ, WS_TV_KD, WS_TV_XS, WS_TV_NID, WS_TV_ST, WS_TV_P, WS_TVB_P, WS_TVB_BT, WS_TVB_XUR, WS_TVB_BI, WS_TVB_NK,
@@ -280,8 +292,11 @@ int tsat_batch_upload(tsat_handle* h, const double* x0, const double* xf, const 
                       const double* ulo, const double* uhi, const double* U0) {
   if (!h) return -1;
   if (h->T < 1) return fail(h, -1, "tsat_batch_reserve has not been called");
-  if (!x0 || !xf || !Btab || !tau0 || !dtau || !dt || !Jmat || !Qd || !Qfd || !Rd || !ulo || !uhi || !U0)
+  if (!x0 || !xf || !tau0 || !dtau || !dt || !Jmat || !Qd || !Qfd || !Rd || !ulo || !uhi || !U0)
     return fail(h, -1, "null input array");
+  if (!Btab && (h->bt_T != h->T || h->n_btab != h->T || h->n_tab > h->bt_rows))
+    return fail(h, -1, "Btab is NULL but the field tables left by the last tsat_btable_batch do not cover this batch "
+                       "(need one table per trajectory, n_btab = T, and n_tab <= its 2 n_half rows)");
   if (!btab_idx && h->n_btab != h->T) return fail(h, -1, "btab_idx is NULL but n_btab != T");
   TSAT_HIP(h, hipSetDevice(h->dev));
   const int64_t T = h->T;
@@ -294,11 +309,21 @@ int tsat_batch_upload(tsat_handle* h, const double* x0, const double* xf, const 
   const std::string bad = check_inputs(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi);
   if (!bad.empty()) return fail(h, -1, bad);
   h->inertia_class = inertia_class(T, Jmat);
-  std::vector<double> P((size_t)T * PSTRIDE), BT((size_t)h->n_btab * h->n_tab * 4);
+  std::vector<double> P((size_t)T * PSTRIDE);
   pack_params<double>(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, P.data());
-  pack_btab<double>(h->n_btab, h->n_tab, Btab, BT.data());
   TSAT_HIP(h, hipMemcpy(h->P, P.data(), P.size() * sizeof(double), hipMemcpyHostToDevice));
-  TSAT_HIP(h, hipMemcpy(h->BT, BT.data(), BT.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (Btab) {
+    std::vector<double> BT((size_t)h->n_btab * h->n_tab * 4);
+    pack_btab<double>(h->n_btab, h->n_tab, Btab, BT.data());
+    TSAT_HIP(h, hipMemcpy(h->BT, BT.data(), BT.size() * sizeof(double), hipMemcpyHostToDevice));
+  } else {   // device to device: the tables tsat_btable_batch left in its workspace, padded to the solver's row layout
+    const int64_t n = T * (int64_t)h->n_tab;
+    const double* B = (const double*)ws_get(h, tsat_handle::WS_BT_B, (size_t)h->bt_T * h->bt_rows * 3 * 8);
+    if (!B) return fail(h, -10, "resident field tables are gone");
+    hipLaunchKernelGGL(tsat_pack_tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, n, h->bt_rows, h->n_tab, B, h->BT);
+    TSAT_HIP(h, hipGetLastError());
+    TSAT_HIP(h, hipStreamSynchronize(h->stream));
+  }
   TSAT_HIP(h, hipMemcpy(h->bidx, bi.data(), bi.size() * sizeof(int), hipMemcpyHostToDevice));
   TSAT_HIP(h, hipMemcpy(h->U0, U0, (size_t)T * (h->N - 1) * 3 * sizeof(double), hipMemcpyHostToDevice));
   h->hx0.assign(x0, x0 + 7 * T); h->hxf.assign(xf, xf + 7 * T); h->htau0.assign(tau0, tau0 + T);
@@ -686,17 +711,22 @@ int tsat_horizon_batch(tsat_handle* h, int64_t T, int32_t n_rows, const double* 
                        const double* cutoff, int32_t* tf_index, double* cond_at) {
   if (!h) return -1;
   if (T < 1 || n_rows < 1) return fail(h, -1, "bad dimensions");
-  if (!Btab || !dt_row || !cutoff || !tf_index) return fail(h, -1, "null array");
+  if (!dt_row || !cutoff || !tf_index) return fail(h, -1, "null array");
+  if (!Btab && (h->bt_T != T || h->bt_rows != n_rows))
+    return fail(h, -1, "Btab is NULL but the field tables left by the last tsat_btable_batch are not T x n_rows");
   TSAT_HIP(h, hipSetDevice(h->dev));
   const size_t Tn = (size_t)T, nB = Tn * (size_t)n_rows * 3;
   double *dB = nullptr, *ddt = nullptr, *dcut = nullptr, *dc = nullptr;
   int* di = nullptr;
   int rc = 0;
   auto A = [&](void** p, int slot, size_t bytes) { if (!rc && !(*p = ws_get(h, slot, bytes))) rc = -10; };
-  A((void**)&dB, tsat_handle::WS_HZ_B, nB * 8); A((void**)&ddt, tsat_handle::WS_HZ_DT, Tn * 8); A((void**)&dcut, tsat_handle::WS_HZ_CUT, Tn * 8);
+  if (Btab) A((void**)&dB, tsat_handle::WS_HZ_B, nB * 8);
+  else dB = (double*)ws_get(h, tsat_handle::WS_BT_B, nB * 8);       // same size as allocated: the resident tables themselves
+  A((void**)&ddt, tsat_handle::WS_HZ_DT, Tn * 8); A((void**)&dcut, tsat_handle::WS_HZ_CUT, Tn * 8);
   A((void**)&dc, tsat_handle::WS_HZ_C, Tn * 8); A((void**)&di, tsat_handle::WS_HZ_I, Tn * sizeof(int));
   auto Cp = [&](void* d, const void* s, size_t bytes) { if (!rc && hipMemcpy(d, s, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = -10; };
-  Cp(dB, Btab, nB * 8); Cp(ddt, dt_row, Tn * 8); Cp(dcut, cutoff, Tn * 8);
+  if (Btab) Cp(dB, Btab, nB * 8);
+  Cp(ddt, dt_row, Tn * 8); Cp(dcut, cutoff, Tn * 8);
   if (!rc) {
     HzArgs<double> a;
     a.T = (int)T; a.n_rows = n_rows; a.BT = dB; a.dt_row = ddt; a.cutoff = dcut; a.tf_index = di; a.cond_at = dc;
@@ -849,7 +879,7 @@ int tsat_btable_batch(tsat_handle* h, const tsat_btable_options* o, int64_t T, c
   if (!h || !o) return -1;
   if (T < 1 || o->n_half < 1) return fail(h, -1, "bad dimensions");
   if (!(o->date >= 2015.0 && o->date < 2020.0)) return fail(h, -1, "date must be in [2015, 2020): IGRF-12 epoch 2015 + secular variation");
-  if (!kep || !t0 || !tf || !Btab) return fail(h, -1, "null array");
+  if (!kep || !t0 || !tf) return fail(h, -1, "null array");
   for (int64_t t = 0; t < T; ++t)
     if (!(kep[6 * t] >= 0.0 && kep[6 * t] < 1.0) || !(kep[6 * t + 1] > 0.0) || !(tf[t] > t0[t]))
       return fail(h, -1, "need 0 <= e < 1, a > 0 and tf > t0");
@@ -873,9 +903,10 @@ int tsat_btable_batch(tsat_handle* h, const tsat_btable_options* o, int64_t T, c
     hipLaunchKernelGGL(tsat_btable_kernel<double>, dim3((unsigned)T), dim3(64), 0, h->stream, a);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) rc = -10;
   }
-  if (!rc && hipMemcpy(Btab, dB, nB * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
+  if (!rc && Btab && hipMemcpy(Btab, dB, nB * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (!rc && pos && hipMemcpy(pos, dP, nP * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = -10;
   if (rc) h->err = "device allocation, copy or launch failed in tsat_btable_batch";
+  h->bt_T = rc ? 0 : T; h->bt_rows = rc ? 0 : 2 * N;     // the tables stay resident for tsat_horizon_batch / tsat_batch_upload
   return rc;
 }
 

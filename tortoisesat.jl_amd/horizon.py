@@ -13,14 +13,18 @@ import numpy as np
 from . import _abi
 
 
-def condition_based_time(solver, Btab, dt_row, cutoff):
+def condition_based_time(solver, Btab, dt_row, cutoff, resident_shape=None):
     """Btab (T, n_rows, 3) coarse field tables, dt_row / cutoff scalars or (T,). Returns (tf_index (T,) 1-based with 0 =
-    never below the cutoff, cond_at (T,))."""
+    never below the cutoff, cond_at (T,)). ``Btab = None`` with ``resident_shape = (T, n_rows)``: the tables the last
+    ``magnetic_simulation(..., host=False)`` left on the device."""
     lib = _abi.load()
-    Btab = np.ascontiguousarray(Btab, dtype=np.float64)
-    if Btab.ndim != 3 or Btab.shape[2] != 3:
-        raise ValueError("Btab must be (T, n_rows, 3)")
-    T, n = Btab.shape[0], Btab.shape[1]
+    if Btab is None:
+        T, n = int(resident_shape[0]), int(resident_shape[1])
+    else:
+        Btab = np.ascontiguousarray(Btab, dtype=np.float64)
+        if Btab.ndim != 3 or Btab.shape[2] != 3:
+            raise ValueError("Btab must be (T, n_rows, 3)")
+        T, n = Btab.shape[0], Btab.shape[1]
     dt_row = np.ascontiguousarray(np.broadcast_to(np.asarray(dt_row, dtype=np.float64), (T,)))
     cutoff = np.ascontiguousarray(np.broadcast_to(np.asarray(cutoff, dtype=np.float64), (T,)))
     idx = np.zeros(T, dtype=np.int32)

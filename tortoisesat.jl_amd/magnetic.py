@@ -13,9 +13,11 @@ from . import _abi
 
 
 def magnetic_simulation(solver, kep, t0, tf, N, mjd=58155.0, gm=3.986004418e5, alt=400.0, R_E=6371.0, date=2019.0,
-                        want_pos=True):
+                        want_pos=True, host=True):
     """kep (T,6) = [e, a (km), i, RAAN, argp, anomaly] in degrees (src/TortoiseSat.jl:35-42); t0, tf scalars or (T,).
-    Returns (B_ECI (T, 2N, 3) Tesla, pos (T, 2N+1, 3) km or None)."""
+    Returns (B_ECI (T, 2N, 3) Tesla, pos (T, 2N+1, 3) km or None). ``host=False``: the tables are not downloaded (B_ECI is
+    None) — they stay on the device, where ``horizon.condition_based_time(solver, None, ...)`` and an upload of a batch with
+    ``Btab = None`` pick them up (the Monte-Carlo's tables never cross PCIe unless the caller wants to keep them)."""
     lib = _abi.load()
     kep = np.ascontiguousarray(np.atleast_2d(kep), dtype=np.float64)
     if kep.shape[1] != 6:
@@ -26,7 +28,7 @@ def magnetic_simulation(solver, kep, t0, tf, N, mjd=58155.0, gm=3.986004418e5, a
     o = _abi.BtableOptions()
     lib.tsat_btable_default_options(C.byref(o))
     o.n_half, o.mjd, o.gm, o.r_igrf_km, o.date = int(N), float(mjd), float(gm), float(alt + R_E), float(date)
-    B = np.empty((T, 2 * N, 3))
+    B = np.empty((T, 2 * N, 3)) if host else None
     pos = np.empty((T, 2 * N + 1, 3)) if want_pos else None
     rc = lib.tsat_btable_batch(solver._h, C.byref(o), T, _abi.as_dp(kep), _abi.as_dp(t0), _abi.as_dp(tf), _abi.as_dp(B),
                                _abi.as_dp(pos))

@@ -59,26 +59,30 @@ class MonteCarloSetup:
 class GpuStages:
     """The four numeric stages through the C ABI; tests substitute the oracle's by passing another object."""
 
+    resident_tables = True    # field tables stay on the device between the stages (run_trials asks with host=False)
+
     def __init__(self, solver):
         self.solver = solver
+        self._resident_shape = None
 
-    def magnetic_simulation(self, kep, t0, tf, N, s):
+    def magnetic_simulation(self, kep, t0, tf, N, s, host=True):
+        self._resident_shape = (len(kep), 2 * N)
         return mg.magnetic_simulation(self.solver, kep, t0, tf, N, mjd=s.mjd, gm=s.GM, alt=s.alt, R_E=s.R_E, date=s.igrf_date,
-                                      want_pos=False)[0]
+                                      want_pos=False, host=host)[0]
 
     def condition_based_time(self, B, dt_row, cutoff):
-        return hz.condition_based_time(self.solver, B, dt_row, cutoff)[0]
+        return hz.condition_based_time(self.solver, B, dt_row, cutoff, resident_shape=self._resident_shape)[0]
 
-    def solve(self, batch, s):
+    def solve(self, batch, s, want_trajectories=True):
         opts = to.AugmentedLagrangianSolverOptions()
         opts.iterations, opts.opts_uncon.iterations, opts.opts_uncon.dJ_counter_limit = s.outer, s.inner, s.dJ_counter_limit
         self.solver.opts = opts
-        return to.solve_(to.BatchProblem.from_arrays(batch, error_state=1), self.solver, want_K=False)
+        return to.solve_(to.BatchProblem.from_arrays(batch, error_state=1), self.solver, want_K=False, want_trajectories=want_trajectories)
 
-    def attitude_simulation(self, batch, X, U, x0_sim, Qd, Qfd, Rd, noise_seed, noise_ids, s):
+    def attitude_simulation(self, batch, X, U, x0_sim, Qd, Qfd, Rd, noise_seed, noise_ids, s, want_trajectories=True):
         # the batch just solved is still resident: its trajectories and tables do not travel again
         return tr.attitude_simulation(self.solver, batch, None, None, x0_sim, Qd, Qfd, Rd, noise_seed=noise_seed, noise_ids=noise_ids,
-                                      w_tol=s.w_tol, angle_tol=s.angle_tol, want_K=False)
+                                      w_tol=s.w_tol, angle_tol=s.angle_tol, want_K=False, want_trajectories=want_trajectories)
 
 
 def trial_rng(seed, i):
@@ -104,7 +108,7 @@ def knot_counts(t_final, t0, dt):
     return (np.floor(q * (1.0 + 8.0 * np.finfo(np.float64).eps) + 1e-12).astype(np.int64) + 1).astype(np.int32)
 
 
-def build_batch(ids, t_final, B_fine, seed, s):
+def build_batch(ids, t_final, B_fine, seed, s, table_rows=None):
     """Guess, weights and the ragged batch of trials `ids` (global indices) whose horizon was found
     (src/monte_carlo.jl:145-193)."""
     T = len(ids)
@@ -126,10 +130,11 @@ def build_batch(ids, t_final, B_fine, seed, s):
     c = np.ascontiguousarray
     # the table has 2N rows over 2 t_final (src/magnetic_toolbox.jl:73); the solve reads rows 0 .. N (+ the stage rows of
     # the last step), so only those travel to the solver
-    n_rows = min(B_fine.shape[1], s.N + 8)
+    # (B_fine None: the tables are on the device, `table_rows` rows each, and the upload packs them there)
+    n_rows = min(B_fine.shape[1] if B_fine is not None else int(table_rows), s.N + 8)
     assert np.all((n_knots.astype(np.float64) - 1.0) * s.dt * rows_per_s < n_rows - 1)     # last row any RK stage reads
-    B_fine = B_fine[:, :n_rows]
-    b = SlewBatch(N=N, n_tab=B_fine.shape[1], x0=c(np.tile(x0, (T, 1))), xf=c(np.tile(xf, (T, 1))), Btab=c(B_fine),
+    b = SlewBatch(N=N, n_tab=n_rows, x0=c(np.tile(x0, (T, 1))), xf=c(np.tile(xf, (T, 1))),
+                  Btab=c(B_fine[:, :n_rows]) if B_fine is not None else None,
                   btab_idx=np.arange(T, dtype=np.int32), tau0=np.zeros(T), dtau=c(s.dt * rows_per_s), dt=np.full(T, s.dt),
                   Jmat=c(np.tile(jmat_cm(J), (T, 1))), Qd=Qd, Qfd=Qfd, Rd=Rd, ulo=np.full((T, 3), -s.u_bnd),
                   uhi=np.full((T, 3), s.u_bnd), U0=U0)
@@ -155,7 +160,8 @@ def run_trials(stages, seed, lo, hi, setup=None, keep_trajectories=True):
     s = setup or MonteCarloSetup()
     A = draw_orbits(seed, lo, hi, s)
     T = hi - lo
-    B_init = stages.magnetic_simulation(A, s.t0, s.tf, s.N, s)                               # (:134)
+    resident = bool(getattr(stages, "resident_tables", False))      # GPU stages: tables stay on the device between the calls
+    B_init = stages.magnetic_simulation(A, s.t0, s.tf, s.N, s, host=False) if resident else stages.magnetic_simulation(A, s.t0, s.tf, s.N, s)   # (:134)
     idx = stages.condition_based_time(B_init, (s.tf - s.t0) / s.N, s.cutoff)                  # (:137-140)
     t_final = idx.astype(np.float64) * (s.tf - s.t0) / s.N
     found = (idx > 0) & (t_final - s.t0 >= 2 * s.dt)
@@ -165,12 +171,18 @@ def run_trials(stages, seed, lo, hi, setup=None, keep_trajectories=True):
     if len(sel) == 0:
         return out
     ids = lo + sel
-    B_fine = stages.magnetic_simulation(A[sel], s.t0, t_final[sel], s.N, s)                  # (:149)
-    batch, n_knots = build_batch(ids, t_final[sel], B_fine, seed, s)
-    res = stages.solve(batch, s)
+    if resident:     # (:149) the script keeps B_ECI_total: downloaded once if the caller keeps trajectories, never uploaded again
+        B_fine = stages.magnetic_simulation(A[sel], s.t0, t_final[sel], s.N, s, host=keep_trajectories)
+        batch, n_knots = build_batch(ids, t_final[sel], None, seed, s, table_rows=2 * s.N)
+    else:
+        B_fine = stages.magnetic_simulation(A[sel], s.t0, t_final[sel], s.N, s)
+        batch, n_knots = build_batch(ids, t_final[sel], B_fine, seed, s)
+    # summaries only (keep_trajectories = False) on resident stages: neither the solved nor the tracked trajectories come back
+    kw = {} if (keep_trajectories or not resident) else dict(want_trajectories=False)
+    res = stages.solve(batch, s, **kw)
     Qd, Qfd, Rd = tr.tvlqr_weights(batch.T, s.lqr_alpha, s.lqr_beta, s.lqr_r)
     x0s = draw_tracking_inputs(batch, ids, seed)
-    tv = stages.attitude_simulation(batch, res["X"], res["U"], x0s, Qd, Qfd, Rd, int(seed), ids.astype(np.int64), s)
+    tv = stages.attitude_simulation(batch, res["X"], res["U"], x0s, Qd, Qfd, Rd, int(seed), ids.astype(np.int64), s, **kw)
     out["n_knots"][sel] = n_knots
     out["slew_time"][sel] = tv["stats"]["slew_time"]
     out["fails"][sel] = tv["stats"]["failed"]

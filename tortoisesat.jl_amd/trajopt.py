@@ -269,7 +269,9 @@ class AugmentedLagrangianSolver:
 
     # ---- resident-batch API -------------------------------------------------------------------
     def upload(self, batch: SlewBatch, max_linesearch):
-        self._check(self._lib.tsat_batch_reserve(self._h, batch.T, batch.N, batch.n_tab, batch.Btab.shape[0],
+        # batch.Btab is None: one table per trajectory, left on the device by the last tsat_btable_batch (magnetic.py, host=False)
+        n_btab = batch.T if batch.Btab is None else batch.Btab.shape[0]
+        self._check(self._lib.tsat_batch_reserve(self._h, batch.T, batch.N, batch.n_tab, n_btab,
                                                  max_linesearch), "tsat_batch_reserve")
         d = _abi.as_dp
         self._check(self._lib.tsat_batch_upload(
@@ -287,9 +289,10 @@ class AugmentedLagrangianSolver:
         self.last_kernel_ms = float(ms.value)
         return self.last_kernel_ms
 
-    def download(self, want_K=True):
+    def download(self, want_K=True, want_trajectories=True):
         T, N = self._shape
-        X = np.empty((T, N, 7)); U = np.empty((T, N - 1, 3))
+        X = np.empty((T, N, 7)) if want_trajectories else None      # None: the statistics only, the batch stays on the device
+        U = np.empty((T, N - 1, 3)) if want_trajectories else None
         K = np.empty((T, N - 1, 7, 3)) if want_K else None
         stats = np.zeros(T, dtype=_abi.STATS_DTYPE)
         self._check(self._lib.tsat_batch_download(self._h, _abi.as_dp(X), _abi.as_dp(U), _abi.as_dp(K),
@@ -436,7 +439,7 @@ class BatchProblem:
         return self
 
 
-def solve_(prob, solver, want_K=True):
+def solve_(prob, solver, want_K=True, want_trajectories=True):
     """solve!(prob, solver) (src/TortoiseSat.jl:199). ``prob`` may be a Problem or a BatchProblem.
 
     Mutates the problem(s): ``.X`` (7,N), ``.U`` (3,N-1), ``.K`` (3,7,N-1), ``.stats``; returns the raw result
@@ -446,8 +449,8 @@ def solve_(prob, solver, want_K=True):
     o = solver.opts.to_abi(b.N, b.n_tab, batch.integrator, batch.terminal_mask, error_state=batch.error_state)
     solver.upload(b, o.max_linesearch)
     solver.run(o)
-    res = solver.download(want_K=want_K)
-    if batch.problems is not None:
+    res = solver.download(want_K=want_K, want_trajectories=want_trajectories)
+    if batch.problems is not None and want_trajectories:
         for t, p in enumerate(batch.problems):
             p.X = np.ascontiguousarray(res["X"][t, : p.N].T)
             p.U = np.ascontiguousarray(res["U"][t, : p.N - 1].T)
