@@ -20,7 +20,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pipeline" -o run -
 cd "$ROOT"
 python3 tools/phase_profile.py > "$OUT/phase_clocks.txt" 2> "$OUT/phase_clocks.err"
 python3 tools/monte_carlo_timing.py 1024 1024 > "$OUT/monte_carlo.txt" 2> "$OUT/monte_carlo.err"
-python3 tools/large_batch.py > "$OUT/large_batch.txt" 2> "$OUT/large_batch.err"
+TSAT_VARIANTS=2,3,4 python3 tools/large_batch.py > "$OUT/large_batch.txt" 2> "$OUT/large_batch.err"
+python3 tools/threshold_timing.py > "$OUT/build_by_batch_size.txt" 2> "$OUT/build_by_batch_size.err"
+python3 tools/fp32_eval.py 16384 512 > "$OUT/fp32_eval.txt" 2> "$OUT/fp32_eval.err"
 { python3 tools/mpc_timing.py 512 500; python3 tools/mpc_timing.py 4096 200; } > "$OUT/mpc_timing.txt" 2> "$OUT/mpc_timing.err"
 # larger configurations on this one GPU: configs[2] shape in fp64 (packed build) and as quoted (fp32), a configs[3] shard of
 # 8192 trajectories per GPU (what each of 8 GPUs gets), configs[4]; kernel statistics and PMC passes of the fp64 16384 run
@@ -36,4 +38,6 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY
   --output-format csv -d "$OUT/pmc_sq_c2" -o run -- $C2 > /dev/null 2> "$OUT/pmc_sq_c2.err"
 cd "$ROOT"
 TSAT_PK_G=4 python3 tools/phase_profile.py 16384 1000 3 1 > "$OUT/phase_clocks_packed.txt" 2> "$OUT/phase_clocks_packed.err"
+TSAT_PK_G=8 python3 tools/phase_profile.py 16384 1000 4 1 > "$OUT/phase_clocks_packed8.txt" 2> "$OUT/phase_clocks_packed8.err"
+python3 tools/phase_profile.py 16384 1000 2 1 > "$OUT/phase_clocks_dense.txt" 2> "$OUT/phase_clocks_dense.err"
 echo done

@@ -21,7 +21,8 @@ print(f"workload {T} x 1000 knots built in {time.time()-t0:.1f} s", flush=True)
 o = opts.to_abi(b.N, b.n_tab, 3, error_state=1)
 s.upload(b, o.max_linesearch)
 res = {}
-for name, prec, var in (("fp64 auto", 64, 0), ("fp32 layout 2 waves/SIMD", 32, 12), ("fp32 layout 3 waves/SIMD", 32, 13), ("fp32 layout 4 waves/SIMD", 32, 14)):
+for name, prec, var in (("fp64 auto", 64, 0), ("fp32 auto (packed, 8 per wave)", 32, 0), ("fp32 packed, 4 per wave", 32, 3), ("fp32 one trajectory per wave, 2 waves/SIMD", 32, 12),
+                        ("fp32 one trajectory per wave, 4 waves/SIMD", 32, 14)):
     o.precision = prec
     s.set_kernel_variant(var)
     ms = [s.run(o) for _ in range(3)][1:]

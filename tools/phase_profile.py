@@ -31,7 +31,7 @@ solver.set_kernel_variant(variant)
 solver.upload(b, o.max_linesearch); solver.trace(1)
 ms = solver.run(o); ms = solver.run(o)
 tr = solver.trace_download()[:, 0, :]
-if variant == 3 or (variant == 0 and T >= 8192):   # the packed build stamps one row per wavefront (its first trajectory): sums over
+if variant in (3, 4) or (variant == 0 and T >= 3072):   # the packed builds stamp one row per wavefront (its first trajectory): sums over
     tr = tr[::int(os.environ.get("TSAT_PK_G", "4"))]   # its PK_G trajectories
 print(f"T = {T}, variant {variant}, error_state {es}: {len(tr)} stamped wavefronts")
 it = tr[:, 4]; nb = tr[:, 5]

@@ -22,6 +22,7 @@ def one(pattern):
 
 def counters(d):
     acc, n = {}, {}
+    kern = None
     with open(one(f"{d}/**/*counter_collection.csv")) as f:
         for r in csv.DictReader(f):
             if "tsat_solve_kernel" not in r["Kernel_Name"]:
@@ -37,7 +38,10 @@ shutil.copy(os.path.join(src, "bench_n1.json"), os.path.join(dst, "bench_n1_fina
 shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(dst, "kernel_stats_bench_steps5_final.csv"))
 shutil.copy(one("pipeline/**/*kernel_stats.csv"), os.path.join(dst, "kernel_stats_pipeline.csv"))
 for a, b in (("phase_clocks.txt", "phase_clocks_final.txt"), ("pipeline.log", "pipeline_wall.txt"),
-             ("monte_carlo.txt", "monte_carlo_wall.txt"), ("large_batch.txt", "large_batch.txt"), ("mpc_timing.txt", "mpc_timing.txt"), ("stats.json", "bench_under_rocprof.json")):
+             ("monte_carlo.txt", "monte_carlo_wall.txt"), ("large_batch.txt", "large_batch.txt"), ("mpc_timing.txt", "mpc_timing.txt"), ("stats.json", "bench_under_rocprof.json"),
+             ("build_by_batch_size.txt", "build_by_batch_size.txt"), ("fp32_eval.txt", "fp32_eval.txt"), ("phase_clocks_packed.txt", "phase_clocks_packed.txt"),
+             ("phase_clocks_packed8.txt", "phase_clocks_packed8.txt"), ("phase_clocks_dense.txt", "phase_clocks_dense.txt"),
+             ("bench_c2_fp64.json", "bench_c2_fp64.json"), ("bench_c2_fp32.json", "bench_c2_fp32.json"), ("bench_c4.json", "bench_c4.json")):
     if not os.path.exists(os.path.join(src, a)):
         continue
     with open(os.path.join(src, a)) as f:
@@ -63,3 +67,27 @@ out = {
 with open(os.path.join(root, "profiles", "pmc_summary.json"), "w") as f:
     json.dump(out, f, indent=1)
 print(json.dumps(out, indent=1))
+
+# the same counters for the fp64 run of configs[2] (16384 x 1000, the packed build), when collected
+if glob.glob(os.path.join(src, "pmc_fetch_c2", "**", "*counter_collection.csv"), recursive=True):
+    shutil.copy(one("stats_c2/**/*kernel_stats.csv"), os.path.join(dst, "kernel_stats_c2_fp64.csv"))
+    b2 = json.loads(open(os.path.join(src, "bench_c2_fp64.json")).read().strip().splitlines()[-1])
+    fe, kern = counters("pmc_fetch_c2")
+    wr, _ = counters("pmc_write_c2")
+    sq, _ = counters("pmc_sq_c2")
+    rd_raw, wr_b = fe["FETCH_SIZE"] * 1024.0, wr["WRITE_SIZE"] * 1024.0
+    ms = b2["roofline"]["kernel_ms"]
+    out2 = {
+        "kernel": kern, "workload": b2["config"]["workload"], "bench_config": 2, "kernel_source_sha256_16": kernel_source_hash(),
+        "kernel_ms": ms, "FETCH_SIZE_KB": fe["FETCH_SIZE"], "WRITE_SIZE_KB": wr["WRITE_SIZE"],
+        "read_bytes_raw": rd_raw, "read_bytes_x2": 2 * rd_raw, "write_bytes": wr_b,
+        "hbm_bytes_per_launch": 2 * rd_raw + wr_b, "hbm_bytes_per_launch_lower": rd_raw + wr_b,
+        "algorithmic_bytes_per_launch": b2["roofline"]["algorithmic_bytes_per_launch"],
+        "hbm_GBs_upper": (2 * rd_raw + wr_b) / (ms * 1e-3) / 1e9,
+        "valu_issue_frac_of_4_cycle_peak": sq["SQ_INSTS_VALU"] / (1024 * 2.4e9 * ms * 1e-3 / 4.0),
+        "note": "as pmc_summary.json; valu_issue_frac: SQ_INSTS_VALU against one VALU instruction per 4 cycles on each of the 1024 SIMDs at 2.4 GHz",
+        "sq": sq,
+    }
+    with open(os.path.join(root, "profiles", "pmc_summary_c2.json"), "w") as f:
+        json.dump(out2, f, indent=1)
+    print(json.dumps(out2, indent=1))
