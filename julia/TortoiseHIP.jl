@@ -250,6 +250,29 @@ function receding_horizon!(s::HIPSolver, p::BatchProblem, n_steps::Integer; plan
     return Xh, Uh
 end
 
+# ---- sweep exchange across GPUs (include/tortoise_hip.h: tsat_comm_*, tsat_sweep_allgather) ----------------------------------
+# One process per GPU (e.g. Distributed.jl workers or MPI ranks), each with its own HIPSolver and an equal shard of the sweep.
+# Rank 0 makes the 128-byte communicator id and sends it to the others by whatever the host uses; after solve! every rank calls
+# sweep_allgather and receives everybody's X (7 x N x world*T), U (3 x (N-1) x world*T) and stats in rank order — the result
+# lists the reference's serial loop appends to (src/monte_carlo.jl:52-66, 199-235), assembled by one RCCL all-gather over xGMI.
+const COMM_ID_BYTES = 128
+function comm_unique_id()
+    id = zeros(UInt8, COMM_ID_BYTES)
+    rc = ccall((:tsat_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id)
+    rc == 0 || error("tsat_comm_unique_id failed ($rc): is librccl.so.1 loadable?")
+    return id
+end
+comm_init(s::HIPSolver, id::Vector{UInt8}, rank::Integer, world::Integer) =
+    check(s, ccall((:tsat_comm_init, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), s.handle, id, rank, world), "tsat_comm_init")
+function sweep_allgather(s::HIPSolver, p::BatchProblem, world::Integer)
+    T, N = size(p.x0, 2), p.N
+    X = zeros(7, N, world * T); U = zeros(3, N - 1, world * T); st = Vector{Stats}(undef, world * T)
+    check(s, ccall((:tsat_sweep_allgather, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Stats}, Int32),
+                   s.handle, X, U, st, 0), "tsat_sweep_allgather")
+    return X, U, st
+end
+comm_destroy(s::HIPSolver) = check(s, ccall((:tsat_comm_destroy, LIB), Cint, (Ptr{Cvoid},), s.handle), "tsat_comm_destroy")
+
 """
 write_results(dir, n, A, sim_states, sim_control_inputs, B_ECI_total, t_total) — the files of src/monte_carlo.jl:334-343
 (`{n}_A.h5` "A"; per trial `{n}_states_{i}.h5` "states", `{n}_control_{i}.h5` "control", `{n}_B_N_{i}.h5` "B_ECI",
@@ -259,6 +282,7 @@ function write_results(dir, n, A, sim_states, sim_control_inputs, B_ECI_total, t
     HDF5 = Base.require(Base.PkgId(Base.UUID("f67ccb44-e63f-5c2f-98bd-6dc0ccc4ba2f"), "HDF5"))
     HDF5.h5write(joinpath(dir, "$(n)_A.h5"), "A", A)
     for i in eachindex(sim_states)
+        HDF5.h5write(joinpath(dir, "$(n)_states_$(i).h5"), "one_state", sim_states[i])      # the script writes both names (:338-339)
         HDF5.h5write(joinpath(dir, "$(n)_states_$(i).h5"), "states", sim_states[i])
         HDF5.h5write(joinpath(dir, "$(n)_control_$(i).h5"), "control", sim_control_inputs[i])
         HDF5.h5write(joinpath(dir, "$(n)_B_N_$(i).h5"), "B_ECI", B_ECI_total[i])

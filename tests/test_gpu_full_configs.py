@@ -4,7 +4,7 @@ trajectory of each batch, in every build of the solve kernel that the size selec
 
   configs[1]  1024 x 1000 knots, 5 x 10, one orbit      hooks off (registered API) and on (src/monte_carlo.jl:158)
   configs[2]  random orbit per trajectory, 1000 knots   fp64 inputs here; the fp32 build is tested in test_gpu_fp32.py
-  configs[3]  inclination-sweep slice, 1000 knots, 3 x 50, own table per trajectory, the large-batch build
+  configs[3]  inclination-sweep slice, 1000 knots, 3 x 50, own table per trajectory, the large-batch builds
   configs[4]  512 x 200-knot horizon x 1000 control steps: properties on all, oracle loop on a sub-sample
 """
 import numpy as np
@@ -57,7 +57,7 @@ def test_gpu_configs2_inputs_fp64(pkg, ol, solver):
     b = pkg.magnetic.attach_igrf_tables(solver, pkg.slew_setup.workload_monte_carlo(T=512, N=1000, seed=20190531, random_orbit=True, tables=False))
     o = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, error_state=1)
     ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False)
-    for variant in (1, 2):
+    for variant in (1, 2, 3, 4):          # wide, dense, packed (the automatic choice from 3072 trajectories on), packed8 (from 16384)
         got = _gpu(pkg, solver, b, o, variant)
         _report(f"configs[2] inputs fp64, build {variant}", ref, got)
         assert_same_solution(ref, got)
@@ -68,9 +68,10 @@ def test_gpu_configs3_slice_large_batch_build(pkg, ol, solver):
     b = pkg.slew_setup.workload_inclination_sweep(T=1024, N=1000, j0=20000)
     o = oracle_options(ol, max_outer=3, max_inner=50, dj_counter_limit=1)
     ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False)
-    got = _gpu(pkg, solver, b, o, variant=2)
-    _report("configs[3] slice, dense build", ref, got)
-    assert_same_solution(ref, got)
+    for variant, name in ((2, "dense"), (3, "packed: what an 8192-trajectory shard takes")):
+        got = _gpu(pkg, solver, b, o, variant=variant)
+        _report(f"configs[3] slice, {name}", ref, got)
+        assert_same_solution(ref, got)
 
 
 def test_gpu_configs4_shard(pkg, ol):
