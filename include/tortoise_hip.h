@@ -330,6 +330,17 @@ typedef struct tsat_btable_options {
 } tsat_btable_options;
 
 void tsat_btable_default_options(tsat_btable_options* o);
+/* ------------------------------------------------------------------------------------------------------------
+ * Script arithmetic of the Monte-Carlo loop body, batched on the host (no GPU work): Bryson weights of the versine eigen-axis
+ * guess (src/eigen_axis_slew.jl:1-38; Q = alpha / w_max^2, Qf = 10 Q, R = 1 / m_max^2 with the SIGNED maximum torque of the
+ * guess as written, src/monte_carlo.jl:165-176) for T slews between the same two attitudes that differ only in their horizon
+ * t = t0 : dt : t0 + (n_knots[t] - 1) dt. theta_f = rotation angle and axis(3) = rotation axis of the slew (computed once by
+ * the caller), Jrm = inertia, row-major 3 x 3. Outputs Qd 7 x T, Qfd 7 x T, Rd 3 x T. Returns -2 when a guess is degenerate
+ * (no positive torque sample), -1 on bad arguments (n_knots >= 3).
+ * ------------------------------------------------------------------------------------------------------------ */
+int  tsat_bryson_eigen_axis_batch(int64_t T, const int32_t* n_knots, double t0, double dt, double theta_f, const double* axis,
+                                  const double* Jrm, double alpha, double beta, double* Qd, double* Qfd, double* Rd);
+
 /* Resident field tables: with Btab = NULL, tsat_btable_batch leaves its tables on the device ([T][2 n_half][3], in the handle's
  * workspace) instead of downloading them; tsat_horizon_batch with Btab = NULL (same T, n_rows = 2 n_half) reads them there,
  * and tsat_batch_upload with Btab = NULL (n_btab = T, n_tab <= 2 n_half, btab_idx = NULL or identity) packs their first n_tab

@@ -149,3 +149,22 @@ def test_batch_of_problems_with_different_horizons_is_ragged(pkg):
     assert bp.arrays.N == 80 and list(bp.arrays.n_knots) == [80, 50]
     assert bp.arrays.U0.shape == (2, 79, 3) and np.all(bp.arrays.U0[1, 49:] == 0) and np.all(bp.arrays.U0[1, :49] == 1e-3)
     assert to.BatchProblem(probs[:1]).arrays.n_knots is None
+
+
+def test_batched_bryson_weights_equal_the_per_trial_functions(pkg):
+    """tsat_bryson_eigen_axis_batch (the Monte-Carlo's per-trial guess + weights, src/monte_carlo.jl:161-176, as one host call)
+    against eigen_axis_slew + bryson_weights trial by trial: the same formulas, equal to rounding"""
+    ss = pkg.slew_setup
+    x0 = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
+    xf = np.array([0.0, 0.0, 0.0, np.sqrt(2.0) / 2.0, np.sqrt(2.0) / 2.0, 0.0, 0.0])
+    n = np.r_[5, 6, 7, 13, 797, 3130, np.random.default_rng(3).integers(20, 3131, size=90)]
+    for name, J in ss.INERTIA.items():
+        Qd, Qfd, Rd = ss.bryson_weights_ragged(x0, xf, n, 0.0, 0.2, J, 0.1, 1e3)
+        for j, k in enumerate(n):
+            q, qf, r = ss.bryson_weights(ss.eigen_axis_slew(x0, xf, 0.2 * np.arange(k), rates_only=True)[0], J, 0.2, 0.1, 1e3)
+            np.testing.assert_allclose(Qd[j], q, rtol=1e-13); np.testing.assert_allclose(Qfd[j], qf, rtol=1e-13)
+            np.testing.assert_allclose(Rd[j], r, rtol=1e-12)
+    with pytest.raises(ValueError):
+        ss.bryson_weights_ragged(x0, xf, [2, 40], 0.0, 0.2, ss.INERTIA["1U"], 0.1, 1e3)
+    with pytest.raises(ValueError):
+        ss.bryson_weights_ragged(x0, x0, [40], 0.0, 0.2, ss.INERTIA["1U"], 0.1, 1e3)

@@ -105,6 +105,8 @@ PROTOTYPES = {
     "tsat_sweep_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "tsat_comm_destroy": (C.c_int, [C.c_void_p]),
     "tsat_btable_default_options": (None, [C.POINTER(BtableOptions)]),
+    "tsat_bryson_eigen_axis_batch": (C.c_int, [C.c_int64, _ip, C.c_double, C.c_double, C.c_double, _dp, _dp, C.c_double, C.c_double,
+                                               _dp, _dp, _dp]),
     "tsat_btable_batch": (C.c_int, [C.c_void_p, C.POINTER(BtableOptions), C.c_int64, _dp, _dp, _dp, _dp, _dp]),
     "tsat_horizon_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _dp, _dp, _dp, _ip, _dp]),
     "tsat_tvlqr_default_options": (None, [C.POINTER(TvlqrOptions)]),

@@ -3,6 +3,9 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared tsat_kernels.hip -o libtortoise_hip.so
 // One wavefront (a 64-thread workgroup) owns one trajectory for the whole AL-iLQR solve; see tsat_device.hpp.
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <cmath>
+#include <thread>
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes only: the library is dlopen'ed on first use (tsat_comm_*), never linked
 #include <cstdio>
@@ -872,6 +875,49 @@ void tsat_btable_default_options(tsat_btable_options* o) {
   o->gm = 3.986004418e14 * 1e-9;             // km^3/s^2, src/input_parameters.jl:26
   o->r_igrf_km = 400.0 + 6371.0;             // alt + R_E, src/magnetic_toolbox.jl:44,81
   o->date = 2019.0;                          // src/magnetic_toolbox.jl:81
+}
+
+// Host-side script arithmetic, batched: Bryson weights of the versine eigen-axis guess for T slews that differ only in their
+// horizon (src/eigen_axis_slew.jl:1-38 + src/monte_carlo.jl:161-176 in the loop body of the Monte-Carlo script). No GPU work.
+int tsat_bryson_eigen_axis_batch(int64_t T, const int32_t* n_knots, double t0, double dt, double theta_f, const double* axis,
+                                 const double* Jrm, double alpha, double beta, double* Qd, double* Qfd, double* Rd) {
+  if (T < 1 || !n_knots || !axis || !Jrm || !Qd || !Qfd || !Rd || !(dt > 0)) return -1;
+  for (int64_t t = 0; t < T; ++t)
+    if (n_knots[t] < 3) return -1;
+  std::atomic<int> bad{0};
+  auto work = [&](int64_t lo, int64_t hi) {
+    std::vector<double> d;
+    for (int64_t j = lo; j < hi; ++j) {
+      const int n = n_knots[j];
+      const double a = 3.14159265358979323846 / (t0 + dt * (double)(n - 1));        // alpha = pi / t[end]
+      const double h = (t0 + dt * 1.0) - (t0 + dt * 0.0);                             // t[2] - t[1]
+      d.resize((size_t)n - 1);
+      double th0 = theta_f * 0.5 * (1.0 - std::cos(a * (t0 + dt * 0.0)));
+      for (int k = 0; k < n - 1; ++k) {                                              // d_theta = diff(theta) / (t[2] - t[1])
+        const double th1 = theta_f * 0.5 * (1.0 - std::cos(a * (t0 + dt * (double)(k + 1))));
+        d[(size_t)k] = (th1 - th0) / h;
+        th0 = th1;
+      }
+      double wmax = 0.0, taumax = -1.0 / 0.0;
+      for (int k = 0; k < n - 1; ++k)
+        for (int c = 0; c < 3; ++c) wmax = std::max(wmax, std::fabs(d[(size_t)k] * axis[c]));
+      // w has n rows (the last rate repeated): diff(w) has n - 1 rows, the last one zero; tau = J dw / dt, signed maximum
+      for (int k = 0; k < n - 1; ++k) {
+        double dw[3];
+        for (int c = 0; c < 3; ++c) dw[c] = (k < n - 2) ? d[(size_t)k + 1] * axis[c] - d[(size_t)k] * axis[c] : 0.0;
+        for (int r = 0; r < 3; ++r) taumax = std::max(taumax, ((Jrm[3 * r] * dw[0] + Jrm[3 * r + 1] * dw[1]) + Jrm[3 * r + 2] * dw[2]) / dt);
+      }
+      if (!(wmax > 0.0) || !(taumax > 0.0)) { bad = 1; continue; }
+      const double mmax = taumax / 1.0e-5 * 1.0e2;
+      for (int i = 0; i < 7; ++i) { Qd[7 * j + i] = (i < 3) ? alpha / (wmax * wmax) : alpha * beta; Qfd[7 * j + i] = 10.0 * Qd[7 * j + i]; }
+      for (int c = 0; c < 3; ++c) Rd[3 * j + c] = 1.0 / (mmax * mmax);
+    }
+  };
+  const int nth = (int)std::min<int64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), (T + 63) / 64);
+  std::vector<std::thread> th;
+  for (int i = 0; i < nth; ++i) th.emplace_back(work, T * i / nth, T * (i + 1) / nth);
+  for (auto& x : th) x.join();
+  return bad ? -2 : 0;
 }
 
 int tsat_btable_batch(tsat_handle* h, const tsat_btable_options* o, int64_t T, const double* kep, const double* t0,

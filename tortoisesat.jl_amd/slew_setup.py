@@ -115,6 +115,34 @@ def bryson_weights(w_guess, J, dt, alpha, beta, degenerate_rd=None):
     return Qd, Qfd, Rd
 
 
+def bryson_weights_ragged(x0, xf, n_knots, t0, dt, J, alpha, beta):
+    """(Qd (T,7), Qfd (T,7), Rd (T,3)) of T slews between the same attitudes whose eigen-axis guesses differ only in the
+    horizon: what ``bryson_weights(eigen_axis_slew(x0, xf, t0 + dt*arange(n), rates_only=True)[0], J, dt, alpha, beta)`` gives
+    for every n of ``n_knots`` (src/monte_carlo.jl:161-176 in the loop body), computed by the library's batched host routine
+    ``tsat_bryson_eigen_axis_batch`` instead of one Python iteration per trial (same formulas; equal to the per-trial functions
+    to rounding — tests/test_host.py)."""
+    import ctypes as C
+
+    from . import _abi
+    x0 = np.asarray(x0, dtype=np.float64); xf = np.asarray(xf, dtype=np.float64)
+    q_e = qmult(xf[3:7], x0[3:7])                                  # as eigen_axis_slew: the script's line 16, literally
+    theta_f = 2.0 * np.arccos(np.clip(q_e[0], -1.0, 1.0))
+    if not np.sin(theta_f / 2.0) > 0.0:
+        raise ValueError("eigen_axis_slew: zero-angle slew (q0 and qf coincide): the guess has no rotation axis")
+    axis = np.ascontiguousarray(-q_e[1:4] / np.sin(theta_f / 2.0))
+    nk = np.ascontiguousarray(n_knots, dtype=np.int32)
+    T = nk.shape[0]
+    Qd = np.empty((T, 7)); Qfd = np.empty((T, 7)); Rd = np.empty((T, 3))
+    Jrm = np.ascontiguousarray(np.asarray(J, dtype=np.float64).reshape(9))
+    rc = _abi.load().tsat_bryson_eigen_axis_batch(T, _abi.as_ip(nk), float(t0), float(dt), float(theta_f), _abi.as_dp(axis),
+                                                  _abi.as_dp(Jrm), float(alpha), float(beta), _abi.as_dp(Qd), _abi.as_dp(Qfd), _abi.as_dp(Rd))
+    if rc == -2:
+        raise ValueError("bryson_weights: a guess has no positive torque sample (tau_max <= 0): R = 1/m_max^2 is undefined")
+    if rc:
+        raise ValueError("tsat_bryson_eigen_axis_batch: bad arguments (every horizon needs at least three knots)")
+    return Qd, Qfd, Rd
+
+
 # --------------------------------------------------------------------------------------------------
 # synthetic B tables (SURVEY.md §8d: tilted-dipole surrogate until the IGRF row §8f-1 exists)
 # --------------------------------------------------------------------------------------------------
