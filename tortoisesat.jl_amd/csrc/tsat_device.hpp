@@ -557,58 +557,113 @@ TSAT_DEV void rk_step(const Traj<real>& tr, const real x[7], const real u[3], co
   }
 }
 
-// discrete Jacobians of one RK step, column by column, written to LDS record `F` (column stride 8).
-// Equivalent of ForwardDiff.jacobian! over the discretised dynamics (src/attitude_controller.jl:95-119).
-// Columns c_lo .. c_hi - 1 only (each column is its own tangent pass, so splitting the columns over lanes — the packed
-// build's Jacobian lanes, tsat_packed.hpp — leaves every column's arithmetic untouched).
+// discrete Jacobians of one RK step, column by column, written to LDS record `F` (column stride FS).
+// Equivalent of ForwardDiff.jacobian! over the discretised dynamics (src/attitude_controller.jl:95-119): the primal stages
+// once (rk_primal), then one tangent pass through the stages per column (rk_tangent) — each column is its own pass, so
+// splitting the columns over lanes (the packed build's Jacobian lanes, tsat_packed.hpp) leaves every column's arithmetic
+// untouched.
+template <typename real> struct RkStages { StageBase<real> s1, s2, s3, s4; real us[3]; };
+template <typename real, int INTEG, int DIAGJ>
+TSAT_DEV void rk_primal(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3], const real b1[3],
+                        const real b2[3], RkStages<real>& st) {
+  for (int a = 0; a < 3; ++a) st.us[a] = u[a] * tr.us;
+  real k1[7], k2[7], k3[7], t[7];
+  dyn_h<real, DIAGJ>(tr, x, st.us, b0, k1, st.s1);
+  for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k1[i];
+  dyn_h<real, DIAGJ>(tr, t, st.us, b1, k2, st.s2);
+  if (INTEG == 3) {
+    for (int i = 0; i < 7; ++i) t[i] = x[i] - k1[i] + 2 * k2[i];
+    dyn_h<real, DIAGJ>(tr, t, st.us, b2, k3, st.s3);
+  } else {
+    for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k2[i];
+    dyn_h<real, DIAGJ>(tr, t, st.us, b1, k3, st.s3);
+    for (int i = 0; i < 7; ++i) t[i] = x[i] + k3[i];
+    real k4[7];
+    dyn_h<real, DIAGJ>(tr, t, st.us, b2, k4, st.s4);
+  }
+}
+// directional derivative of the RK step along (ex, du): out = ex + (weighted sum of the stage tangents)
+template <typename real, int INTEG, int DIAGJ>
+TSAT_DEV void rk_tangent(const Traj<real>& tr, const RkStages<real>& st, const real b0[3], const real b1[3], const real b2[3],
+                         const real ex[7], const real du[3], real out[7]) {
+  real v1[7], v2[7], v3[7], arg[7];
+  dyn_h_jvp<real, DIAGJ>(tr, st.s1, st.us, b0, ex, du, v1);
+  for (int i = 0; i < 7; ++i) arg[i] = ex[i] + (real)0.5 * v1[i];
+  dyn_h_jvp<real, DIAGJ>(tr, st.s2, st.us, b1, arg, du, v2);
+  if (INTEG == 3) {
+    for (int i = 0; i < 7; ++i) arg[i] = ex[i] - v1[i] + 2 * v2[i];
+    dyn_h_jvp<real, DIAGJ>(tr, st.s3, st.us, b2, arg, du, v3);
+    for (int i = 0; i < 7; ++i) out[i] = ex[i] + (v1[i] + 4 * v2[i] + v3[i]) * (real)(1.0 / 6.0);
+  } else {
+    real v4[7];
+    for (int i = 0; i < 7; ++i) arg[i] = ex[i] + (real)0.5 * v2[i];
+    dyn_h_jvp<real, DIAGJ>(tr, st.s3, st.us, b1, arg, du, v3);
+    for (int i = 0; i < 7; ++i) arg[i] = ex[i] + v3[i];
+    dyn_h_jvp<real, DIAGJ>(tr, st.s4, st.us, b2, arg, du, v4);
+    for (int i = 0; i < 7; ++i) out[i] = ex[i] + (v1[i] + 2 * v2[i] + 2 * v3[i] + v4[i]) * (real)(1.0 / 6.0);
+  }
+}
+// columns c_lo .. c_hi - 1 of [A|B] (7 x 10) in the full state: unit seeds
 template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_DEV void rk_jacobian_cols(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3],
                                const real b1[3], const real b2[3], real* F, int c_lo, int c_hi) {
-  const real us[3] = {u[0] * tr.us, u[1] * tr.us, u[2] * tr.us};
-  real k1[7], k2[7], k3[7], t[7];
-  StageBase<real> s1, s2, s3, s4;
-  dyn_h<real, DIAGJ>(tr, x, us, b0, k1, s1);
-  for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k1[i];
-  dyn_h<real, DIAGJ>(tr, t, us, b1, k2, s2);
-  if (INTEG == 3) {
-    for (int i = 0; i < 7; ++i) t[i] = x[i] - k1[i] + 2 * k2[i];
-    dyn_h<real, DIAGJ>(tr, t, us, b2, k3, s3);
-  } else {
-    for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k2[i];
-    dyn_h<real, DIAGJ>(tr, t, us, b1, k3, s3);
-    for (int i = 0; i < 7; ++i) t[i] = x[i] + k3[i];
-    real k4[7];
-    dyn_h<real, DIAGJ>(tr, t, us, b2, k4, s4);
-  }
+  RkStages<real> st;
+  rk_primal<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, st);
 #ifndef TSAT_EMU
 #pragma unroll 1
 #endif
   for (int c = c_lo; c < c_hi; ++c) {
-    real ex[7], du[3];
+    real ex[7], du[3], out[7];
     for (int i = 0; i < 7; ++i) ex[i] = (i == c) ? (real)1 : (real)0;
     for (int a = 0; a < 3; ++a) du[a] = (c == 7 + a) ? tr.us : (real)0;
-    real v1[7], v2[7], v3[7], arg[7];
-    dyn_h_jvp<real, DIAGJ>(tr, s1, us, b0, ex, du, v1);
-    for (int i = 0; i < 7; ++i) arg[i] = ex[i] + (real)0.5 * v1[i];
-    dyn_h_jvp<real, DIAGJ>(tr, s2, us, b1, arg, du, v2);
-    if (INTEG == 3) {
-      for (int i = 0; i < 7; ++i) arg[i] = ex[i] - v1[i] + 2 * v2[i];
-      dyn_h_jvp<real, DIAGJ>(tr, s3, us, b2, arg, du, v3);
-      for (int i = 0; i < 7; ++i) F[c * FS + i] = ex[i] + (v1[i] + 4 * v2[i] + v3[i]) * (real)(1.0 / 6.0);
-    } else {
-      real v4[7];
-      for (int i = 0; i < 7; ++i) arg[i] = ex[i] + (real)0.5 * v2[i];
-      dyn_h_jvp<real, DIAGJ>(tr, s3, us, b1, arg, du, v3);
-      for (int i = 0; i < 7; ++i) arg[i] = ex[i] + v3[i];
-      dyn_h_jvp<real, DIAGJ>(tr, s4, us, b2, arg, du, v4);
-      for (int i = 0; i < 7; ++i) F[c * FS + i] = ex[i] + (v1[i] + 2 * v2[i] + 2 * v3[i] + v4[i]) * (real)(1.0 / 6.0);
-    }
+    rk_tangent<real, INTEG, DIAGJ>(tr, st, b0, b1, b2, ex, du, out);
+    for (int i = 0; i < 7; ++i) F[c * FS + i] = out[i];
   }
 }
 template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_DEV void rk_jacobian(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3],
                           const real b1[3], const real b2[3], real* F) {
   rk_jacobian_cols<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, F, 0, 10);
+}
+
+// o = G(q)' r for a 4-vector r, G(q) = [-v'; s I + hat(v)] with the raw state quaternion (src/attitude_controller.jl:69)
+template <typename real>
+TSAT_DEV void gt_apply(const real q[4], real r0, real r1, real r2, real r3, real o[3]) {
+  const real s = q[0], v0 = q[1], v1 = q[2], v2 = q[3];
+  // (two-product terms with the rounding spelled out, see dmm_: every build of the kernel rounds them the same way)
+  o[0] = dmm_(s, r1, v0, r0) + dmm_(v2, r2, v1, r3);
+  o[1] = fma_(s, r2, v0 * r3) - fma_(v2, r1, v1 * r0);
+  o[2] = dmm_(v1, r1, v2, r0) + dmm_(s, r3, v0, r2);
+}
+
+// The same in ERROR coordinates (error_state = 1), columns c_lo .. c_hi - 1 of [A^|B^] (6 x 9):
+//   A^ = E(q_{k+1})' A E(q_k), B^ = E(q_{k+1})' B, E(q) = blkdiag(I3, G(q))   (src/attitude_controller.jl:59-81)
+// A E(q_k) is taken by linearity: the tangent pass of column c is seeded with column c of E(q_k) — a unit rate, or a column of
+// G(q_k) in the quaternion slots — instead of forming the four quaternion columns of A and mixing them afterwards (nine
+// passes instead of ten, and no pass over the finished record); E(q_{k+1})' acts on each finished column by itself. qn is the
+// NOMINAL next quaternion, as in the reference. Column c lands at F[c * FS + 0..5].
+template <typename real, int INTEG, int DIAGJ>
+TSAT_DEV void rk_jacobian_es_cols(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3], const real b1[3],
+                                  const real b2[3], const real qn[4], real* F, int c_lo, int c_hi) {
+  RkStages<real> st;
+  rk_primal<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, st);
+  const real sq = x[3], v0 = x[4], v1 = x[5], v2 = x[6];
+#ifndef TSAT_EMU
+#pragma unroll 1
+#endif
+  for (int c = c_lo; c < c_hi; ++c) {
+    real ex[7], du[3], out[7], o[3];
+    const int t = c - 3;      // column of G(q_k) = [-v'; s I + hat(v)] on the attitude columns
+    for (int i = 0; i < 3; ++i) ex[i] = (i == c) ? (real)1 : (real)0;
+    ex[3] = (t == 0) ? -v0 : (t == 1 ? -v1 : (t == 2 ? -v2 : (real)0));
+    ex[4] = (t == 0) ? sq : (t == 1 ? -v2 : (t == 2 ? v1 : (real)0));
+    ex[5] = (t == 0) ? v2 : (t == 1 ? sq : (t == 2 ? -v0 : (real)0));
+    ex[6] = (t == 0) ? -v1 : (t == 1 ? v0 : (t == 2 ? sq : (real)0));
+    for (int a = 0; a < 3; ++a) du[a] = (c == 6 + a) ? tr.us : (real)0;
+    rk_tangent<real, INTEG, DIAGJ>(tr, st, b0, b1, b2, ex, du, out);
+    gt_apply(qn, out[3], out[4], out[5], out[6], o);
+    for (int i = 0; i < 3; ++i) { F[c * FS + i] = out[i]; F[c * FS + 3 + i] = o[i]; }
+  }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -896,15 +951,6 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
   return out;
 }
 
-// o = G(q)' r for a 4-vector r, G(q) = [-v'; s I + hat(v)] with the raw state quaternion (src/attitude_controller.jl:69)
-template <typename real>
-TSAT_DEV void gt_apply(const real q[4], real r0, real r1, real r2, real r3, real o[3]) {
-  const real s = q[0], v0 = q[1], v1 = q[2], v2 = q[3];
-  // (two-product terms with the rounding spelled out, see dmm_: every build of the kernel rounds them the same way)
-  o[0] = dmm_(s, r1, v0, r0) + dmm_(v2, r2, v1, r3);
-  o[1] = fma_(s, r2, v0 * r3) - fma_(v2, r1, v1 * r0);
-  o[2] = dmm_(v1, r1, v2, r0) + dmm_(s, r3, v0, r2);
-}
 
 // control gradient and Hessian diagonal of one knot with the AL terms of the control box: lu = R u + (lambda+ + I mu c+) -
 // (lambda- + I mu c-), luu = R + I+ mu + I- mu, row active iff c > 0 or lambda > 0. The fused operations are spelled out
@@ -942,31 +988,23 @@ TSAT_PHASE void jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, 
     const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
     for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
     real* rc = lds + L_REC + lane * BwdCfg<ES>::RECS;
-    rk_jacobian<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, rc + R_F);
-    for (int i = 0; i < 7; ++i) rc[R_LX + i] = tr.Qd[i] * (x[i] - tr.xf[i]);
-    if (ES) {
-      // reduce to error coordinates in place: A^ = E(q_{k+1})' A E(q_k), B^ = E(q_{k+1})' B
-      // (src/attitude_controller.jl:59-81), lx^ = E(q_k)' lx, Qxx^ = E(q_k)' Q E(q_k) (src/quaternion_toolbox.jl:15-36)
+    if (!ES) {
+      rk_jacobian<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, rc + R_F);
+      for (int i = 0; i < 7; ++i) rc[R_LX + i] = tr.Qd[i] * (x[i] - tr.xf[i]);
+    } else {
+      // error coordinates: A^ = E(q_{k+1})' A E(q_k), B^ = E(q_{k+1})' B column by column (rk_jacobian_es_cols),
+      // lx^ = E(q_k)' lx, Qxx^ = E(q_k)' Q E(q_k) (src/quaternion_toolbox.jl:15-36)
       real qk[4], qn[4];
       for (int i = 0; i < 4; ++i) { qk[i] = x[3 + i]; qn[i] = xu[XUW + 3 + i]; }
-      real* F = rc + R_F;
-      for (int i = 0; i < 7; ++i) {   // columns 3..6 of A -> 3 error columns
-        real o[3];
-        gt_apply(qk, F[3 * FS + i], F[4 * FS + i], F[5 * FS + i], F[6 * FS + i], o);
-        F[3 * FS + i] = o[0]; F[4 * FS + i] = o[1]; F[5 * FS + i] = o[2];
-      }
-      for (int a = 0; a < 3; ++a)     // B columns move from 7..9 to 6..8
-        for (int i = 0; i < 7; ++i) F[(6 + a) * FS + i] = F[(7 + a) * FS + i];
-      for (int c = 0; c < 9; ++c) {   // rows 3..6 -> 3 error rows
-        real o[3];
-        gt_apply(qn, F[c * FS + 3], F[c * FS + 4], F[c * FS + 5], F[c * FS + 6], o);
-        F[c * FS + 3] = o[0]; F[c * FS + 4] = o[1]; F[c * FS + 5] = o[2];
-      }
+      rk_jacobian_es_cols<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, qn, rc + R_F, 0, 9);
+      real lx[7];
+      for (int i = 0; i < 7; ++i) lx[i] = tr.Qd[i] * (x[i] - tr.xf[i]);
       {
         real o[3];
-        gt_apply(qk, rc[R_LX + 3], rc[R_LX + 4], rc[R_LX + 5], rc[R_LX + 6], o);
-        rc[R_LX + 3] = o[0]; rc[R_LX + 4] = o[1]; rc[R_LX + 5] = o[2];
+        gt_apply(qk, lx[3], lx[4], lx[5], lx[6], o);
+        lx[3] = o[0]; lx[4] = o[1]; lx[5] = o[2];
       }
+      for (int i = 0; i < 7; ++i) rc[R_LX + i] = lx[i];
       {  // G' diag(Qd[3:7]) G, upper triangle (0,0)(0,1)(0,2)(1,1)(1,2)(2,2); G rows: [-v'; s I + hat(v)]
         const real sq = qk[0], v0 = qk[1], v1 = qk[2], v2 = qk[3];
         const real G[4][3] = {{-v0, -v1, -v2}, {sq, -v2, v1}, {v2, sq, -v0}, {-v1, v0, sq}};

@@ -359,7 +359,6 @@ TSAT_PHASE void jacobian_group(const KArgs<real>& a, int traj0, int k0, bool nee
   const bool valid = need && k < N - 1;
   real* rc = lds + L_GREC + g * PK_GRS + kk * PK_RECS;
   real* F = rc + R_F;
-  real qk[4] = {1, 0, 0, 0}, qn[4] = {1, 0, 0, 0};
   if (valid) {
     const int tmax = a.T - 1;
     const int traj = (traj0 + g <= tmax) ? traj0 + g : tmax;
@@ -373,61 +372,42 @@ TSAT_PHASE void jacobian_group(const KArgs<real>& a, int traj0, int k0, bool nee
     const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
     const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
     for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
-    const int c_lo = (qtr == 0) ? 0 : (qtr == 1 ? 3 : (qtr == 2 ? 6 : 8));
-    const int c_hi = (qtr == 0) ? 3 : (qtr == 1 ? 6 : (qtr == 2 ? 8 : 10));
-    rk_jacobian_cols<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, F, c_lo, c_hi);
-    if (ES)
-      for (int i = 0; i < 4; ++i) { qk[i] = x[3 + i]; qn[i] = xu[XUW + 3 + i]; }
-    if (qtr == 2) {          // state gradient (error-state mode: lx^ = E(q_k)' lx)
+    if (!ES) {
+      const int c_lo = (qtr == 0) ? 0 : (qtr == 1 ? 3 : (qtr == 2 ? 6 : 8));
+      const int c_hi = (qtr == 0) ? 3 : (qtr == 1 ? 6 : (qtr == 2 ? 8 : 10));
+      rk_jacobian_cols<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, F, c_lo, c_hi);
+    } else {    // error coordinates: nine columns, finished per column (rk_jacobian_es_cols): quarters {0-2 | 3,4 | 5,6 | 7,8}
+      real qn[4];
+      for (int i = 0; i < 4; ++i) qn[i] = xu[XUW + 3 + i];
+      const int c_lo = (qtr == 0) ? 0 : 2 * qtr + 1, c_hi = (qtr == 0) ? 3 : 2 * qtr + 3;
+      rk_jacobian_es_cols<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, qn, F, c_lo, c_hi);
+    }
+    if (qtr == 1) {          // state gradient (error-state mode: lx^ = E(q_k)' lx, and G'QG into the record's column 9)
       real lx[7];
       for (int i = 0; i < 7; ++i) lx[i] = tr.Qd[i] * (x[i] - tr.xf[i]);
       if (ES) {
+        const real qk[4] = {x[3], x[4], x[5], x[6]};
         real o[3];
         gt_apply(qk, lx[3], lx[4], lx[5], lx[6], o);
         lx[3] = o[0]; lx[4] = o[1]; lx[5] = o[2];
       }
       for (int i = 0; i < 7; ++i) rc[R_LX + i] = lx[i];
     }
+    if (ES && qtr == 2) {    // G' diag(Qd[3:7]) G, upper triangle (0,0)(0,1)(0,2)(1,1)(1,2)(2,2); G rows: [-v'; s I + hat(v)]
+      const real sq = x[3], v0 = x[4], v1 = x[5], v2 = x[6];
+      const real G[4][3] = {{-v0, -v1, -v2}, {sq, -v2, v1}, {v2, sq, -v0}, {-v1, v0, sq}};
+      int idx = 0;
+      for (int j = 0; j < 3; ++j)
+        for (int l = j; l < 3; ++l) {
+          real acc = 0;
+          for (int r = 0; r < 4; ++r) acc += G[r][j] * tr.Qd[3 + r] * G[r][l];
+          rc[PK_R_QQ + idx++] = acc;
+        }
+    }
     if (qtr == 3) {          // control gradient and Hessian diagonal with the AL terms of the control box
       real lam[6];
       for (int c = 0; c < 6; ++c) lam[c] = p.LAM[(size_t)k * LMW + c];
       al_control_terms(tr, u, lam, mu, rc + R_LU, rc + R_LUU);
-    }
-  }
-  if (ES) {
-    // reduction to error coordinates, in place: A^ = E(q_{k+1})' A E(q_k), B^ = E(q_{k+1})' B (src/attitude_controller.jl:59-81),
-    // Qxx^ = E(q_k)' Q E(q_k) (src/quaternion_toolbox.jl:15-36). First the columns 3..6 of A -> 3 error columns, rows split over
-    // the quarters; then, per destination column (B moves from 7..9 to 6..8), the rows 3..6 -> 3 error rows. The quarter that
-    // moves B (sources 7, 8, 9, in that order) writes G'QG into the vacated column 9 afterwards.
-    TSAT_SYNC_LDS();
-    if (valid)
-      for (int i = qtr; i < 7; i += 4) {
-        real o[3];
-        gt_apply(qk, F[3 * FS + i], F[4 * FS + i], F[5 * FS + i], F[6 * FS + i], o);
-        F[3 * FS + i] = o[0]; F[4 * FS + i] = o[1]; F[5 * FS + i] = o[2];
-      }
-    TSAT_SYNC_LDS();
-    if (valid) {
-      const int d_lo = (qtr < 3) ? 2 * qtr : 6, d_hi = (qtr < 3) ? 2 * qtr + 2 : 9;
-      for (int c = d_lo; c < d_hi; ++c) {
-        const int src = (c < 6) ? c : c + 1;
-        real v[7], o[3];
-        for (int i = 0; i < 7; ++i) v[i] = F[src * FS + i];
-        gt_apply(qn, v[3], v[4], v[5], v[6], o);
-        for (int i = 0; i < 3; ++i) { F[c * FS + i] = v[i]; F[c * FS + 3 + i] = o[i]; }
-      }
-      if (qtr == 3) {  // G' diag(Qd[3:7]) G, upper triangle (0,0)(0,1)(0,2)(1,1)(1,2)(2,2); G rows: [-v'; s I + hat(v)]
-        const real* Qd = lds + L_GTR + g * PK_GTRW + P_QD;
-        const real sq = qk[0], v0 = qk[1], v1 = qk[2], v2 = qk[3];
-        const real G[4][3] = {{-v0, -v1, -v2}, {sq, -v2, v1}, {v2, sq, -v0}, {-v1, v0, sq}};
-        int idx = 0;
-        for (int j = 0; j < 3; ++j)
-          for (int l = j; l < 3; ++l) {
-            real acc = 0;
-            for (int r = 0; r < 4; ++r) acc += G[r][j] * Qd[3 + r] * G[r][l];
-            rc[PK_R_QQ + idx++] = acc;
-          }
-      }
     }
   }
 }
