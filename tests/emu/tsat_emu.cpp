@@ -73,6 +73,8 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
   a.P = P.data(); a.BT = BT.data(); a.bidx = bidx.data(); a.nk = n_knots; a.U0 = U0r.data();
   a.XU = XU.data(); a.KD = KD.data(); a.LAM = LAM.data(); a.CAND = CAND.data();
   a.stats = stats; a.trace = trace; a.trace_rows = trace_rows;
+  std::vector<R> JW((size_t)((T + 3) / 4) * TSAT_JW_REALS_PER_4, (R)0);     // packed builds: Jacobian records in flight
+  a.JW = JW.data();
   const int cls = inertia_class(T, Jmat);   // same variant selection as tsat_batch_upload
   using blk_t = void (*)(const KArgs<R>&, int);
   static const blk_t variants[2][3][2] = {

@@ -125,3 +125,34 @@ def test_gpu_configs4_shard(pkg, ol):
     assert dX < 1e-9 and dU < 1e-9 * 19.0
     for k in ("inner_iters", "ls_trials", "status"):
         assert np.array_equal(ref["stats"][k], got["stats"][k][idx]), k
+
+
+def test_gpu_large_batch_runs_are_repeatable(pkg):
+    """16384 x 1000 knots (configs[2] shape) three times per build: identical results run to run. The machine is under full
+    memory load here, which is where an unsafe s_waitcnt count shows (the forward chunk wait of the packed builds once did:
+    loads and stores do not retire in order relative to each other) — small batches never saw it."""
+    ss, to = pkg.slew_setup, pkg.trajopt
+    base = ss.workload_monte_carlo(T=1024, N=1000, seed=20190531, random_orbit=True)
+    rep = lambda a: np.ascontiguousarray(np.concatenate([a] * 16))
+    b = ss.SlewBatch(base.N, base.n_tab, rep(base.x0), rep(base.xf), base.Btab, rep(base.btab_idx), rep(base.tau0), rep(base.dtau),
+                     rep(base.dt), rep(base.Jmat), rep(base.Qd), rep(base.Qfd), rep(base.Rd), rep(base.ulo), rep(base.uhi), rep(base.U0))
+    opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = 5
+    opts.opts_uncon.iterations = 10; opts.opts_uncon.dJ_counter_limit = 1
+    s = to.AugmentedLagrangianSolver(None, opts)
+    o = opts.to_abi(b.N, b.n_tab, 3, error_state=1)
+    s.upload(b, o.max_linesearch)
+    for prec, variant in ((32, 4), (32, 3), (64, 4), (64, 3)):
+        o.precision = prec
+        s.set_kernel_variant(variant)
+        runs = []
+        for _ in range(3):
+            s.run(o)
+            r = s.download(want_K=False)
+            runs.append((r["stats"].copy(), r["X"][::97].copy(), r["U"][::97].copy()))
+        for st, X, U in runs[1:]:
+            assert np.array_equal(st, runs[0][0]) and np.array_equal(X, runs[0][1]) and np.array_equal(U, runs[0][2]), (prec, variant)
+        assert not np.any(runs[0][0]["status"] == pkg._abi.TSAT_DIVERGED)
+        if prec == 64:      # the tiled batch repeats its 1024 trajectories 16 times: all copies solve alike, whatever wave they sit in
+            assert np.array_equal(runs[0][0]["inner_iters"][:1024], runs[0][0]["inner_iters"][1024:2048])
+    s.set_kernel_variant(0)
+    s.close()

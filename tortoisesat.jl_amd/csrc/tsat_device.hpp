@@ -149,7 +149,11 @@ struct KArgs {
   tsat_stats* stats;  // [T]
   double* trace;      // [T][trace_rows][8] or null
   int trace_rows;
+  real* JW;           // packed builds: Jacobian records of the backward chunk in flight, [wavefront][4][16][84] (tsat_packed.hpp)
 };
+
+// reals of a.JW per group of four trajectories (4 trajectories x 16 knots x 84-real records): host allocation and kernels agree on it
+constexpr int TSAT_JW_REALS_PER_4 = 4 * 16 * 84;
 
 // per-trajectory pointers handed (by value) to the phase functions
 template <typename real>
@@ -604,9 +608,9 @@ TSAT_DEV void rk_tangent(const Traj<real>& tr, const RkStages<real>& st, const r
   }
 }
 // columns c_lo .. c_hi - 1 of [A|B] (7 x 10) in the full state: unit seeds
-template <typename real, int INTEG, int DIAGJ, int ES>
+template <typename real, int INTEG, int DIAGJ, int ES, typename FP>
 TSAT_DEV void rk_jacobian_cols(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3],
-                               const real b1[3], const real b2[3], real* F, int c_lo, int c_hi) {
+                               const real b1[3], const real b2[3], FP F, int c_lo, int c_hi) {
   RkStages<real> st;
   rk_primal<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, st);
 #ifndef TSAT_EMU
@@ -642,9 +646,9 @@ TSAT_DEV void gt_apply(const real q[4], real r0, real r1, real r2, real r3, real
 // G(q_k) in the quaternion slots — instead of forming the four quaternion columns of A and mixing them afterwards (nine
 // passes instead of ten, and no pass over the finished record); E(q_{k+1})' acts on each finished column by itself. qn is the
 // NOMINAL next quaternion, as in the reference. Column c lands at F[c * FS + 0..5].
-template <typename real, int INTEG, int DIAGJ>
+template <typename real, int INTEG, int DIAGJ, typename FP>
 TSAT_DEV void rk_jacobian_es_cols(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3], const real b1[3],
-                                  const real b2[3], const real qn[4], real* F, int c_lo, int c_hi) {
+                                  const real b2[3], const real qn[4], FP F, int c_lo, int c_hi) {
   RkStages<real> st;
   rk_primal<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, st);
   const real sq = x[3], v0 = x[4], v1 = x[5], v2 = x[6];
@@ -743,8 +747,7 @@ TSAT_DEV void glds_put(real* dst, const TSAT_GLOBAL real* src) {
 #endif
 }
 // One (x,u) knot record to HBM as exactly FIVE store instructions (16-byte pieces of the 80-byte double record, 8-byte
-// pieces of the 40-byte float record; both are aligned that way by construction). The packed forward sweep counts on the
-// number: it waits for its LDS copies with s_waitcnt vmcnt(5 x knots) so that these stores stay in flight (tsat_packed.hpp).
+// pieces of the 40-byte float record; both are aligned that way by construction).
 constexpr int REC_STORES = 5;
 template <typename real>
 TSAT_DEV void store_record5(TSAT_GLOBAL real* cr, const real x[7], const real u[3]) {
@@ -755,11 +758,18 @@ TSAT_DEV void store_record5(TSAT_GLOBAL real* cr, const real x[7], const real u[
   typedef real v2 __attribute__((ext_vector_type(2)));
   typedef TSAT_GLOBAL v2* gv2;
   v2 a = {x[0], x[1]}, b = {x[2], x[3]}, c = {x[4], x[5]}, d = {x[6], u[0]}, e = {u[1], u[2]};
+#ifdef TSAT_NT_CAND   /* experiment: stream the candidate records past the caches */
+  __builtin_nontemporal_store(a, &((gv2)cr)[0]); __builtin_nontemporal_store(b, &((gv2)cr)[1]); __builtin_nontemporal_store(c, &((gv2)cr)[2]);
+  __builtin_nontemporal_store(d, &((gv2)cr)[3]); __builtin_nontemporal_store(e, &((gv2)cr)[4]);
+#else
   ((gv2)cr)[0] = a; ((gv2)cr)[1] = b; ((gv2)cr)[2] = c; ((gv2)cr)[3] = d; ((gv2)cr)[4] = e;
 #endif
+#endif
 }
-// wait until all but the `n` youngest vector-memory operations of the wave have completed (loads, stores and LDS copies count
-// together, in issue order), then order LDS traffic between the lanes; the emulator synchronises fully
+// wait until at most `n` vector-memory operations of the wave are outstanding, then order LDS traffic between the lanes. Loads
+// (and LDS copies) retire in issue order among themselves, stores among themselves, but not relative to each other: the only
+// safe use is to let n count YOUNGER LOADS — then at most n loads are outstanding and an older load has landed whatever the
+// stores do (the record ring of tsat_packed.hpp). The emulator synchronises fully.
 #ifdef TSAT_EMU
 #define TSAT_SYNC_OLDER_THAN(n) (tsat_emu::sync())
 #else

@@ -136,7 +136,7 @@ struct tsat_handle {
   // allocated on first use and kept for the life of the handle, so repeated calls pay no hipMalloc / hipFree
   enum { WS_TV_NZ, WS_TV_KD, WS_TV_XS, WS_TV_NID, WS_TV_ST, WS_TV_P, WS_TVB_P, WS_TVB_BT, WS_TVB_XUR, WS_TVB_BI, WS_TVB_NK,
          WS_HZ_B, WS_HZ_DT, WS_HZ_CUT, WS_HZ_C, WS_HZ_I, WS_BT_COEF, WS_BT_KEP, WS_BT_T0, WS_BT_TF, WS_BT_POS, WS_BT_B,
-         WS_MPC_HX, WS_MPC_HU, WS_DL_X, WS_DL_U, WS_DL_K, WS_AG_X, WS_AG_U, WS_AG_ST, WS_AG_XA, WS_AG_UA, WS_AG_STA, WS_COUNT };
+         WS_JW, WS_MPC_HX, WS_MPC_HU, WS_DL_X, WS_DL_U, WS_DL_K, WS_AG_X, WS_AG_U, WS_AG_ST, WS_AG_XA, WS_AG_UA, WS_AG_STA, WS_COUNT };
   void* ws[WS_COUNT] = {};
   size_t ws_bytes[WS_COUNT] = {};
   // RCCL communicator of the sweep (tsat_comm_init): one rank per handle / GPU
@@ -386,12 +386,19 @@ hipError_t launch_solve(const tsat_handle* h, const tsat_options* o, const KArgs
   return hipGetLastError();
 }
 
-KArgs<double> solve_args(const tsat_handle* h, const tsat_options* o) {
+// Jacobian-record workspace of the packed builds (one block per wavefront, i.e. per four trajectories at most), persistent in
+// the handle; sized for doubles, the float build uses half of it
+void* packed_workspace(tsat_handle* h) {
+  return ws_get(h, tsat_handle::WS_JW, (size_t)((h->T + 3) / 4) * TSAT_JW_REALS_PER_4 * sizeof(double));
+}
+
+KArgs<double> solve_args(tsat_handle* h, const tsat_options* o) {
   KArgs<double> a;
   a.T = (int)h->T; a.N = h->N; a.n_tab = h->n_tab; a.max_ls = h->max_ls < NSTORE ? h->max_ls : NSTORE; a.opt = *o;
   a.P = h->P; a.BT = h->BT; a.bidx = h->bidx; a.nk = h->ragged ? h->nk : nullptr; a.U0 = h->U0;
   a.XU = h->XU; a.KD = h->KD; a.LAM = h->LAM; a.CAND = h->CAND;
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
+  a.JW = (h->variant == 3 || h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T)) ? (double*)packed_workspace(h) : nullptr;
   return a;
 }
 
@@ -416,6 +423,8 @@ int launch_solve_f32(tsat_handle* h, const tsat_options* o) {
   a.P = h->P32; a.BT = h->BT32; a.bidx = h->bidx; a.nk = h->ragged ? h->nk : nullptr; a.U0 = h->U032;
   a.XU = (float*)h->XU; a.KD = (float*)h->KD; a.LAM = (float*)h->LAM; a.CAND = (float*)h->CAND;
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
+  a.JW = (h->variant == 3 || h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED_F32_MIN_T)) ? (float*)packed_workspace(h) : nullptr;
+  if ((h->variant == 3 || h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED_F32_MIN_T)) && !a.JW) return -10;
   // build by batch size: the layout for two wavefronts per SIMD while the batch fits the GPU that way (256 CUs x 4 SIMDs x 2),
   // else the one for four; tsat_set_kernel_variant(h, 12 | 13 | 14) forces one (tuning, tests)
   // batches several times larger than the machine: the packed build (tsat_kernels_packed_f32.hip), as in fp64
@@ -437,6 +446,8 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
   if (!why.empty()) return fail(h, -1, why);
   TSAT_HIP(h, hipSetDevice(h->dev));
   const KArgs<double> a = solve_args(h, o);
+  if (!a.JW && (h->variant == 3 || h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T)))
+    return fail(h, -10, "device allocation of the packed builds' Jacobian workspace failed");
   if (h->trace) TSAT_HIP(h, hipMemsetAsync(h->trace, 0, (size_t)h->T * h->trace_rows * 8 * sizeof(double), h->stream));
   if (o->precision == 32) {
     // first fp32 run after an upload: the float mirrors are built before the events, so that kernel_ms is the solve alone

@@ -57,24 +57,26 @@ constexpr int PK_NI_KD = (PK_G * (PK_UKD + 1) + WAVE - 1) / WAVE, PK_NI_LM = (PK
 static_assert(L_FWD + PK_NBUF * PK_FB <= LDS_REALS, "packed forward buffers fit the wave's LDS block");
 
 // ---- joint backward sweep: carve-up behind L_UNION (the forward chunk buffers overlay all of it between backward sweeps) -----
-// The PK_G trajectories of the wave run their backward sweeps TOGETHER, PK_CHG knots of each per chunk:
-//   Jacobian lanes   lane = (trajectory, knot of the chunk, quarter): the quarter owns tangent columns {0-2 | 3-5 | 6,7 | 8,9}
-//                    of [A|B] (each column is its own pass through the RK stages), so all 64 lanes linearise although a
-//                    trajectory has only PK_CHG knots in LDS;
+// The PK_G trajectories of the wave run their backward sweeps TOGETHER, four at a time, 16 knots of each per chunk:
+//   Jacobian lanes   lane = (trajectory, knot): all 64 lanes linearise a knot each, all columns, and leave the finished record
+//                    (84 reals) in the wavefront's HBM workspace a.JW — the LDS of two wavefronts per SIMD holds only four
+//                    knots per trajectory, and a narrower Jacobian pass repeats the primal stages on every lane of a knot
+//                    (measured 2.3x the instructions per knot); the workspace is written and read back by the same wavefront
+//                    within microseconds (42 KB per wavefront: it lives in L2 / MALL);
+//   record ring      the Riccati lanes stream the records back: four knots of the four trajectories are resident in LDS, the
+//                    record three knots ahead is copied by global_load_lds while the recursion works (vmcnt-counted wait);
 //   Riccati lanes    PK_C = 16 lanes per trajectory, lane j < NH + 3 owns COLUMN j of [A|B]: it keeps S~ in registers, forms
 //                    column j of W~ = S~ F and of F'W~ (the rows the recursion needs), its gain column and column j of the new
 //                    cost-to-go; three small exchanges per knot go through the trajectory's block in LDS (Quu / Qu, the
 //                    gain columns, the new S~). Element by element the operations — and their order — are those of
 //                    riccati_chunk (tsat_device.hpp): the results are bit-identical to the one-trajectory builds.
-#ifndef TSAT_PK_CHG
-#define TSAT_PK_CHG 4
-#endif
-constexpr int PK_CHG = TSAT_PK_CHG;               // knots per trajectory and backward chunk
+constexpr int PK_JCH = 16;                        // knots per trajectory and Jacobian pass (= lanes per trajectory)
+constexpr int PK_RING = (sizeof(cfg_real) == 8) ? 4 : 8;   // knots of every trajectory resident in LDS during the recursion (20 KB: 4 in double, 8 in float)
 constexpr int PK_BC = 16;                         // lanes per trajectory in a backward pass
 constexpr int PK_BG = WAVE / PK_BC;               // trajectories per backward pass (4); a wave of PK_G trajectories takes PK_G / PK_BG passes
-static_assert(PK_G % PK_BG == 0 && PK_CHG * 4 == PK_BC, "Jacobian lanes: 16 lanes of a trajectory = PK_CHG knots x 4 column quarters");
-constexpr int PK_RECS = 83;                       // knot record: F = [A|B] column-major (70), lx (7), lu (3), luu (3); error-state
-constexpr int PK_R_QQ = 9 * FS;                   //   mode keeps G'QG (6) in F's column 9, which the reduction has vacated
+static_assert(PK_G % PK_BG == 0 && PK_JCH == PK_BC, "Jacobian lanes: the 16 lanes of a trajectory linearise 16 knots");
+constexpr int PK_RECS = 84;                       // knot record: F = [A|B] column-major (70), lx (7), lu (3), luu (3), pad (1): 42 16-byte
+constexpr int PK_R_QQ = 9 * FS;                   //   units; error-state mode has nine columns and keeps G'QG (6) where the tenth would be
 constexpr int PK_GTRW = 88;                       // per-trajectory constants: staged parameter record (76), nu (8), pad
 constexpr int PK_GT_NU = 76;
 constexpr int PK_GXW = 88;                        // per-trajectory exchange block of the Riccati lanes:
@@ -82,20 +84,22 @@ constexpr int GX_S = 0;                           //   S~ as packed upper triang
 constexpr int GX_QU = 36;                         //   Quu (0,0)(0,1)(0,2)(1,1)(1,2)(2,2), Qu (3)
 constexpr int GX_XK = 46;                         //   per state column i: Qux(:,i) (3), K(:,i) (3)
 static_assert(GX_XK + 7 * 6 <= PK_GXW && PK_GXW % 2 == 0 && GX_XK % 2 == 0, "exchange block layout");
+static_assert(PK_RECS % RPU == 0, "a record is a whole number of 16-byte units");
 constexpr int L_GTR = L_UNION;
 constexpr int L_GX = L_GTR + PK_BG * PK_GTRW;
 constexpr int L_GREC = L_GX + PK_BG * PK_GXW;
-constexpr int PK_GRS = PK_CHG * PK_RECS;          // stride between the trajectories' record blocks (2656 B: 96 B past a multiple of
-                                                  // 256 B, so the four trajectories' broadcast reads fall into different banks)
-static_assert(L_GREC + PK_BG * PK_GRS <= LDS_REALS, "joint backward sweep fits the wave's LDS block");
+constexpr int PK_SLOT = PK_BG * PK_RECS;          // one ring slot: the records of ONE knot of the pass's four trajectories, contiguous
+static_assert(L_GREC + PK_RING * PK_SLOT <= LDS_REALS, "joint backward sweep fits the wave's LDS block");
+constexpr int PK_JW_WAVE = PK_BG * PK_JCH * PK_RECS;    // workspace reals per wavefront (its passes of four trajectories share it)
+static_assert(PK_JW_WAVE == TSAT_JW_REALS_PER_4, "host allocation of a.JW");
+// packed index of (i <= j) in an n x n upper triangle, row by row
+constexpr int sym_ut(int i, int j, int n) { return i * n - (i * (i - 1)) / 2 + (j - i); }
 // hand-over between the trajectories' state lanes (PK_C per trajectory) and the lanes of a backward pass (PK_BC per trajectory),
 // in the part of the one-trajectory Riccati scratch the packed build does not use
 template <typename real> struct BwdIn { int N, need; real mu, rho; };
 template <typename real> struct BwdRes { acc_t dV1, dV2; int ok, pad; };
 constexpr int L_BWT = L_HXX;
 static_assert(L_BWT % 2 == 0, "hand-over tables are 8-byte aligned");
-// packed index of (i <= j) in an n x n upper triangle, row by row
-constexpr int sym_ut(int i, int j, int n) { return i * n - (i * (i - 1)) / 2 + (j - i); }
 
 // per-trajectory position in the AL-iLQR iteration; lives in the registers of the trajectory's PK_C lanes and is made
 // wave-uniform (through LDS) for the phases that work on one trajectory at a time
@@ -321,13 +325,12 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
         TSAT_SYNC_LDS();
         issue(fbn, kn);
       }
-      // The copy of the next chunk has to have landed; the candidate stores need not. Double-buffered, the copy was issued
-      // BEFORE this chunk's PK_CK x REC_STORES candidate stores (every knot of a chunk that has a successor is live for at
-      // least one trajectory, so all of them were issued), and vector-memory operations retire in issue order: waiting for all
-      // but that many youngest ones covers the copy and leaves the stores in flight — a full drain would expose the write
-      // acknowledge latency of the scattered candidate stores at every chunk boundary (measured: 1.8x per knot).
-      if (PK_NBUF == 2) TSAT_SYNC_OLDER_THAN(PK_CK * REC_STORES);
-      else TSAT_SYNC();
+      // The copy of the next chunk has to have landed: a full vmcnt(0). (Waiting for "all but the chunk's candidate stores" —
+      // s_waitcnt vmcnt(PK_CK x REC_STORES), the copy being older than those stores — is NOT safe: loads and stores retire in
+      // order among themselves but not relative to each other, so under memory load a store can retire before the older copy
+      // and the count is met with the copy still in flight. It showed as run-to-run differences of the float eight-per-wave
+      // build at 16384 trajectories (tools/repeat_runs.py); the drain costs 0 - 3 %.)
+      TSAT_SYNC();
       gates(fbn);
       TSAT_SYNC_LDS();
       if (PK_NBUF == 2) cur = 1 - cur;
@@ -347,54 +350,51 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
 }
 
 // --------------------------------------------------------------------------------------------------
-// joint backward sweep, Jacobian lanes: knots k0 .. k0 + PK_CHG - 1 of every trajectory that takes part (`need`, group-uniform;
-// N, mu: the lane's own trajectory). Leaves [A|B], lx, lu, luu (error-state mode: reduced to error coordinates, G'QG in column 9)
-// in the trajectory's record block. Same per-knot arithmetic as jacobian_chunk (tsat_device.hpp).
+// joint backward sweep, Jacobian lanes: knots kb0 .. kb0 + 15 of the pass's four trajectories (`need`, group-uniform; N, mu:
+// the lane's own trajectory), lane = (trajectory, knot). Each lane leaves the finished record of its knot — [A|B], lx, lu, luu;
+// error-state mode: in error coordinates, G'QG in the tenth column's place — in the wavefront's workspace `jw`
+// ([4][16][PK_RECS]). Same per-knot arithmetic as jacobian_chunk (tsat_device.hpp).
 // --------------------------------------------------------------------------------------------------
 template <typename real, int INTEG, int DIAGJ, int ES>
-TSAT_PHASE void jacobian_group(const KArgs<real>& a, int traj0, int k0, bool need, int N, real mu) {
+TSAT_PHASE void jacobian16(const KArgs<real>& a, int traj0, TSAT_GLOBAL real* jw, int kb0, bool need, int N, real mu) {
   real* lds = lds_base<real>();
-  const int lane = TSAT_LANE(), g = lane / PK_BC, kk = (lane % PK_BC) >> 2, qtr = lane & 3;
-  const int k = k0 + kk;
-  const bool valid = need && k < N - 1;
-  real* rc = lds + L_GREC + g * PK_GRS + kk * PK_RECS;
-  real* F = rc + R_F;
-  if (valid) {
-    const int tmax = a.T - 1;
-    const int traj = (traj0 + g <= tmax) ? traj0 + g : tmax;
-    const TPtrs<real> p = group_ptrs<real>(a, traj);
-    const Traj<real> tr = load_traj_at<real>(lds + L_GTR + g * PK_GTRW, N, a.n_tab, p.bt);
-    const TSAT_GLOBAL real* xu = p.XU + (size_t)k * XUW;
-    real x[7], u[3], b0[3], b1[3], b2[3];
-    for (int i = 0; i < 7; ++i) x[i] = xu[i];
-    for (int c = 0; c < 3; ++c) u[c] = xu[7 + c];
-    const TSAT_GLOBAL real* p0 = tr.bt + (size_t)brow_index(tr, k, 0.0) * 4;
-    const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
-    const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
-    for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
-    if (!ES) {
-      const int c_lo = (qtr == 0) ? 0 : (qtr == 1 ? 3 : (qtr == 2 ? 6 : 8));
-      const int c_hi = (qtr == 0) ? 3 : (qtr == 1 ? 6 : (qtr == 2 ? 8 : 10));
-      rk_jacobian_cols<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, F, c_lo, c_hi);
-    } else {    // error coordinates: nine columns, finished per column (rk_jacobian_es_cols): quarters {0-2 | 3,4 | 5,6 | 7,8}
-      real qn[4];
-      for (int i = 0; i < 4; ++i) qn[i] = xu[XUW + 3 + i];
-      const int c_lo = (qtr == 0) ? 0 : 2 * qtr + 1, c_hi = (qtr == 0) ? 3 : 2 * qtr + 3;
-      rk_jacobian_es_cols<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, qn, F, c_lo, c_hi);
+  const int lane = TSAT_LANE(), g = lane / PK_BC, kk = lane % PK_BC;
+  const int k = kb0 + kk;
+  if (!(need && k < N - 1)) return;
+  const int tmax = a.T - 1;
+  const int traj = (traj0 + g <= tmax) ? traj0 + g : tmax;
+  const TPtrs<real> p = group_ptrs<real>(a, traj);
+  const Traj<real> tr = load_traj_at<real>(lds + L_GTR + g * PK_GTRW, N, a.n_tab, p.bt);
+  const TSAT_GLOBAL real* xu = p.XU + (size_t)k * XUW;
+  real x[7], u[3], lam[6], b0[3], b1[3], b2[3];
+  for (int i = 0; i < 7; ++i) x[i] = xu[i];
+  for (int c = 0; c < 3; ++c) u[c] = xu[7 + c];
+  for (int c = 0; c < 6; ++c) lam[c] = p.LAM[(size_t)k * LMW + c];
+  const TSAT_GLOBAL real* p0 = tr.bt + (size_t)brow_index(tr, k, 0.0) * 4;
+  const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
+  const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
+  for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
+  // the last PK_RING knots of the chunk are the first the recursion consumes: their lanes put the record straight into its
+  // ring slot in LDS; the others go through the workspace (one code path for both: a generic pointer, flat stores)
+  real* rc = (kk >= PK_JCH - PK_RING) ? lds + L_GREC + (kk & (PK_RING - 1)) * PK_SLOT + g * PK_RECS
+                                      : (real*)(jw + (size_t)(g * PK_JCH + kk) * PK_RECS);
+  real lx[7];
+  for (int i = 0; i < 7; ++i) lx[i] = tr.Qd[i] * (x[i] - tr.xf[i]);
+  if (!ES) {
+    rk_jacobian_cols<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, rc + R_F, 0, 10);
+  } else {
+    // error coordinates: A^ = E(q_{k+1})' A E(q_k), B^ = E(q_{k+1})' B column by column (rk_jacobian_es_cols),
+    // lx^ = E(q_k)' lx, Qxx^ = E(q_k)' Q E(q_k) (src/quaternion_toolbox.jl:15-36)
+    real qk[4], qn[4];
+    for (int i = 0; i < 4; ++i) { qk[i] = x[3 + i]; qn[i] = xu[XUW + 3 + i]; }
+    rk_jacobian_es_cols<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, qn, rc + R_F, 0, 9);
+    {
+      real o[3];
+      gt_apply(qk, lx[3], lx[4], lx[5], lx[6], o);
+      lx[3] = o[0]; lx[4] = o[1]; lx[5] = o[2];
     }
-    if (qtr == 1) {          // state gradient (error-state mode: lx^ = E(q_k)' lx, and G'QG into the record's column 9)
-      real lx[7];
-      for (int i = 0; i < 7; ++i) lx[i] = tr.Qd[i] * (x[i] - tr.xf[i]);
-      if (ES) {
-        const real qk[4] = {x[3], x[4], x[5], x[6]};
-        real o[3];
-        gt_apply(qk, lx[3], lx[4], lx[5], lx[6], o);
-        lx[3] = o[0]; lx[4] = o[1]; lx[5] = o[2];
-      }
-      for (int i = 0; i < 7; ++i) rc[R_LX + i] = lx[i];
-    }
-    if (ES && qtr == 2) {    // G' diag(Qd[3:7]) G, upper triangle (0,0)(0,1)(0,2)(1,1)(1,2)(2,2); G rows: [-v'; s I + hat(v)]
-      const real sq = x[3], v0 = x[4], v1 = x[5], v2 = x[6];
+    {  // G' diag(Qd[3:7]) G, upper triangle (0,0)(0,1)(0,2)(1,1)(1,2)(2,2); G rows: [-v'; s I + hat(v)]
+      const real sq = qk[0], v0 = qk[1], v1 = qk[2], v2 = qk[3];
       const real G[4][3] = {{-v0, -v1, -v2}, {sq, -v2, v1}, {v2, sq, -v0}, {-v1, v0, sq}};
       int idx = 0;
       for (int j = 0; j < 3; ++j)
@@ -404,12 +404,11 @@ TSAT_PHASE void jacobian_group(const KArgs<real>& a, int traj0, int k0, bool nee
           rc[PK_R_QQ + idx++] = acc;
         }
     }
-    if (qtr == 3) {          // control gradient and Hessian diagonal with the AL terms of the control box
-      real lam[6];
-      for (int c = 0; c < 6; ++c) lam[c] = p.LAM[(size_t)k * LMW + c];
-      al_control_terms(tr, u, lam, mu, rc + R_LU, rc + R_LUU);
-    }
   }
+  for (int i = 0; i < 7; ++i) rc[R_LX + i] = lx[i];
+  real lu[3], luu[3];
+  al_control_terms(tr, u, lam, mu, lu, luu);
+  for (int c = 0; c < 3; ++c) { rc[R_LU + c] = lu[c]; rc[R_LUU + c] = luu[c]; }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -418,10 +417,18 @@ TSAT_PHASE void jacobian_group(const KArgs<real>& a, int traj0, int k0, bool nee
 // lanes and re-read from its exchange block after every knot. Per output element the operations are those of riccati_chunk.
 // `ok`: no Quu_reg of this trajectory has failed the PD test so far (group-uniform); returned updated.
 // --------------------------------------------------------------------------------------------------
+// wait until at most min(l, PK_RING - 1) copy sets of NCI instructions are outstanding (the immediate of s_waitcnt is a
+// compile-time constant: one case per possible count)
+template <int NCI, int M = PK_RING - 1>
+TSAT_DEV void ring_wait(int l) {
+  if (l >= M) { TSAT_SYNC_OLDER_THAN(M * NCI); }
+  else if constexpr (M > 0) ring_wait<NCI, M - 1>(l);
+}
 template <typename real> struct GBwd { acc_t dV1, dV2; int ok; };
 
 template <typename real, int NH>
-TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, int k0, bool need, int N, real rho, acc_t dV1, acc_t dV2, int ok_in) {
+TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_GLOBAL real* jw, int kb0, bool need, int N, real rho,
+                                    acc_t dV1, acc_t dV2, int ok_in) {
   constexpr int ES = (NH == 6) ? 1 : 0;
   constexpr int NC = NH + 3;
   constexpr int NP = NH * (NH + 1) / 2;
@@ -443,7 +450,24 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, int k0, boo
   const int rlo = helper ? rmain : 0, rhi = helper ? cx + 1 : (xmain ? rmain : 0);
   real* gx = lds + L_GX + g * PK_GXW;
   const real* Qd = lds + L_GTR + g * PK_GTRW + P_QD;
-  const real* recs = lds + L_GREC + g * PK_GRS;
+  const real* recs = lds + L_GREC + g * PK_RECS;                   // this trajectory's record inside a ring slot
+  // copy lanes of the record ring: a slot (the records of one knot of the four trajectories, contiguous) is PK_SLOT / RPU
+  // 16-byte units; unit v belongs to trajectory v / (PK_RECS / RPU). Source of knot q: jw + (trajectory * 16 + q) * PK_RECS.
+  constexpr int UPR = PK_RECS / RPU, UPS = PK_SLOT / RPU, NCI = (UPS + WAVE - 1) / WAVE;
+  const TSAT_GLOBAL real* cp_src[NCI];
+  bool cp_on[NCI];
+  for (int i = 0; i < NCI; ++i) {
+    const int v = lane + WAVE * i;
+    cp_on[i] = v < UPS;
+    const int vg = cp_on[i] ? v / UPR : 0, ve = cp_on[i] ? v - vg * UPR : 0;
+    cp_src[i] = jw + (size_t)vg * PK_JCH * PK_RECS + (size_t)ve * RPU;
+  }
+  auto ring_copy = [&](int q) {          // knot q of the chunk into slot q % PK_RING; every lane with a unit copies, whatever its
+    real* slot = lds + L_GREC + (q & (PK_RING - 1)) * PK_SLOT;      // trajectory's state: the count of copies in flight is fixed
+    for (int i = 0; i < NCI; ++i)
+      if (cp_on[i]) glds_put_at<real>(slot + GLDS * i, cp_src[i] + (size_t)q * PK_RECS);
+  };
+  // (knots 15 .. 12 of the chunk are in their slots already: their Jacobian lanes wrote them there)
   const int tmax = a.T - 1;
   const int traj = (traj0 + g <= tmax) ? traj0 + g : tmax;
   TSAT_GLOBAL real* KDg = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * kd_stride<real>(a.N));
@@ -472,10 +496,16 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, int k0, boo
   real Ss[NP], sv[NH];
   for (int e = 0; e < NP; ++e) Ss[e] = gx[GX_S + e];
   for (int m = 0; m < NH; ++m) sv[m] = gx[GX_S + NP + m];
-  for (int l = PK_CHG - 1; l >= 0; --l) {
-    const int k = k0 + l;
+  for (int l = PK_JCH - 1; l >= 0; --l) {
+    const int k = kb0 + l;
     bool act = need && ok && k < N - 1;
-    const real* rc = recs + l * PK_RECS;
+    // the record PK_RING - 1 knots ahead starts its way into the slot knot l + 1 has just left
+    if (l >= PK_RING - 1 && l < PK_JCH - 1) ring_copy(l - (PK_RING - 1));
+    // knot l's record was copied PK_RING - 1 steps ago (or written straight into its slot); the copy sets issued since — one
+    // per step, NCI instructions each, none any more once l < PK_RING - 1 — may stay in flight, together with whatever gain
+    // stores were issued behind them: vector-memory operations retire in issue order
+    ring_wait<NCI>(l);
+    const real* rc = recs + (l & (PK_RING - 1)) * PK_SLOT;
     // step 1: column `col` of W~ = [S; s'] F
     real f[NH], W[NH + 1];
     for (int m = 0; m < NH; ++m) f[m] = rc[col * FS + m];
@@ -773,15 +803,16 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
             TSAT_SYNC_LDS();
           }
           const bool bneed = in.need != 0;
-          const int nch = (nmax - 1 + PK_CHG - 1) / PK_CHG;
+          TSAT_GLOBAL real* jw = (TSAT_GLOBAL real*)(a.JW + (size_t)wave * PK_JW_WAVE);
+          const int nch = (nmax - 1 + PK_JCH - 1) / PK_JCH;
           for (int ch = nch - 1; ch >= 0; --ch) {
-            const int k0 = ch * PK_CHG;
+            const int kb0 = ch * PK_JCH;
             const unsigned long long c0 = tick_();
-            jacobian_group<real, INTEG, DIAGJ, ES>(a, traj0 + t0, k0, bneed && bw.ok, in.N, in.mu);
-            TSAT_SYNC_LDS();
+            jacobian16<real, INTEG, DIAGJ, ES>(a, traj0 + t0, jw, kb0, bneed && bw.ok, in.N, in.mu);
+            TSAT_SYNC();         // the records are in the workspace (vmcnt(0)) before the ring copies read them
             const unsigned long long c1 = tick_();
-            bw = riccati_group<real, NH>(a, traj0 + t0, k0, bneed, in.N, in.rho, bw.dV1, bw.dV2, bw.ok);
-            TSAT_SYNC_LDS();
+            bw = riccati_group<real, NH>(a, traj0 + t0, jw, kb0, bneed, in.N, in.rho, bw.dV1, bw.dV2, bw.ok);
+            TSAT_SYNC();         // every copy has landed and every record has been consumed before the next pass overwrites them
             pc_jac += c1 - c0; pc_ric += tick_() - c1;
           }
         }
