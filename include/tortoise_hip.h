@@ -237,7 +237,7 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
  *   3 packed  four trajectories per wavefront share every forward sweep (16 line-search candidates each) and run their
  *             backward sweeps together (Jacobian lanes = trajectory x knot x column quarter, Riccati recursion on 16 lanes per
  *             trajectory), two wavefronts per SIMD: from 3072 trajectories; with precision = 32 the float build of the same
- *             (from 4096);
+ *             (from 3072);
  *   4 packed8 the same with eight trajectories per wavefront (eight candidates each, two backward passes): from 16384;
  *   12 | 13 | 14  precision = 32 only: the one-trajectory float build laid out for 2 | 3 | 4 wavefronts per SIMD.
  * The fp64 builds give bit-identical results (X, U, K, iteration counts; `n_forward` counts the sweeps a build executed and

@@ -50,7 +50,7 @@ def _errors(ref, got):
 @pytest.mark.parametrize("variant", [12, 13, 14, 3, 4])
 def test_gpu_fp32_short_solves_agree_outright(pkg, ol, solver, variant):
     """the three LDS layouts of the fp32 build (2 / 3 / 4 wavefronts per SIMD) and the fp32 packed builds (variants 3 / 4: four / eight
-    trajectories per wavefront, taken automatically from 4096 / 16384 trajectories on) on short solves: oracle's statuses and counts"""
+    trajectories per wavefront, taken automatically from 3072 / 16384 trajectories on) on short solves: oracle's statuses and counts"""
     b = pkg.slew_setup.workload_monte_carlo(T=16, N=120, seed=31)
     o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1, error_state=1)
     ref, got = ol.solve_batch(b, o, nthreads=8), _run32(pkg, solver, b, o, variant)

@@ -374,7 +374,7 @@ solve_kern_t solve_variant(const tsat_handle* h, const tsat_options* o) {
 constexpr int64_t TSAT_WIDE_MAX_T = 1024;
 constexpr int64_t TSAT_PACKED_MIN_T = 3072;
 constexpr int64_t TSAT_PACKED8_MIN_T = 16384;
-constexpr int64_t TSAT_PACKED_F32_MIN_T = 4096;     // below it the one-trajectory float build (two waves per SIMD) is faster
+constexpr int64_t TSAT_PACKED_F32_MIN_T = 3072;     // below it the one-trajectory float build (two waves per SIMD) is faster
 hipError_t launch_solve(const tsat_handle* h, const tsat_options* o, const KArgs<double>& a) {
   const bool packed8 = h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED8_MIN_T);
   if (packed8) return tsat_launch_solve_packed8(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream);

@@ -5,8 +5,9 @@
 // times larger than the machine (T >> 1024 wavefronts) the lanes are better spent on MORE TRAJECTORIES: a wavefront owns
 // PK_G trajectories, lane = (trajectory g, candidate c) with PK_C = 64 / PK_G candidates alpha = 2^-(c + shift) per sweep
 // (a further sweep with shift += PK_C serves the trajectories whose search went deeper — rare), so ONE forward sweep advances
-// PK_G trajectories. The backward sweeps (Jacobian lanes + Riccati recursion, lanes = knots / matrix elements) and the
-// lane-strided passes stay per trajectory and run one after the other through the very same phase functions as the
+// PK_G trajectories. The backward sweeps run jointly too, four trajectories at a time (below: 64-lane Jacobian passes into an
+// HBM workspace, a column-oriented Riccati recursion on 16 lanes per trajectory fed through an LDS ring); the lane-strided
+// passes (adopt, costs, duals) stay per trajectory and run one after the other through the very same phase functions as the
 // one-trajectory kernel. Each trajectory keeps its own position in the AL-iLQR iteration (outer / inner counters, penalty,
 // regularisation, multipliers): the driver below is the loop body of solve_trajectory (tsat_device.hpp) turned into a
 // per-trajectory state machine that is advanced between two forward sweeps. The arithmetic of a trajectory is, operation
@@ -63,8 +64,10 @@ static_assert(L_FWD + PK_NBUF * PK_FB <= LDS_REALS, "packed forward buffers fit 
 //                    knots per trajectory, and a narrower Jacobian pass repeats the primal stages on every lane of a knot
 //                    (measured 2.3x the instructions per knot); the workspace is written and read back by the same wavefront
 //                    within microseconds (42 KB per wavefront: it lives in L2 / MALL);
-//   record ring      the Riccati lanes stream the records back: four knots of the four trajectories are resident in LDS, the
-//                    record three knots ahead is copied by global_load_lds while the recursion works (vmcnt-counted wait);
+//   record ring      the Riccati lanes stream the records back: PK_RING knots of the four trajectories are resident in LDS, the
+//                    record PK_RING - 1 knots ahead is copied by global_load_lds while the recursion works (the wait counts
+//                    younger LOADS only: safe whatever the stores do); the last PK_RING knots of a pass — the first the
+//                    recursion consumes — never leave the chip: their Jacobian lanes write them straight into the ring;
 //   Riccati lanes    PK_C = 16 lanes per trajectory, lane j < NH + 3 owns COLUMN j of [A|B]: it keeps S~ in registers, forms
 //                    column j of W~ = S~ F and of F'W~ (the rows the recursion needs), its gain column and column j of the new
 //                    cost-to-go; three small exchanges per knot go through the trajectory's block in LDS (Quu / Qu, the
