@@ -16,7 +16,9 @@ def test_oracle_reproduces_golden(pkg, ol, name):
     np.testing.assert_allclose(got["K"], ref["K"], rtol=1e-7, atol=1e-9)
 
 
-@pytest.mark.parametrize("name", helpers.golden_cases())
+# the two longest fixtures (200 and 150 knots: 1.5 minutes of 64-thread barriers) are replayed by the GPU tier and by the oracle
+# test above; the emulator replays the others, which cover every code path (rk3/rk4, error state, random orbit, negative R)
+@pytest.mark.parametrize("name", [n for n in helpers.golden_cases() if n not in ("mc_n200_t2_rk3.npz", "single_n150_rk3.npz")])
 def test_emulated_kernel_reproduces_golden(pkg, ol, emu, name):
     b, o, ref = helpers.load_case(name, pkg, ol)
     got = emu.solve(b, o)

@@ -608,7 +608,7 @@ TSAT_DEV void rk_tangent(const Traj<real>& tr, const RkStages<real>& st, const r
   }
 }
 // columns c_lo .. c_hi - 1 of [A|B] (7 x 10) in the full state: unit seeds
-template <typename real, int INTEG, int DIAGJ, int ES, typename FP>
+template <typename real, int INTEG, int DIAGJ, int ES, typename FP, int FSS = FS>
 TSAT_DEV void rk_jacobian_cols(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3],
                                const real b1[3], const real b2[3], FP F, int c_lo, int c_hi) {
   RkStages<real> st;
@@ -621,7 +621,7 @@ TSAT_DEV void rk_jacobian_cols(const Traj<real>& tr, const real x[7], const real
     for (int i = 0; i < 7; ++i) ex[i] = (i == c) ? (real)1 : (real)0;
     for (int a = 0; a < 3; ++a) du[a] = (c == 7 + a) ? tr.us : (real)0;
     rk_tangent<real, INTEG, DIAGJ>(tr, st, b0, b1, b2, ex, du, out);
-    for (int i = 0; i < 7; ++i) F[c * FS + i] = out[i];
+    for (int i = 0; i < 7; ++i) F[c * FSS + i] = out[i];
   }
 }
 template <typename real, int INTEG, int DIAGJ, int ES>
@@ -645,8 +645,8 @@ TSAT_DEV void gt_apply(const real q[4], real r0, real r1, real r2, real r3, real
 // A E(q_k) is taken by linearity: the tangent pass of column c is seeded with column c of E(q_k) — a unit rate, or a column of
 // G(q_k) in the quaternion slots — instead of forming the four quaternion columns of A and mixing them afterwards (nine
 // passes instead of ten, and no pass over the finished record); E(q_{k+1})' acts on each finished column by itself. qn is the
-// NOMINAL next quaternion, as in the reference. Column c lands at F[c * FS + 0..5].
-template <typename real, int INTEG, int DIAGJ, typename FP>
+// NOMINAL next quaternion, as in the reference. Column c lands at F[c * FSS + 0..5] (FSS: column stride of the record).
+template <typename real, int INTEG, int DIAGJ, typename FP, int FSS = FS>
 TSAT_DEV void rk_jacobian_es_cols(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3], const real b1[3],
                                   const real b2[3], const real qn[4], FP F, int c_lo, int c_hi) {
   RkStages<real> st;
@@ -666,7 +666,7 @@ TSAT_DEV void rk_jacobian_es_cols(const Traj<real>& tr, const real x[7], const r
     for (int a = 0; a < 3; ++a) du[a] = (c == 6 + a) ? tr.us : (real)0;
     rk_tangent<real, INTEG, DIAGJ>(tr, st, b0, b1, b2, ex, du, out);
     gt_apply(qn, out[3], out[4], out[5], out[6], o);
-    for (int i = 0; i < 3; ++i) { F[c * FS + i] = out[i]; F[c * FS + 3 + i] = o[i]; }
+    for (int i = 0; i < 3; ++i) { F[c * FSS + i] = out[i]; F[c * FSS + 3 + i] = o[i]; }
   }
 }
 
@@ -758,12 +758,7 @@ TSAT_DEV void store_record5(TSAT_GLOBAL real* cr, const real x[7], const real u[
   typedef real v2 __attribute__((ext_vector_type(2)));
   typedef TSAT_GLOBAL v2* gv2;
   v2 a = {x[0], x[1]}, b = {x[2], x[3]}, c = {x[4], x[5]}, d = {x[6], u[0]}, e = {u[1], u[2]};
-#ifdef TSAT_NT_CAND   /* experiment: stream the candidate records past the caches */
-  __builtin_nontemporal_store(a, &((gv2)cr)[0]); __builtin_nontemporal_store(b, &((gv2)cr)[1]); __builtin_nontemporal_store(c, &((gv2)cr)[2]);
-  __builtin_nontemporal_store(d, &((gv2)cr)[3]); __builtin_nontemporal_store(e, &((gv2)cr)[4]);
-#else
   ((gv2)cr)[0] = a; ((gv2)cr)[1] = b; ((gv2)cr)[2] = c; ((gv2)cr)[3] = d; ((gv2)cr)[4] = e;
-#endif
 #endif
 }
 // wait until at most `n` vector-memory operations of the wave are outstanding, then order LDS traffic between the lanes. Loads

@@ -78,8 +78,17 @@ constexpr int PK_RING = (sizeof(cfg_real) == 8) ? 4 : 8;   // knots of every tra
 constexpr int PK_BC = 16;                         // lanes per trajectory in a backward pass
 constexpr int PK_BG = WAVE / PK_BC;               // trajectories per backward pass (4); a wave of PK_G trajectories takes PK_G / PK_BG passes
 static_assert(PK_G % PK_BG == 0 && PK_JCH == PK_BC, "Jacobian lanes: the 16 lanes of a trajectory linearise 16 knots");
-constexpr int PK_RECS = 84;                       // knot record: F = [A|B] column-major (70), lx (7), lu (3), luu (3), pad (1): 42 16-byte
-constexpr int PK_R_QQ = 9 * FS;                   //   units; error-state mode has nine columns and keeps G'QG (6) where the tenth would be
+// Knot record. Full state: F = [A|B] 7 x 10 column-major (70), lx (7), lu (3), luu (3), pad (1) = 84 reals. Error coordinates: F
+// 6 x 9 with column stride 6 (54; 48-byte columns: 16-byte LDS reads), G'QG (6), lx (6), lu (3), luu (3) = 72 reals. Both are
+// whole numbers of 16-byte units in either precision.
+template <int ES> struct PkRec {
+  static constexpr int FSR = ES ? 6 : FS;
+  static constexpr int QQ = 54;
+  static constexpr int LX = ES ? 60 : 70, LU = ES ? 66 : 77, LUU = ES ? 69 : 80;
+  static constexpr int RECS = ES ? 72 : 84;
+  static constexpr int SLOT = (WAVE / 16) * RECS;   // one ring slot: the records of ONE knot of the pass's four trajectories, contiguous
+};
+constexpr int PK_RECS = 84;                       // the larger of the two: LDS ring and workspace are sized for it
 constexpr int PK_GTRW = 88;                       // per-trajectory constants: staged parameter record (76), nu (8), pad
 constexpr int PK_GT_NU = 76;
 constexpr int PK_GXW = 88;                        // per-trajectory exchange block of the Riccati lanes:
@@ -87,11 +96,11 @@ constexpr int GX_S = 0;                           //   S~ as packed upper triang
 constexpr int GX_QU = 36;                         //   Quu (0,0)(0,1)(0,2)(1,1)(1,2)(2,2), Qu (3)
 constexpr int GX_XK = 46;                         //   per state column i: Qux(:,i) (3), K(:,i) (3)
 static_assert(GX_XK + 7 * 6 <= PK_GXW && PK_GXW % 2 == 0 && GX_XK % 2 == 0, "exchange block layout");
-static_assert(PK_RECS % RPU == 0, "a record is a whole number of 16-byte units");
+static_assert(PkRec<0>::RECS % RPU == 0 && PkRec<1>::RECS % RPU == 0 && PkRec<0>::RECS <= PK_RECS, "a record is a whole number of 16-byte units");
 constexpr int L_GTR = L_UNION;
 constexpr int L_GX = L_GTR + PK_BG * PK_GTRW;
 constexpr int L_GREC = L_GX + PK_BG * PK_GXW;
-constexpr int PK_SLOT = PK_BG * PK_RECS;          // one ring slot: the records of ONE knot of the pass's four trajectories, contiguous
+constexpr int PK_SLOT = PK_BG * PK_RECS;
 static_assert(L_GREC + PK_RING * PK_SLOT <= LDS_REALS, "joint backward sweep fits the wave's LDS block");
 constexpr int PK_JW_WAVE = PK_BG * PK_JCH * PK_RECS;    // workspace reals per wavefront (its passes of four trajectories share it)
 static_assert(PK_JW_WAVE == TSAT_JW_REALS_PER_4, "host allocation of a.JW");
@@ -379,18 +388,19 @@ TSAT_PHASE void jacobian16(const KArgs<real>& a, int traj0, TSAT_GLOBAL real* jw
   for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
   // the last PK_RING knots of the chunk are the first the recursion consumes: their lanes put the record straight into its
   // ring slot in LDS; the others go through the workspace (one code path for both: a generic pointer, flat stores)
-  real* rc = (kk >= PK_JCH - PK_RING) ? lds + L_GREC + (kk & (PK_RING - 1)) * PK_SLOT + g * PK_RECS
-                                      : (real*)(jw + (size_t)(g * PK_JCH + kk) * PK_RECS);
+  using R = PkRec<ES>;
+  real* rc = (kk >= PK_JCH - PK_RING) ? lds + L_GREC + (kk & (PK_RING - 1)) * R::SLOT + g * R::RECS
+                                      : (real*)(jw + (size_t)(g * PK_JCH + kk) * R::RECS);
   real lx[7];
   for (int i = 0; i < 7; ++i) lx[i] = tr.Qd[i] * (x[i] - tr.xf[i]);
   if (!ES) {
-    rk_jacobian_cols<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, rc + R_F, 0, 10);
+    rk_jacobian_cols<real, INTEG, DIAGJ, ES, real*, R::FSR>(tr, x, u, b0, b1, b2, rc, 0, 10);
   } else {
     // error coordinates: A^ = E(q_{k+1})' A E(q_k), B^ = E(q_{k+1})' B column by column (rk_jacobian_es_cols),
     // lx^ = E(q_k)' lx, Qxx^ = E(q_k)' Q E(q_k) (src/quaternion_toolbox.jl:15-36)
     real qk[4], qn[4];
     for (int i = 0; i < 4; ++i) { qk[i] = x[3 + i]; qn[i] = xu[XUW + 3 + i]; }
-    rk_jacobian_es_cols<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, qn, rc + R_F, 0, 9);
+    rk_jacobian_es_cols<real, INTEG, DIAGJ, real*, R::FSR>(tr, x, u, b0, b1, b2, qn, rc, 0, 9);
     {
       real o[3];
       gt_apply(qk, lx[3], lx[4], lx[5], lx[6], o);
@@ -404,14 +414,14 @@ TSAT_PHASE void jacobian16(const KArgs<real>& a, int traj0, TSAT_GLOBAL real* jw
         for (int l = j; l < 3; ++l) {
           real acc = 0;
           for (int r = 0; r < 4; ++r) acc += G[r][j] * tr.Qd[3 + r] * G[r][l];
-          rc[PK_R_QQ + idx++] = acc;
+          rc[R::QQ + idx++] = acc;
         }
     }
   }
-  for (int i = 0; i < 7; ++i) rc[R_LX + i] = lx[i];
+  for (int i = 0; i < BwdCfg<ES>::NH; ++i) rc[R::LX + i] = lx[i];
   real lu[3], luu[3];
   al_control_terms(tr, u, lam, mu, lu, luu);
-  for (int c = 0; c < 3; ++c) { rc[R_LU + c] = lu[c]; rc[R_LUU + c] = luu[c]; }
+  for (int c = 0; c < 3; ++c) { rc[R::LU + c] = lu[c]; rc[R::LUU + c] = luu[c]; }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -420,6 +430,18 @@ TSAT_PHASE void jacobian16(const KArgs<real>& a, int traj0, TSAT_GLOBAL real* jw
 // lanes and re-read from its exchange block after every knot. Per output element the operations are those of riccati_chunk.
 // `ok`: no Quu_reg of this trajectory has failed the PD test so far (group-uniform); returned updated.
 // --------------------------------------------------------------------------------------------------
+// n consecutive reals of LDS into registers. In double with `aligned` set (six-real rows that start on 16-byte boundaries: the
+// columns of an error-state record, the gain exchange rows) as 16-byte reads, two reals each.
+template <typename real, int n, int aligned>
+TSAT_DEV void lds_row(const real* p, real out[n]) {
+  if constexpr (aligned && sizeof(real) == 8 && n % 2 == 0) {
+    typedef real v2 __attribute__((vector_size(16)));
+    const v2* q = reinterpret_cast<const v2*>(p);
+    for (int t = 0; t < n / 2; ++t) { const v2 v = q[t]; out[2 * t] = v[0]; out[2 * t + 1] = v[1]; }
+  } else {
+    for (int m = 0; m < n; ++m) out[m] = p[m];
+  }
+}
 // wait until at most min(l, PK_RING - 1) copy sets of NCI instructions are outstanding (the immediate of s_waitcnt is a
 // compile-time constant: one case per possible count)
 template <int NCI, int M = PK_RING - 1>
@@ -453,22 +475,23 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
   const int rlo = helper ? rmain : 0, rhi = helper ? cx + 1 : (xmain ? rmain : 0);
   real* gx = lds + L_GX + g * PK_GXW;
   const real* Qd = lds + L_GTR + g * PK_GTRW + P_QD;
-  const real* recs = lds + L_GREC + g * PK_RECS;                   // this trajectory's record inside a ring slot
-  // copy lanes of the record ring: a slot (the records of one knot of the four trajectories, contiguous) is PK_SLOT / RPU
-  // 16-byte units; unit v belongs to trajectory v / (PK_RECS / RPU). Source of knot q: jw + (trajectory * 16 + q) * PK_RECS.
-  constexpr int UPR = PK_RECS / RPU, UPS = PK_SLOT / RPU, NCI = (UPS + WAVE - 1) / WAVE;
+  using R = PkRec<ES>;
+  const real* recs = lds + L_GREC + g * R::RECS;                   // this trajectory's record inside a ring slot
+  // copy lanes of the record ring: a slot (the records of one knot of the four trajectories, contiguous) is SLOT / RPU
+  // 16-byte units; unit v belongs to trajectory v / (RECS / RPU). Source of knot q: jw + (trajectory * 16 + q) * RECS.
+  constexpr int UPR = R::RECS / RPU, UPS = R::SLOT / RPU, NCI = (UPS + WAVE - 1) / WAVE;
   const TSAT_GLOBAL real* cp_src[NCI];
   bool cp_on[NCI];
   for (int i = 0; i < NCI; ++i) {
     const int v = lane + WAVE * i;
     cp_on[i] = v < UPS;
     const int vg = cp_on[i] ? v / UPR : 0, ve = cp_on[i] ? v - vg * UPR : 0;
-    cp_src[i] = jw + (size_t)vg * PK_JCH * PK_RECS + (size_t)ve * RPU;
+    cp_src[i] = jw + (size_t)vg * PK_JCH * R::RECS + (size_t)ve * RPU;
   }
   auto ring_copy = [&](int q) {          // knot q of the chunk into slot q % PK_RING; every lane with a unit copies, whatever its
-    real* slot = lds + L_GREC + (q & (PK_RING - 1)) * PK_SLOT;      // trajectory's state: the count of copies in flight is fixed
+    real* slot = lds + L_GREC + (q & (PK_RING - 1)) * R::SLOT;      // trajectory's state: the count of copies in flight is fixed
     for (int i = 0; i < NCI; ++i)
-      if (cp_on[i]) glds_put_at<real>(slot + GLDS * i, cp_src[i] + (size_t)q * PK_RECS);
+      if (cp_on[i]) glds_put_at<real>(slot + GLDS * i, cp_src[i] + (size_t)q * R::RECS);
   };
   // (knots 15 .. 12 of the chunk are in their slots already: their Jacobian lanes wrote them there)
   const int tmax = a.T - 1;
@@ -487,7 +510,7 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
     rv[r] = rlo + r < rhi;
     qdiag[r] = (i == cx && (!ES || i < 3)) ? Qd[i] : (real)0;
     const int aa = i - 3, bb = cx - 3;
-    qq_off[r] = (ES && i >= 3 && cx >= i) ? PK_R_QQ + (aa == 0 ? bb : (aa == 1 ? 2 + bb : 5)) : -1;
+    qq_off[r] = (ES && i >= 3 && cx >= i) ? R::QQ + (aa == 0 ? bb : (aa == 1 ? 2 + bb : 5)) : -1;
     s_off[r] = rv[r] ? GX_S + (i * NH - (i * (i - 1)) / 2 + (cx - i)) : GX_SINK;
   }
   // where the control lanes put Quu(a, jb), a <= jb, and Qu(jb)
@@ -508,10 +531,10 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
     // per step, NCI instructions each, none any more once l < PK_RING - 1 — may stay in flight, together with whatever gain
     // stores were issued behind them: vector-memory operations retire in issue order
     ring_wait<NCI>(l);
-    const real* rc = recs + (l & (PK_RING - 1)) * PK_SLOT;
+    const real* rc = recs + (l & (PK_RING - 1)) * R::SLOT;
     // step 1: column `col` of W~ = [S; s'] F
     real f[NH], W[NH + 1];
-    for (int m = 0; m < NH; ++m) f[m] = rc[col * FS + m];
+    lds_row<real, NH, ES>(rc + col * R::FSR, f);
     for (int r = 0; r < NH; ++r) {
       real acc = 0;
       for (int m = 0; m < NH; ++m) acc = fma_(Ss[(r <= m) ? sym_ut(r, m, NH) : sym_ut(m, r, NH)], f[m], acc);
@@ -526,21 +549,24 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
     // column, Quu(a, b) (used for a <= b) on the control lane b; Qu(b) = lu + B(:, b)' s on the control lanes
     real Qx[RMAX], Qh[3];
     for (int r = 0; r < RMAX; ++r) {
-      const real ini = rc[(qq_off[r] >= 0) ? qq_off[r] : R_LUU];        // (a finite word of the record when there is no G'QG term)
+      const real ini = rc[(qq_off[r] >= 0) ? qq_off[r] : R::LUU];       // (a finite word of the record when there is no G'QG term)
       real acc = qdiag[r] + ((qq_off[r] >= 0) ? ini : (real)0);
-      const real* fi = rc + ri[r] * FS;
+      real fi[NH];
+      lds_row<real, NH, ES>(rc + ri[r] * R::FSR, fi);
       for (int m = 0; m < NH; ++m) acc = fma_(fi[m], W[m], acc);
       Qx[r] = acc;
     }
     for (int aa = 0; aa < 3; ++aa) {
-      const real luu = rc[R_LUU + aa];
+      const real luu = rc[R::LUU + aa];
       real acc = (real)0 + ((umain && jb == aa) ? luu : (real)0);
-      for (int m = 0; m < NH; ++m) acc = fma_(rc[(NH + aa) * FS + m], W[m], acc);
+      real fb[NH];
+      lds_row<real, NH, ES>(rc + (NH + aa) * R::FSR, fb);
+      for (int m = 0; m < NH; ++m) acc = fma_(fb[m], W[m], acc);
       Qh[aa] = acc;
     }
     real Qu;
     {
-      real acc = (real)0 + rc[R_LU + jb];
+      real acc = (real)0 + rc[R::LU + jb];
       for (int m = 0; m < NH; ++m) acc = fma_(f[m], sv[m], acc);
       Qu = acc;
     }
@@ -591,8 +617,9 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
       const real* xk = gx + GX_XK;
       real Sn[RMAX];
       for (int r = 0; r < RMAX; ++r) {
-        real hi[3], ki[3];
-        for (int c = 0; c < 3; ++c) { hi[c] = xk[ri[r] * 6 + c]; ki[c] = xk[ri[r] * 6 + 3 + c]; }
+        real hk[6];
+        lds_row<real, 6, 1>(xk + ri[r] * 6, hk);
+        const real hi[3] = {hk[0], hk[1], hk[2]}, ki[3] = {hk[3], hk[4], hk[5]};
         real acc = Qx[r] + (real)0;
         real sy = 0, kk = 0;
         for (int c = 0; c < 3; ++c) {
@@ -604,7 +631,7 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
       }
       real sn;
       {   // s(col): the same formula with "column 7": hi = Qux(:, col), hj = Qu, ki = K(:, col), kj = d
-        real acc = rc[R_LX + cx] + W[NH];
+        real acc = rc[R::LX + cx] + W[NH];
         real sy = 0, kk = 0;
         for (int c = 0; c < 3; ++c) {
           sy += fma_(Qh[c], d[c], qu[c] * Kc[c]);
