@@ -285,6 +285,23 @@ def test_gpu_dense_and_wide_builds_agree(pkg, ol, solver):
         solver.set_kernel_variant(5)
 
 
+@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("es", [0, 1])
+def test_gpu_packed_builds_ragged_and_tiny_horizons(pkg, ol, solver, variant, es):
+    """the packed builds forced onto small odd batches: horizons of 2 ... 97 knots inside one batch (partial 16-knot passes,
+    record-ring tails), a trajectory count that fills neither the last wavefront nor its backward passes"""
+    b = pkg.slew_setup.workload_monte_carlo(T=13, N=97, seed=41 + es, degenerate_rd=0.03)
+    b.n_knots = np.array([97, 2, 3, 16, 17, 18, 33, 5, 96, 49, 64, 65, 4], dtype=np.int32)
+    o = oracle_options(ol, max_outer=2, max_inner=4, dj_counter_limit=1, error_state=es)
+    ref = ol.solve_batch(b, o, nthreads=8)
+    solver.set_kernel_variant(variant)
+    got = gpu_solve(pkg, solver, b, o)
+    solver.set_kernel_variant(0)
+    assert_same_solution(ref, got)
+    for t, n in enumerate(b.n_knots):
+        assert np.all(got["X"][t, n:] == 0) and np.all(got["U"][t, n - 1:] == 0)
+
+
 def test_gpu_one_call_abi_entry(pkg, ol, solver):
     """tsat_solve_batch: the single call a Julia `ccall` would make in place of solve!(prob, solver)"""
     lib, abi = pkg._abi.load(), pkg._abi
