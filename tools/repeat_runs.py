@@ -1,5 +1,9 @@
+"""Developer tool: the same 16384 x 1000 batch four times per build — do repeated runs give identical statuses and iteration
+totals? (This is how the store-counted s_waitcnt of the packed forward sweep was caught: under full memory load a store can
+retire before an older LDS copy.)   python tools/repeat_runs.py"""
 import os, sys
-sys.path.insert(0, '/root/repo')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np
 from tsat_loader import load_package
 pkg = load_package()
