@@ -22,8 +22,8 @@ s.upload(b, o.max_linesearch)
 for prec, var in ((32, 4), (32, 3), (64, 4), (64, 3)):
     o.precision = prec; s.set_kernel_variant(var)
     out=[]
-    for r in range(4):
+    for r in range(int(os.environ.get("REPS", "4"))):
         ms = s.run(o); st = s.download(want_K=False)["stats"]
-        out.append((round(ms,1), np.bincount(st['status'], minlength=4).tolist(), int(st['inner_iters'].sum())))
+        out.append((round(ms,1), np.bincount(st["status"], minlength=4).tolist(), int(st["inner_iters"].sum()), float(st["cost"].sum())))
     print(prec, var, out, flush=True)
 s.close()
