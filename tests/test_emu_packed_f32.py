@@ -31,7 +31,7 @@ def test_packed_build_is_the_same_solve(pkg, ol, emu, emu_packed, T, N, es, inte
 
 @pytest.mark.parametrize("T,N,es,integ", [(9, 18, 0, 4), (11, 34, 1, 3)])
 def test_packed8_build_is_the_same_solve(pkg, ol, emu, emu_packed8, T, N, es, integ):
-    """eight trajectories per wavefront (two backward passes of four, two-knot forward chunks), ragged horizons, partial groups"""
+    """eight trajectories per wavefront (two backward passes of four, one single-buffered forward chunk), ragged horizons, partial groups"""
     b = pkg.slew_setup.workload_monte_carlo(T=T, N=N, seed=500 + 7 * T + N, random_orbit=(T == 11))
     b.n_knots = np.array([N, 2, max(3, N // 2), N - 1, 3, N, N - 2, 7, N, N, 5, N, 4, N, N, 9, N][:T], dtype=np.int32)
     o = oracle_options(ol, max_outer=2, max_inner=4, dj_counter_limit=1, error_state=es, integrator=integ)

@@ -4,7 +4,7 @@
 // and register budget are per-kernel compile-time facts.
 //
 // Compiled twice: itself (PK_G = 4 trajectories per wavefront, from TSAT_PACKED_MIN_T trajectories on) and through
-// tsat_kernels_packed8.hip (PK_G = 8, two-knot forward chunks: one forward sweep serves eight trajectories, eight line-search
+// tsat_kernels_packed8.hip (PK_G = 8, one single-buffered four-knot forward chunk: one forward sweep serves eight trajectories, eight line-search
 // candidates each; pays once eight trajectories per wavefront still fill the machine, from 16384 trajectories on).
 #define TSAT_DENSE 1
 #define TSAT_PACKED 1
