@@ -155,8 +155,16 @@ int  tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms);
 int  tsat_batch_download(tsat_handle* h, double* X, double* U, double* K, tsat_stats* stats);
 /* unpack results to DEVICE buffers owned by the caller on the same GPU (any may be NULL); blocks */
 int  tsat_batch_export_device(tsat_handle* h, void* X_dev, void* U_dev, void* K_dev, void* stats_dev);
-/* bytes of HBM currently reserved by the handle */
+/* bytes of HBM currently reserved by the handle for the resident batch */
 int64_t tsat_batch_bytes(const tsat_handle* h);
+/* The stages around the solve (downloads, gathers, tracking, horizon, field tables, receding-horizon history) keep grow-only
+ * device workspaces in the handle so that repeated calls pay no allocation; after ONE large download or gather they hold
+ * multi-GB staging buffers for the life of the handle. tsat_workspace_bytes reports them; tsat_workspace_trim frees them:
+ *   what = 0  the staging buffers of tsat_batch_download and tsat_sweep_allgather only
+ *   what = 1  every workspace — including the resident field tables of tsat_btable_batch(Btab = NULL), which are then gone
+ * They are allocated again on the next call that needs them. */
+int64_t tsat_workspace_bytes(const tsat_handle* h);
+int  tsat_workspace_trim(tsat_handle* h, int32_t what);
 /* optional per-iteration trace for debugging parity: rows of 8 doubles
  * [outer, inner, J_prev, J_new, alpha_index(-1 = none), rho, dV1, dV2], `rows` per trajectory.
  * Pass rows = 0 to disable. Call before tsat_batch_run; read back with tsat_batch_trace_download. */
@@ -233,7 +241,7 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
 
 /* Build of the solve kernel used by tsat_batch_run / tsat_solve_batch / tsat_mpc_run. 0 = automatic (default), by batch size:
  *   1 wide    one trajectory per wavefront, one wavefront per SIMD (40 KB of LDS, full register file): up to 1024 trajectories;
- *   2 dense   one trajectory per wavefront, two wavefronts per SIMD (20 KB, 256 registers): up to 8191;
+ *   2 dense   one trajectory per wavefront, two wavefronts per SIMD (20 KB, 256 registers): 1025 .. 3071;
  *   3 packed  four trajectories per wavefront share every forward sweep (16 line-search candidates each) and run their
  *             backward sweeps together (Jacobian lanes = trajectory x knot x column quarter, Riccati recursion on 16 lanes per
  *             trajectory), two wavefronts per SIMD: from 3072 trajectories; with precision = 32 the float build of the same
@@ -271,6 +279,10 @@ int  tsat_tvlqr_resident(tsat_handle* h, const tsat_tvlqr_options* o, const doub
  * ------------------------------------------------------------------------------------------------------------ */
 int  tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t plant_integrator,
                   double* X_hist, double* U_hist, tsat_stats* stats_last, float* solve_ms);
+/* executed counts of the last tsat_mpc_run, summed over its control steps on the device: per trajectory
+ * [backward sweeps, forward sweeps, AL dual updates (outer_iters - 1), inner iterations]  (4 x T, int64) — what a measurement
+ * needs to price the loop's memory traffic without bringing per-step statistics to the host */
+int  tsat_mpc_tally(tsat_handle* h, int64_t* tally /* 4 x T */);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Sweep exchange across GPUs. The reference's Monte-Carlo is a serial loop whose iterations share nothing but the result
@@ -285,10 +297,16 @@ int  tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_
  *                         stats_all (world T) in rank order; any of the three may be NULL. on_device = 0: host buffers;
  *                         on_device = 1: device buffers of the caller on the handle's GPU. Blocks until the data is there.
  *   tsat_comm_destroy     releases the communicator (tsat_destroy does it too)
+ *   tsat_comm_available   0 when RCCL can be loaded in this process, -11 otherwise: a LOCAL probe without any communication, so that
+ *                         the ranks can agree (by their own means) to use this exchange before any of them enters the collective
+ *                         tsat_comm_init — a rank that fails on its own would leave the others waiting inside ncclCommInitRank
  * RCCL is loaded at the first tsat_comm_* call (librccl.so.1, or $TSAT_RCCL_LIB); the library has no link-time dependency
- * on it, error code -11 reports that it is missing or that a collective failed. Ragged totals: pad the last shard.
+ * on it, error code -11 reports that it is missing or that a collective failed. Every rank must hold a shard of the same
+ * shape (T, N) — ragged totals: pad the last shard; tsat_sweep_allgather verifies it with a 16-byte all-gather whenever the shape
+ * is new to the communicator and fails with -1 on EVERY rank when the shapes differ.
  * ------------------------------------------------------------------------------------------------------------ */
 #define TSAT_COMM_ID_BYTES 128
+int  tsat_comm_available(void);
 int  tsat_comm_unique_id(void* id_out /* TSAT_COMM_ID_BYTES */);
 int  tsat_comm_init(tsat_handle* h, const void* id /* TSAT_COMM_ID_BYTES */, int32_t rank, int32_t world);
 int  tsat_sweep_allgather(tsat_handle* h, void* X_all, void* U_all, void* stats_all, int32_t on_device);
@@ -345,7 +363,12 @@ int  tsat_bryson_eigen_axis_batch(int64_t T, const int32_t* n_knots, double t0, 
  * workspace) instead of downloading them; tsat_horizon_batch with Btab = NULL (same T, n_rows = 2 n_half) reads them there,
  * and tsat_batch_upload with Btab = NULL (n_btab = T, n_tab <= 2 n_half, btab_idx = NULL or identity) packs their first n_tab
  * rows into the solver's tables device to device — the Monte-Carlo's chain magnetic_simulation -> condition_based_time ->
- * magnetic_simulation -> solve! (src/monte_carlo.jl:134-196) without a table crossing PCIe. */
+ * magnetic_simulation -> solve! (src/monte_carlo.jl:134-196) without a table crossing PCIe.
+ * The resident tables are the LAST call's, identified to the NULL-Btab consumers by shape only: any later tsat_btable_batch on
+ * the handle replaces them (a failed or rejected call leaves none). tsat_btable_generation returns a counter that every
+ * tsat_btable_batch call (and a trim of the workspace) bumps: a host that interleaves table generations records it after its
+ * call and compares before the consuming call (tortoisesat.jl_amd/monte_carlo.py does). */
+int64_t tsat_btable_generation(const tsat_handle* h);
 int  tsat_btable_batch(tsat_handle* h, const tsat_btable_options* o, int64_t T, const double* kep, const double* t0,
                        const double* tf, double* Btab, double* pos);
 

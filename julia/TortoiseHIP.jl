@@ -8,7 +8,10 @@
 # eigen_axis_slew / Bryson weights stay in Julia exactly as the reference scripts have them; plain column-major arrays
 # cross the ABI (Julia's native layout — no copies).
 #
-# NOTE: no Julia toolchain exists in the authoring image; this file is syntax-reviewed only (DESIGN.md §1).
+# NOTE: no Julia toolchain exists in the authoring image, so this file has never been executed. What IS checked, in the CPU test
+# tier (tests/test_julia_shim.py): every `ccall` below names a function of include/tortoise_hip.h with the header's arity and
+# layout-compatible argument / return types, every header function is bound here, and the structs mirror the C structs field
+# for field (names, order, types, sizes).
 module TortoiseHIP
 
 const LIB = joinpath(@__DIR__, "..", "tortoisesat.jl_amd", "csrc", "libtortoise_hip.so")
@@ -63,7 +66,17 @@ mutable struct HIPSolver          # plays the role of AugmentedLagrangianSolver 
     end
 end
 
-"set_kernel_variant!(s, v) — 0 automatic, 1 wide (one wavefront per SIMD), 2 dense (two); results do not depend on it"
+"library / ABI version: major*100 + minor"
+version() = ccall((:tsat_version, LIB), Cint, ())
+
+"Options() as tsat_default_options fills them (the defaults above are the same numbers)"
+function default_options()
+    o = Options()
+    ccall((:tsat_default_options, LIB), Cvoid, (Ref{Options},), o)
+    return o
+end
+
+"set_kernel_variant!(s, v) — 0 automatic by batch size; 1 wide, 2 dense, 3 packed, 4 packed8 (fp64 results do not depend on it); 12-14 fp32 layouts"
 set_kernel_variant!(s::HIPSolver, v::Integer) =
     check(s, ccall((:tsat_set_kernel_variant, LIB), Cint, (Ptr{Cvoid}, Int32), s.handle, v), "tsat_set_kernel_variant")
 
@@ -124,6 +137,32 @@ function solve!(p::BatchProblem, s::HIPSolver)
     return p
 end
 
+"bytes of HBM reserved for the resident batch / held by the grow-only workspaces of the stages around the solve"
+batch_bytes(s::HIPSolver) = ccall((:tsat_batch_bytes, LIB), Int64, (Ptr{Cvoid},), s.handle)
+workspace_bytes(s::HIPSolver) = ccall((:tsat_workspace_bytes, LIB), Int64, (Ptr{Cvoid},), s.handle)
+"workspace_trim!(s; everything = false) — free the staging buffers of downloads / gathers (everything: all workspaces)"
+workspace_trim!(s::HIPSolver; everything::Bool = false) =
+    check(s, ccall((:tsat_workspace_trim, LIB), Cint, (Ptr{Cvoid}, Int32), s.handle, everything ? 1 : 0), "tsat_workspace_trim")
+
+"""
+trace!(s, rows) before solve!, then `trace(s, rows, T)` after it: per-iteration rows
+[outer, inner, J_prev, J_new, alpha_index (-1 = none), rho, dV1, dV2] :: 8×rows×T (debugging parity).
+"""
+trace!(s::HIPSolver, rows::Integer) = check(s, ccall((:tsat_batch_trace, LIB), Cint, (Ptr{Cvoid}, Int32), s.handle, rows), "tsat_batch_trace")
+function trace(s::HIPSolver, rows::Integer, T::Integer)
+    tr = zeros(8, rows, T)
+    check(s, ccall((:tsat_batch_trace_download, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), s.handle, tr), "tsat_batch_trace_download")
+    return tr
+end
+
+"""
+export_device!(s; X, U, K, stats) — unpack the resident results into DEVICE buffers the caller owns on the same GPU
+(raw pointers, e.g. from AMDGPU.jl's `pointer(roc_array)`; C_NULL = not wanted): the hand-off to a collective of the host's own.
+"""
+export_device!(s::HIPSolver; X::Ptr{Cvoid} = C_NULL, U::Ptr{Cvoid} = C_NULL, K::Ptr{Cvoid} = C_NULL, stats::Ptr{Cvoid} = C_NULL) =
+    check(s, ccall((:tsat_batch_export_device, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                   s.handle, X, U, K, stats), "tsat_batch_export_device")
+
 check(s::HIPSolver, rc, what) = rc == 0 ? nothing :
     error("$what failed ($rc): " * unsafe_string(ccall((:tsat_last_error, LIB), Cstring, (Ptr{Cvoid},), s.handle)))
 
@@ -138,6 +177,29 @@ Base.@kwdef mutable struct BtableOptions
     gm::Float64 = 3.986004418e5      # km^3/s^2, src/input_parameters.jl:26
     r_igrf_km::Float64 = 6771.0      # alt + R_E, src/magnetic_toolbox.jl:44,81
     date::Float64 = 2019.0           # src/magnetic_toolbox.jl:81
+end
+
+function default_btable_options()
+    o = BtableOptions()
+    ccall((:tsat_btable_default_options, LIB), Cvoid, (Ref{BtableOptions},), o)
+    return o
+end
+"counter bumped by every tsat_btable_batch on the handle: identifies the field tables left resident on the device"
+btable_generation(s::HIPSolver) = ccall((:tsat_btable_generation, LIB), Int64, (Ptr{Cvoid},), s.handle)
+
+"""
+bryson_eigen_axis_batch(n_knots, t0, dt, theta_f, axis, J; alpha, beta) — the loop body's script arithmetic for T slews between
+the same two attitudes that differ only in their horizon (src/eigen_axis_slew.jl:1-38 + src/monte_carlo.jl:161-176), batched
+on the host by the library. J :: 3×3 (symmetric: row- and column-major coincide). Returns Q 7×T, Qf 7×T, R 3×T diagonals.
+"""
+function bryson_eigen_axis_batch(n_knots::Vector{Int32}, t0::Float64, dt::Float64, theta_f::Float64, axis::Vector{Float64},
+                                 J::Matrix{Float64}; alpha::Float64 = 0.1, beta::Float64 = 1.0e3)
+    T = length(n_knots); Q = zeros(7, T); Qf = zeros(7, T); R = zeros(3, T)
+    rc = ccall((:tsat_bryson_eigen_axis_batch, LIB), Cint,
+        (Int64, Ptr{Int32}, Float64, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        T, n_knots, t0, dt, theta_f, axis, Matrix(transpose(J)), alpha, beta, Q, Qf, R)
+    rc == 0 || error("tsat_bryson_eigen_axis_batch failed ($rc): " * (rc == -2 ? "a guess has no positive torque sample" : "bad arguments"))
+    return Q, Qf, R
 end
 
 """
@@ -186,6 +248,12 @@ Base.@kwdef mutable struct TvlqrOptions
 end
 struct TvlqrStats
     slew_index::Int32; failed::Int32; slew_time::Float64; final_w_norm::Float64; final_angle::Float64
+end
+
+function default_tvlqr_options()
+    o = TvlqrOptions()
+    ccall((:tsat_tvlqr_default_options, LIB), Cvoid, (Ref{TvlqrOptions},), o)
+    return o
 end
 
 """
@@ -250,12 +318,21 @@ function receding_horizon!(s::HIPSolver, p::BatchProblem, n_steps::Integer; plan
     return Xh, Uh
 end
 
+"mpc_tally(s, T) — executed counts of the last receding_horizon! summed over its control steps: 4×T [backward, forward, dual updates, inner iterations]"
+function mpc_tally(s::HIPSolver, T::Integer)
+    t = zeros(Int64, 4, T)
+    check(s, ccall((:tsat_mpc_tally, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), s.handle, t), "tsat_mpc_tally")
+    return t
+end
+
 # ---- sweep exchange across GPUs (include/tortoise_hip.h: tsat_comm_*, tsat_sweep_allgather) ----------------------------------
 # One process per GPU (e.g. Distributed.jl workers or MPI ranks), each with its own HIPSolver and an equal shard of the sweep.
 # Rank 0 makes the 128-byte communicator id and sends it to the others by whatever the host uses; after solve! every rank calls
 # sweep_allgather and receives everybody's X (7 x N x world*T), U (3 x (N-1) x world*T) and stats in rank order — the result
 # lists the reference's serial loop appends to (src/monte_carlo.jl:52-66, 199-235), assembled by one RCCL all-gather over xGMI.
 const COMM_ID_BYTES = 128
+"local probe, no communication: can this process load RCCL behind the C ABI? Agree on it across ranks BEFORE anybody calls comm_init"
+comm_available() = ccall((:tsat_comm_available, LIB), Cint, ()) == 0
 function comm_unique_id()
     id = zeros(UInt8, COMM_ID_BYTES)
     rc = ccall((:tsat_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id)
@@ -289,5 +366,8 @@ function write_results(dir, n, A, sim_states, sim_control_inputs, B_ECI_total, t
         HDF5.h5write(joinpath(dir, "$(n)_t_total_$(i).h5"), "t_total", collect(t_total[i]))
     end
 end
+
+# Entry points of include/tortoise_hip.h deliberately left without a binding here (read by tests/test_julia_shim.py): none.
+const UNBOUND = Symbol[]
 
 end # module

@@ -131,7 +131,7 @@ extern "C" int emu_mpc_batch(const tsat_options* o, int64_t T, int64_t n_btab, c
   MpcArgs<double> m;
   m.T = (int)T; m.N = N; m.n_tab = n_tab; m.plant_integ = plant_integrator; m.n_steps = n_steps; m.us = o->u_scale;
   m.P = P.data(); m.BT = BT.data(); m.bidx = bidx.data(); m.nk = n_knots; m.XU = XU.data(); m.U0 = U0w.data();
-  m.HX = X_hist; m.HU = U_hist;
+  m.HX = X_hist; m.HU = U_hist; m.stats = nullptr; m.tally = nullptr;
   const int cls = inertia_class(T, Jmat);
   using blk_t = void (*)(const KArgs<double>&, int);
   static const blk_t variants[2][3][2] = {

@@ -47,3 +47,28 @@ def abi_options_like(o, pkg, N, n_tab):
     a = o.copy()
     a.n_knots, a.n_tab, a.precision = N, n_tab, 64
     return a
+
+
+def rk3_numpy(x, u, b):
+    """vectorised rk3 of the slew dynamics for (T, N-1, .) arrays; rows k, k, k+1 (dtau = 1, tau0 = 0)"""
+    Bt = b.Btab[b.btab_idx]                       # (T, n_tab, 3)
+    Jd = np.array([b.Jmat[0, 0], b.Jmat[0, 4], b.Jmat[0, 8]])   # diagonal inertia in this workload
+    h = 0.2
+
+    def f(x, bb):
+        w, q = x[..., :3], x[..., 3:]
+        q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+        s, v = q[..., :1], q[..., 1:]
+        qd = 0.5 * np.concatenate([-np.sum(v * w, -1, keepdims=True), s * w + np.cross(v, w)], -1)
+        BB = bb + 2 * np.cross(v, np.cross(v, bb) + s * bb)
+        tau = np.cross(u * 1e-2, BB)
+        wd = (tau - np.cross(w, Jd * w)) / Jd
+        return np.concatenate([wd, qd], -1)
+
+    n = x.shape[1]
+    b0 = Bt[:, :n]
+    b2 = Bt[:, 1:n + 1]
+    k1 = f(x, b0) * h
+    k2 = f(x + k1 / 2, b0) * h
+    k3 = f(x - k1 + 2 * k2, b2) * h
+    return x + (k1 + 4 * k2 + k3) / 6

@@ -32,9 +32,26 @@ inline double checksum(const std::vector<double>& v) {
   return s;
 }
 
+// SYNTH_T > 2 (solve-only drivers of the packed builds: full and partial groups of four / eight trajectories per wavefront):
+// trajectory t repeats the inputs of trajectory t % 2 with its own horizon and a perturbed initial attitude
+#ifndef SYNTH_T
+#define SYNTH_T 2
+#endif
+template <typename V> inline void tile2(V& v, int per, int T) {
+  v.resize((size_t)per * T);
+  for (int t = 2; t < T; ++t)
+    for (int i = 0; i < per; ++i) v[(size_t)t * per + i] = v[(size_t)(t % 2) * per + i];
+}
+
 inline int run(const Api& api, const tsat_options& defaults, const tsat_tvlqr_options& tv_defaults) {
-  const int T = 2, N = 40, NH = 24;                       // NH: half-length of the field tables (2 NH = 48 rows)
-  const int32_t nk[2] = {40, 33};                         // ragged: chunk boundaries of the forward (32) sweeps on both sides
+  const int T = SYNTH_T, N = 40, NH = 24;                 // NH: half-length of the field tables (2 NH = 48 rows)
+  // ragged: chunk boundaries of the forward (32) sweeps on both sides; shortest possible, one past a 16-knot pass, ...
+  const int32_t nk_all[12] = {40, 33, 2, 17, 40, 5, 29, 40, 16, 40, 3, 34};
+  static_assert(SYNTH_T >= 2 && SYNTH_T <= 12, "SYNTH_T");
+#ifndef SYNTH_SOLVE_ONLY
+  static_assert(SYNTH_T == 2, "the whole pipeline is laid out for two orbits; more trajectories only in the solve-only drivers");
+#endif
+  const int32_t* nk = nk_all;
   std::vector<double> kep = {0.0, 6771.0, 96.6, 30.0, 0.0, 40.0, 0.01, 6900.0, 51.6, 200.0, 10.0, 300.0};
   std::vector<double> t0 = {0.0, 5.0}, tf = {NH * 0.2, 5.0 + NH * 0.2};
   std::vector<double> B((size_t)T * 2 * NH * 3), pos((size_t)T * (2 * NH + 1) * 3);
@@ -60,6 +77,12 @@ inline int run(const Api& api, const tsat_options& defaults, const tsat_tvlqr_op
   std::vector<double> xf = {0, 0, 0, M_SQRT1_2, M_SQRT1_2, 0, 0, 0, 0, 0, M_SQRT1_2, M_SQRT1_2, 0, 0};
   std::vector<double> tau0 = {0, 1.5}, dtau = {1.0, 0.9}, dt = {0.2, 0.2};
   std::vector<double> J = {1.25e-3, 0, 0, 0, 1.25e-3, 0, 0, 0, 1.25e-3, 2.0e-3, 1.0e-4, -2.0e-4, 1.0e-4, 1.5e-3, 3.0e-4, -2.0e-4, 3.0e-4, 2.5e-3};
+  if (T > 2) {
+    tile2(x0, 7, T); tile2(xf, 7, T); tile2(tau0, 1, T); tile2(dtau, 1, T); tile2(dt, 1, T); tile2(J, 9, T);
+    for (int t = 2; t < T; ++t) {        // another initial attitude per trajectory (normalised inside the dynamics only)
+      x0[7 * t + 3] += 0.05 * t; x0[7 * t + 5] -= 0.03 * t; x0[7 * t + 0] = 1e-3 * t;
+    }
+  }
   std::vector<double> Qd(7 * T), Qfd(7 * T), Rd(3 * T, 0.03), ulo(3 * T, -19.0), uhi(3 * T, 19.0), U0((size_t)T * (N - 1) * 3);
   for (int t = 0; t < T; ++t)
     for (int i = 0; i < 7; ++i) { Qd[7 * t + i] = (i < 3) ? 40.0 : 100.0; Qfd[7 * t + i] = 10 * Qd[7 * t + i]; }

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg._abi.load()          # raises if libtortoise_hip.so is not built — there is no fallback
     for name in header_functions():
         assert hasattr(lib, name), name
-    assert lib.tsat_version() == 200
+    assert lib.tsat_version() == 300
 
 
 def test_struct_layouts_and_defaults(pkg, ol):

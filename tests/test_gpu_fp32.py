@@ -5,9 +5,13 @@ stops depends on every accept / reject decision of the line search on the way. C
 but the rolled-out states are float, so roughly nine in ten trajectories take at least one decision differently from the fp64
 oracle and end at a different point of the SAME descent. The bar is therefore stated in two parts, both asserted here:
 
-  * on the trajectories with the oracle's iteration and line-search counts (about one in six; equal counts still allow a
-    different accepted step here and there): |dX| < 1e-3 on >= 90 % of them (fp32 bar 1e-3; the worst of
-    them is a few 1e-3 to 1e-2);
+  * on the trajectories that follow the oracle's iteration PATH — the same accepted line-search index in every iteration, read
+    from the per-iteration traces of both (about one in eight) — |dX| < 1e-3 and |dU| < 5e-3 of the control scale on EVERY one
+    of them (fp32 bar 1e-3; measured worst 3.4e-4 / 1.8e-3). Equal iteration and line-search COUNTS are not the same thing: two solves can take index 1 at
+    iteration 3 and 0 at iteration 7 or the other way round; round 2 used the counts and reported such a trajectory (0.22 away
+    from the oracle) as a same-path outlier — tools/fp32_paths.py shows where its path leaves the oracle's;
+  * every float build gives the same bits: they contract a*b + c only where the source writes it in one expression
+    (`#pragma clang fp contract(on)` in the float translation units), so the packed builds are the one-trajectory float solve;
   * on all trajectories: status agreement >= 99 % (§8(d)), |dX| < 1e-3 on >= 85 %, median |dU| / scale < 1e-3, the
     achieved cost within 1e-4 relative on >= 90 %, and no loss of solution quality in the mean (cost and constraint
     violation within 1 % / 5 % of the oracle's batch means).
@@ -29,15 +33,28 @@ def solver(pkg):
     s.close()
 
 
-def _run32(pkg, solver, b, o, variant):
+TRACE_ROWS = 64
+
+
+def _run32(pkg, solver, b, o, variant, trace=False):
     import helpers
     a = helpers.abi_options_like(o, pkg, b.N, b.n_tab)
     a.precision = 32
     solver.set_kernel_variant(variant)
     solver.upload(b, a.max_linesearch)
+    solver.trace(TRACE_ROWS if trace else 0)
     solver.run(a)
     solver.set_kernel_variant(0)
-    return solver.download(want_K=False)
+    out = solver.download(want_K=False)
+    if trace:
+        out["trace"] = solver.trace_download()
+        solver.trace(0)
+    return out
+
+
+def _paths(trace):
+    """accepted line-search index of every iteration, (T, rows); rows beyond the last iteration marked"""
+    return np.where(trace[:, :, 1] > 0, trace[:, :, 4], -9).astype(np.int64)
 
 
 def _errors(ref, got):
@@ -66,13 +83,13 @@ def test_gpu_fp32_configs2_inputs_1000_knots(pkg, ol, solver):
     T = 512
     b = pkg.magnetic.attach_igrf_tables(solver, pkg.slew_setup.workload_monte_carlo(T=T, N=1000, seed=20190531, random_orbit=True, tables=False))
     o = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, error_state=1)
-    ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False)
+    ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False, trace_rows=TRACE_ROWS)
     layouts = {}
     for variant in (12, 14, 3, 4):
-        got = layouts[variant] = _run32(pkg, solver, b, o, variant)
+        got = layouts[variant] = _run32(pkg, solver, b, o, variant, trace=True)
         rs, gs = ref["stats"], got["stats"]
         dX, dU = _errors(ref, got)
-        same = (rs["inner_iters"] == gs["inner_iters"]) & (rs["ls_trials"] == gs["ls_trials"])
+        same = np.all(_paths(ref["trace"]) == _paths(got["trace"]), axis=1)          # the oracle's iteration path, step for step
         rel_cost = np.abs(gs["cost"] / rs["cost"] - 1)
         print(f"[fp32 layout {variant}] same path {same.mean():.3f}; status agreement {np.mean(rs['status'] == gs['status']):.3f}; "
               f"|dX|<1e-3 {np.mean(dX < 1e-3):.3f}; median |dU|/scale {np.median(dU):.2e}; same-path q90/max |dX| "
@@ -81,15 +98,19 @@ def test_gpu_fp32_configs2_inputs_1000_knots(pkg, ol, solver):
               f"{gs['c_max'].mean():.4g} vs {rs['c_max'].mean():.4g}")
         assert np.all(np.isfinite(got["X"])) and np.all(np.isfinite(got["U"]))
         assert np.mean(rs["status"] == gs["status"]) >= 0.99
-        assert same.sum() >= 8 and np.quantile(dX[same], 0.9) < 1e-3
+        # the fp32 bar on EVERY same-path trajectory: 1e-3 on the states (measured worst 3.4e-4), 5e-3 of the control scale (1.8e-3)
+        assert same.sum() >= 8 and dX[same].max() < 1e-3 and dU[same].max() < 5e-3
         assert np.mean(dX < 1e-3) >= 0.85 and np.median(dU) < 1e-3
         assert np.mean(rel_cost < 1e-4) >= 0.90
         assert abs(gs["cost"].mean() / rs["cost"].mean() - 1) < 0.01
         assert gs["c_max"].mean() < 1.05 * rs["c_max"].mean() + 1e-6
         qn = np.linalg.norm(got["X"][:, :, 3:7], axis=2)                 # the states are still attitudes
         assert np.max(np.abs(qn - 1)) < 1e-2
-    # the layouts differ in LDS chunking only: same arithmetic, same bits
-    assert np.array_equal(layouts[12]["X"], layouts[14]["X"]) and np.array_equal(layouts[12]["U"], layouts[14]["U"])
+    # one fp32 solve, whatever the build: LDS layouts, four or eight trajectories per wavefront — same arithmetic, same bits
+    for variant in (14, 3, 4):
+        assert np.array_equal(layouts[12]["X"], layouts[variant]["X"]) and np.array_equal(layouts[12]["U"], layouts[variant]["U"]), variant
+        for f in ("status", "outer_iters", "inner_iters", "ls_trials", "n_backward", "bp_restarts", "fp_fails", "cost", "c_max"):
+            assert np.array_equal(layouts[12]["stats"][f], layouts[variant]["stats"][f]), (variant, f)
 
 
 def test_gpu_fp32_then_fp64_on_the_same_upload(pkg, ol, solver):

@@ -371,7 +371,7 @@ def test_gpu_full_size_properties(pkg, ol, solver):
     # (3) x_{k+1} = rk3(x_k, u_k) along every trajectory (vectorised NumPy restatement of the step)
     X, U = g["X"], g["U"]
     assert np.array_equal(X[:, 0], b.x0)
-    xn = _rk3_numpy(X[:, :-1], U, b)
+    xn = helpers.rk3_numpy(X[:, :-1], U, b)
     assert np.max(np.abs(xn - X[:, 1:])) < 1e-12
     # (4) reported cost / violation match a recomputation from the returned arrays
     e = X - b.xf[:, None, :]
@@ -390,30 +390,6 @@ def test_gpu_full_size_properties(pkg, ol, solver):
         r = ol.solve_batch(b.slice(int(i), int(i) + 1), o)
         assert np.max(np.abs(r["X"][0] - X[i])) < 1e-9 and np.max(np.abs(r["U"][0] - U[i])) < 1e-9
         assert r["stats"]["inner_iters"][0] == st["inner_iters"][i]
-
-
-def _rk3_numpy(x, u, b):
-    """vectorised rk3 of the slew dynamics for (T, N-1, .) arrays; rows k, k, k+1 (dtau = 1, tau0 = 0)"""
-    Bt = b.Btab[b.btab_idx]                       # (T, n_tab, 3)
-    Jd = np.array([b.Jmat[0, 0], b.Jmat[0, 4], b.Jmat[0, 8]])   # diagonal inertia in this workload
-    h = 0.2
-
-    def f(x, bb):
-        w, q = x[..., :3], x[..., 3:]
-        q = q / np.linalg.norm(q, axis=-1, keepdims=True)
-        s, v = q[..., :1], q[..., 1:]
-        qd = 0.5 * np.concatenate([-np.sum(v * w, -1, keepdims=True), s * w + np.cross(v, w)], -1)
-        BB = bb + 2 * np.cross(v, np.cross(v, bb) + s * bb)
-        tau = np.cross(u * 1e-2, BB)
-        wd = (tau - np.cross(w, Jd * w)) / Jd
-        return np.concatenate([wd, qd], -1)
-
-    b0 = Bt[:, :-1]
-    b2 = Bt[:, 1:]
-    k1 = f(x, b0) * h
-    k2 = f(x + k1 / 2, b0) * h
-    k3 = f(x - k1 + 2 * k2, b2) * h
-    return x + (k1 + 4 * k2 + k3) / 6
 
 
 def test_gpu_example_script_runs(pkg):

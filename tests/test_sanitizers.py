@@ -2,7 +2,8 @@
 
   * the CPU oracle under AddressSanitizer + UndefinedBehaviorSanitizer, through every batch entry point;
   * the lane emulator of the HIP kernel source (64 host threads per wavefront, TSAT_SYNC / TSAT_SYNC_LDS = std::barrier)
-    under ThreadSanitizer, wide and dense build: the independent check that every cross-lane LDS / HBM hand-off of the
+    under ThreadSanitizer, every build of the solve kernel (wide, dense, packed with four / eight trajectories per wavefront —
+    record ring, hand-over tables, joint backward passes — and the float builds): the independent check that every cross-lane LDS / HBM hand-off of the
     kernels sits behind one of the two sync macros (DESIGN.md §3);
   * both run the same workload (tests/sanitize/synth.hpp) and print checksums, which must agree between oracle and
     emulated kernel.
@@ -50,7 +51,7 @@ def test_oracle_is_clean_under_asan_and_ubsan(oracle_run):
     assert "mpc X" in out
 
 
-@pytest.mark.parametrize("exe", ["emu_tsan", "emu_tsan_dense"])
+@pytest.mark.parametrize("exe", ["emu_tsan", "emu_tsan_dense", "emu_tsan_packed", "emu_tsan_packed8", "emu_tsan_packed_f32", "emu_tsan_f32"])
 def test_emulated_kernels_are_race_free_under_tsan(exe, oracle_run):
     _build(exe)
     rc, out, err = _run(exe, {"TSAN_OPTIONS": "halt_on_error=0:report_signal_unsafe=0"})
@@ -60,6 +61,7 @@ def test_emulated_kernels_are_race_free_under_tsan(exe, oracle_run):
         pytest.skip("ThreadSanitizer cannot map its shadow in this environment") if rc else None
     assert "ThreadSanitizer" not in err, err[-3000:]
     assert rc == 0
+    assert out.count("solve es=") == 4        # both state-difference modes x both integrators ran to the end
     if exe == "emu_tsan":                        # same workload as the oracle run: the checksums agree
         a, b = _numbers(oracle_run[1]), _numbers(out)
         assert a.keys() == b.keys() and len(a) >= 7

@@ -1,0 +1,31 @@
+"""Developer tool (GPU): iteration spread of a configs[3] shard — how the live trajectories of an 8192-trajectory shard thin out
+over the joint iterations, and what the launch would cost if the live ones were kept packed (an upper bound for any compaction)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from tsat_loader import load_package
+pkg = load_package()
+from tortoisesat_jl_amd import magnetic as mg, slew_setup as ss, trajopt as to
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = 3
+opts.opts_uncon.iterations = 50; opts.opts_uncon.dJ_counter_limit = 1
+s = to.AugmentedLagrangianSolver(None, opts)
+b = mg.attach_igrf_tables(s, ss.workload_inclination_sweep(T=T, N=1000, j0=3 * 8192, tables=False))
+o = opts.to_abi(b.N, b.n_tab, 3, error_state=1)
+s.upload(b, o.max_linesearch)
+for v in (0, 2, 3, 4):
+    s.set_kernel_variant(v)
+    ms = s.run(o); ms = s.run(o)
+    print(f"variant {v}: {ms:.1f} ms -> {T / ms * 1e3:.0f} solves/s")
+st = s.download(want_K=False)["stats"]
+it = st["inner_iters"].astype(int) + st["bp_restarts"]
+print("status counts", np.bincount(st["status"], minlength=4), "; inner iterations: min / q10 / median / mean / q90 / max",
+      it.min(), int(np.quantile(it, .1)), int(np.median(it)), f"{it.mean():.1f}", int(np.quantile(it, .9)), it.max())
+print("ls trials per iteration", st["ls_trials"].sum() / st["inner_iters"].sum(), "; fp_fails", st["fp_fails"].sum(), "; n_forward per iteration", st["n_forward"].sum() / st["inner_iters"].sum())
+live = np.array([(it > k).sum() for k in range(it.max() + 1)])
+print("live trajectories after k iterations:", {k: int(live[k]) for k in range(0, it.max() + 1, 10)})
+w4 = it.reshape(-1, 4).max(1)
+print(f"packed as launched: mean of per-wave maxima {w4.mean():.1f}, slowest wave {w4.max()} joint iterations; sum of iterations {it.sum()}")
+s.close()

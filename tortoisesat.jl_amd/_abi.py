@@ -94,12 +94,17 @@ PROTOTYPES = {
     "tsat_batch_download": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_void_p]),
     "tsat_batch_export_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tsat_batch_bytes": (C.c_int64, [C.c_void_p]),
+    "tsat_workspace_bytes": (C.c_int64, [C.c_void_p]),
+    "tsat_workspace_trim": (C.c_int, [C.c_void_p, C.c_int32]),
+    "tsat_btable_generation": (C.c_int64, [C.c_void_p]),
+    "tsat_comm_available": (C.c_int, []),
     "tsat_batch_trace": (C.c_int, [C.c_void_p, C.c_int32]),
     "tsat_batch_trace_download": (C.c_int, [C.c_void_p, _dp]),
     "tsat_set_kernel_variant": (C.c_int, [C.c_void_p, C.c_int32]),
     "tsat_tvlqr_resident": (C.c_int, [C.c_void_p, C.POINTER(TvlqrOptions), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p,
                                       C.POINTER(C.c_int64)]),
     "tsat_mpc_run": (C.c_int, [C.c_void_p, C.POINTER(Options), C.c_int32, C.c_int32, _dp, _dp, C.c_void_p, C.POINTER(C.c_float)]),
+    "tsat_mpc_tally": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "tsat_comm_unique_id": (C.c_int, [C.c_void_p]),
     "tsat_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "tsat_sweep_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),

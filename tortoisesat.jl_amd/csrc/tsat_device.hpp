@@ -64,6 +64,16 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 #define TSAT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// The float builds contract a*b + c ONLY where the source writes it in one expression (the language's own rule, decided by the front end
+// per expression): every float build — one trajectory per wavefront in its three LDS layouts, packed, packed8 — then rounds
+// the same source expression the same way and they agree bit for bit on the GPU as they do on the emulator. hipcc's default
+// (fast: the back end fuses across statements, differently in different code shapes) made the packed float builds differ from
+// the one-trajectory float build by rounding, which a budget-limited solve amplifies into another iteration path on five
+// trajectories in six. The double builds keep the default: their fused operations are spelled out where a choice exists.
+#if defined(TSAT_F32) && !defined(TSAT_EMU)
+#pragma clang fp contract(on)
+#endif
+
 namespace tsat {
 
 // Storage / arithmetic type of the translation unit's solve kernel: double (tsat_kernels.hip, tsat_kernels_dense.hip) or
@@ -103,23 +113,39 @@ enum { P_X0 = 0, P_XF = 7, P_QD = 14, P_QFD = 21, P_RD = 28, P_ULO = 31, P_UHI =
        // floor(fma(k + c, dtau, tau0)) in double whatever the storage type, so a float record carries tau0 and dtau as
        // (hi, lo) pairs; zero in a double record
        P_TAU0L = 61, P_DTAUL = 62 };
-// Jacobian record left in LDS per knot (reals): F=[A|B] column-major (column stride FS = 7), then gradients.
-// error_state = 1 appends the projected attitude block of the stage Hessian (6 unique entries of G'QG).
+// Jacobian record of one knot (reals), left in LDS by the Jacobian lanes for the Riccati lanes (one-trajectory builds) or sent
+// through the wavefront's workspace and the record ring (packed builds, tsat_packed.hpp) — one layout for both:
+//   full state        F = [A|B] 7 x 10 column-major, column stride 7 (70), lx (7), lu (3), luu (3), pad (1)            = 84 reals
+//   error coordinates F^ = [A^|B^] 6 x 9, column stride 6 (54; 48-byte columns: 16-byte LDS reads), G'QG upper triangle (6),
+//                     lx^ (6), lu (3), luu (3)                                                                        = 72 reals
+// Both are whole numbers of 16-byte units in either precision.
 constexpr int FS = 7;
-constexpr int R_F = 0, R_LX = 70, R_LU = 77, R_LUU = 80, R_QQ = 83;
+template <int ES> struct PkRec {
+  static constexpr int FSR = ES ? 6 : FS;
+  static constexpr int QQ = 54;
+  static constexpr int LX = ES ? 60 : 70, LU = ES ? 66 : 77, LUU = ES ? 69 : 80;
+  static constexpr int RECS = ES ? 72 : 84;
+  static constexpr int SLOT = (64 / 16) * RECS;   // packed builds: one ring slot = the records of ONE knot of a pass's four trajectories
+};
+// the tracking kernel (tvlqr_trajectory) reduces a full-state record in place: error-state blocks with the full-state strides
+struct TvRec {
+  static constexpr int FSR = FS, LX = 70, LU = 77, LUU = 80, QQ = 83, RECS = 89;
+};
+constexpr int TV_CHB = 52;                     // knots per chunk of the tracking kernel's gain recursion (wide build only)
 template <int ES> struct BwdCfg {
   static constexpr int NH = ES ? 6 : 7;        // dimension of the state difference the gains act on
-  static constexpr int RECS = ES ? 89 : 83;    // reals per knot record
+  static constexpr int RECS = PkRec<ES>::RECS; // reals per knot record
+  // knots per backward chunk = Jacobian lanes per pass: as many as the LDS budget of the build holds, 64 at most
 #if defined(TSAT_F32)
   // fp32 build: 4-byte records plus the 512-byte double reduction scratch inside the budget of TSAT_OCC waves per SIMD
-  static constexpr int CHB = (TSAT_OCC == 2) ? (ES ? 51 : 55) : (TSAT_OCC == 3) ? (ES ? 31 : 33) : (ES ? 22 : 24);
+  static constexpr int CHB = (TSAT_OCC == 2) ? (ES ? 63 : 54) : (TSAT_OCC == 3) ? (ES ? 39 : 34) : (ES ? 27 : 23);
 #elif defined(TSAT_DENSE)
   // "dense" build of the solve kernel (tsat_kernels_dense.hip) for batches of more than one wave per SIMD: 8 waves x
   // <= 20 KB per CU and <= 256 registers, so that two trajectories share a SIMD (1.45x fp64 issue); the price is
-  // 25-knot Jacobian chunks and 88 spilled registers, 11 % per wave
-  static constexpr int CHB = ES ? 23 : 25;
+  // 25 / 29-knot Jacobian chunks and 88 spilled registers, 11 % per wave
+  static constexpr int CHB = ES ? 29 : 25;
 #else
-  static constexpr int CHB = ES ? 52 : 56;     // knots per backward chunk: 4 waves x <= 40.6 KB fit one CU
+  static constexpr int CHB = ES ? 64 : 55;     // 4 waves x <= 40.6 KB fit one CU
 #endif
 };
 // forward-sweep chunk arrays
@@ -182,27 +208,32 @@ constexpr int L_SINK = L_ZERO + 1;       // write target of lanes without a role
 constexpr int L_UNION = L_SINK + 1;      // 424 (16-byte aligned)
 static_assert(L_UNION % 2 == 0, "phase buffers must stay 16-byte aligned");
 constexpr int L_REC = L_UNION;           // BwdCfg::CHB x BwdCfg::RECS
-// Forward-sweep chunk buffer (reals). The first five arrays are filled by global_load_lds_dwordx4 — 64 lanes x 16 bytes
-// = 128 reals per instruction, lane-linear — so each is padded to a whole number of instructions; FB_GT (activity gates
-// of the control-box rows, see forward_sweep) is derived from FB_LM once the copy has landed.
+// Forward-sweep chunk buffer (reals). The arrays are filled by global_load_lds_dwordx4 — 64 lanes x 16 bytes
+// = 128 reals per instruction, lane-linear — so each is padded to a whole number of instructions. (The control-box multipliers
+// are not staged: the roll-out does not evaluate costs, candidate_costs does, with lanes = knots.)
 constexpr int GLDS = RPU * WAVE;                                       // reals per copy instruction
 constexpr int BROW_UNITS = 4 / RPU;                                    // 16-byte units per 4-real field-table row: 2 | 1
 constexpr int FB_KD = 0;                                               // CK x 24 = 6 instructions
 constexpr int FB_XU = FB_KD + ((CK * KDW + GLDS - 1) / GLDS) * GLDS;   // CK x 10 -> 3 instructions
-constexpr int FB_LM = FB_XU + ((CK * XUW + GLDS - 1) / GLDS) * GLDS;   // CK x 6  -> 2 instructions
-constexpr int FB_BA = FB_LM + ((CK * LMW + GLDS - 1) / GLDS) * GLDS;   // 3 CK stage rows: (b0, b1) [double] or the whole row (b0, b1, b2, pad) [float]
+constexpr int FB_BA = FB_XU + ((CK * XUW + GLDS - 1) / GLDS) * GLDS;   // 3 CK stage rows: (b0, b1) [double] or the whole row (b0, b1, b2, pad) [float]
 constexpr int FB_BB = FB_BA + ((CK * 3 * RPU + GLDS - 1) / GLDS) * GLDS; // 3 CK stage rows, (b2, pad) [double only]
-constexpr int FB_GT = FB_BB + (BROW_UNITS == 2 ? ((CK * 3 * RPU + GLDS - 1) / GLDS) * GLDS : 0); // CK x 6
-constexpr int FB_SIZE = FB_GT + CK * LMW;
+constexpr int FB_SIZE = FB_BB + (BROW_UNITS == 2 ? ((CK * 3 * RPU + GLDS - 1) / GLDS) * GLDS : 0);
+// candidate_costs: per-knot costs of CG candidates x KB knots (+2: the CG summing lanes read different banks)
+constexpr int CG = 4, KB = 4 * WAVE, KBS = KB + 2;
 #if defined(TSAT_DENSE) || (defined(TSAT_F32) && TSAT_OCC >= 3)
 constexpr int FWD_NBUF = 1;   // 20 KB budget: one buffer; the second wavefront on the SIMD covers the copy latency
 #else
 constexpr int FWD_NBUF = 2;   // the next chunk is copied while this one is rolled out
 #endif
 constexpr int L_FWD = L_UNION;
-constexpr int L_FWD_END = L_FWD + FWD_NBUF * FB_SIZE;
-constexpr int L_BWD_END = L_REC + (BwdCfg<0>::CHB * BwdCfg<0>::RECS > BwdCfg<1>::CHB * BwdCfg<1>::RECS
-                                    ? BwdCfg<0>::CHB * BwdCfg<0>::RECS : BwdCfg<1>::CHB * BwdCfg<1>::RECS);
+constexpr int L_FWD_END = L_FWD + (FWD_NBUF * FB_SIZE > CG * KBS ? FWD_NBUF * FB_SIZE : CG * KBS);
+constexpr int L_BWD_SOLVE = (BwdCfg<0>::CHB * BwdCfg<0>::RECS > BwdCfg<1>::CHB * BwdCfg<1>::RECS
+                                ? BwdCfg<0>::CHB * BwdCfg<0>::RECS : BwdCfg<1>::CHB * BwdCfg<1>::RECS);
+#if !defined(TSAT_DENSE) && !defined(TSAT_F32)
+constexpr int L_BWD_END = L_REC + (L_BWD_SOLVE > TV_CHB * TvRec::RECS ? L_BWD_SOLVE : TV_CHB * TvRec::RECS);   // + the tracking kernel
+#else
+constexpr int L_BWD_END = L_REC + L_BWD_SOLVE;
+#endif
 #if defined(TSAT_PACKED)
 // packed build (tsat_packed.hpp): its own carve-up behind L_UNION, sized to the 20 480 B of two wavefronts per SIMD (fp64) or
 // to TSAT_PK_LDS_BYTES (the fp32 packed build: three wavefronts per SIMD, tsat_kernels_packed_f32.hip)
@@ -804,21 +835,20 @@ TSAT_DEV void fwd_brows(const real* fb, int kk, real b0[3], real b1[3], real b2[
 }
 
 // Issue the copy of one forward chunk (knots k0 .. k0 + nk - 1) into the chunk buffer `fb`: gains K,d (closed-loop sweeps),
-// nominal (x,u) records, control-box multipliers and the three field rows of every step. On the GPU these are
+// nominal (x,u) records and the three field rows of every step. On the GPU these are
 // global_load_lds_dwordx4 instructions: no VGPR destination (the sweep is at the register cap) and no wait — the data is
 // guaranteed in LDS after the next vmcnt(0) (TSAT_SYNC). A lane past the end of a short last chunk copies the last element
 // again into the padding. The emulator copies synchronously.
 template <typename real>
-TSAT_DEV void fwd_chunk_issue(real* fb, const TSAT_GLOBAL real* KDg, const TSAT_GLOBAL real* XUg, const TSAT_GLOBAL real* LMg,
+TSAT_DEV void fwd_chunk_issue(real* fb, const TSAT_GLOBAL real* KDg, const TSAT_GLOBAL real* XUg,
                               const Traj<real>& tr, int k0, int nk, int closed) {
   static_assert(sizeof(real) == sizeof(cfg_real), "16-byte copy units are RPU reals");
   const int lane = TSAT_LANE();
   // in 16-byte units, rounded up: a float chunk of an odd number of 40- / 24-byte records ends inside a unit whose tail is
   // the next record (x,u: the terminal knot's record exists) or the slab's alignment padding (multipliers)
-  const int n2k = (nk * KDW + RPU - 1) / RPU, n2x = (nk * XUW + RPU - 1) / RPU, n2l = (nk * LMW + RPU - 1) / RPU, nb = nk * 3;
+  const int n2k = (nk * KDW + RPU - 1) / RPU, n2x = (nk * XUW + RPU - 1) / RPU, nb = nk * 3;
   const TSAT_GLOBAL real* kd = KDg + (size_t)k0 * KDW;
   const TSAT_GLOBAL real* xu = XUg + (size_t)k0 * XUW;
-  const TSAT_GLOBAL real* lm = LMg + (size_t)k0 * LMW;
   auto put = [&](real* dst, const TSAT_GLOBAL real* src) { glds_put<real>(dst, src); };
   if (closed)
     for (int j = 0; j < (CK * KDW + GLDS - 1) / GLDS; ++j) {
@@ -829,10 +859,6 @@ TSAT_DEV void fwd_chunk_issue(real* fb, const TSAT_GLOBAL real* KDg, const TSAT_
     const int i = lane + WAVE * j, ic = (i < n2x) ? i : n2x - 1;
     put(fb + FB_XU + RPU * i, xu + RPU * ic);
   }
-  for (int j = 0; j < (CK * LMW + GLDS - 1) / GLDS; ++j) {
-    const int i = lane + WAVE * j, ic = (i < n2l) ? i : n2l - 1;
-    put(fb + FB_LM + RPU * i, lm + RPU * ic);
-  }
   for (int j = 0; j < (CK * 3 * RPU + GLDS - 1) / GLDS; ++j) {
     const int e = lane + WAVE * j, ec = (e < nb) ? e : nb - 1;
     const int kk = ec / 3, st = ec - 3 * kk;
@@ -841,22 +867,18 @@ TSAT_DEV void fwd_chunk_issue(real* fb, const TSAT_GLOBAL real* KDg, const TSAT_
     if (BROW_UNITS == 2) put(fb + FB_BB + RPU * e, br + 2);
   }
 }
-// once the copy has landed: gate = -inf where the multiplier is positive (row active whatever c is), else 0
-template <typename real>
-TSAT_DEV void fwd_chunk_gates(real* fb, int nk) {
-  for (int e = TSAT_LANE(); e < nk * LMW; e += WAVE) fb[FB_GT + e] = (fb[FB_LM + e] > 0) ? -inf_<real>() : (real)0;
-}
-
 template <typename real> struct FwdOut { acc_t J; int ok; };
 template <typename real> struct BwdOut { acc_t dV1, dV2; int pd_ok; };
 
 // --------------------------------------------------------------------------------------------------
-// forward sweep: all line-search candidates at once (lane j: alpha = 2^-j). Returns this lane's AL cost and
-// whether its rollout stayed within max_state. Candidate knot records go to CAND[lane].
+// forward sweep: all line-search candidates at once (lane j: alpha = 2^-(j + alpha_shift)). The first n_cand lanes keep their
+// roll-outs in HBM (CAND[lane]); NOTHING else is computed in the sequential loop — the AL cost and the validity of a candidate are
+// evaluated afterwards from its stored records with lanes = knots (candidate_costs), 64 knots per instruction instead of one: the
+// per-knot cost terms were a fifth of the loop's instructions, on the critical path of the launch, and only the first candidates
+// of a sweep ever need them.
 // --------------------------------------------------------------------------------------------------
 template <typename real, int INTEG, int DIAGJ, int ES>
-TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_cand, int alpha_shift,
-                                      real mu, int term_mask, real max_state) {
+TSAT_FWD void forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_cand, int alpha_shift) {
   real* lds = lds_base<real>();
   const Traj<real> tr = load_traj<real>(N, n_tab, p.bt);
   const int lane = TSAT_LANE();
@@ -864,33 +886,22 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
   for (int j = 0; j < lane + alpha_shift && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (real)0.5;
   real x[7];
   for (int i = 0; i < 7; ++i) x[i] = lds[L_TR + P_X0 + i];
-  acc_t J = 0;
-  real amax = 0;
   const TSAT_GLOBAL real* XUg = p.XU;
   const TSAT_GLOBAL real* KDg = p.KD;
-  const TSAT_GLOBAL real* LMg = p.LAM;
   TSAT_GLOBAL real* Cg = p.CAND + (size_t)(lane < n_cand ? lane : 0) * (size_t)N * XUW;
-  HalfWeights<real> hw;
-  for (int i = 0; i < 7; ++i) hw.hQd[i] = (real)0.5 * tr.Qd[i];
-  for (int i = 0; i < 3; ++i) hw.hRd[i] = (real)0.5 * tr.Rd[i];
-  hw.hmu = (real)0.5 * mu;
   // chunk pipeline: buffer `cur` holds the chunk being rolled out; with two buffers the copy of the next chunk is issued
-  // before the roll-out and has landed long before it ends (32 knots ~ 35 us against ~1 us of memory latency)
+  // before the roll-out and has landed long before it ends (32 knots ~ 30 us against ~1 us of memory latency)
   int cur = 0;
-  fwd_chunk_issue<real>(lds + L_FWD, KDg, XUg, LMg, tr, 0, (N - 1 < CK) ? N - 1 : CK, closed);
+  fwd_chunk_issue<real>(lds + L_FWD, KDg, XUg, tr, 0, (N - 1 < CK) ? N - 1 : CK, closed);
   TSAT_SYNC();
-  fwd_chunk_gates<real>(lds + L_FWD, (N - 1 < CK) ? N - 1 : CK);
-  TSAT_SYNC_LDS();
   for (int k0 = 0; k0 < N - 1; k0 += CK) {
     const int nk = (N - 1 - k0 < CK) ? (N - 1 - k0) : CK;
     const int kn = k0 + CK, nkn = (N - 1 - kn < CK) ? (N - 1 - kn) : CK;     // next chunk (nkn <= 0: none)
     real* fb = lds + L_FWD + cur * FB_SIZE;
     real* fbn = lds + L_FWD + ((FWD_NBUF == 2) ? (1 - cur) : 0) * FB_SIZE;
-    if (FWD_NBUF == 2 && nkn > 0) fwd_chunk_issue<real>(fbn, KDg, XUg, LMg, tr, kn, nkn, closed);
+    if (FWD_NBUF == 2 && nkn > 0) fwd_chunk_issue<real>(fbn, KDg, XUg, tr, kn, nkn, closed);
     const real* KDc = fb + FB_KD;
     const real* XUc = fb + FB_XU;
-    const real* LMc = fb + FB_LM;
-    const real* GTc = fb + FB_GT;
     for (int kk = 0; kk < nk; ++kk) {
       const real* xu = XUc + kk * XUW;
       real u[3] = {xu[7], xu[8], xu[9]};
@@ -917,9 +928,6 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
           u[c] = v + alpha * kd[21 + c];
         }
       }
-      for (int i = 0; i < 7; ++i) amax = fmaxabs_(amax, x[i]);
-      for (int c = 0; c < 3; ++c) amax = fmaxabs_(amax, u[c]);
-      J += (acc_t)stage_cost_gated(tr, hw, x, u, LMc + kk * LMW, GTc + kk * LMW);
       if (lane < n_cand) {
         TSAT_GLOBAL real* cr = Cg + (size_t)(k0 + kk) * XUW;
         for (int i = 0; i < 7; ++i) cr[i] = x[i];
@@ -933,26 +941,95 @@ TSAT_FWD FwdOut<real> forward_sweep(TPtrs<real> p, int N, int n_tab, int closed,
     if (nkn > 0) {
       if (FWD_NBUF == 1) {          // single buffer: copy the next chunk now that this one has been consumed
         TSAT_SYNC_LDS();
-        fwd_chunk_issue<real>(fbn, KDg, XUg, LMg, tr, kn, nkn, closed);
+        fwd_chunk_issue<real>(fbn, KDg, XUg, tr, kn, nkn, closed);
       }
       TSAT_SYNC();                  // vmcnt(0): the copy issued before (or just after) the roll-out has landed
-      fwd_chunk_gates<real>(fbn, nkn);
-      TSAT_SYNC_LDS();
       if (FWD_NBUF == 2) cur = 1 - cur;
     }
   }
-  for (int i = 0; i < 7; ++i) amax = fmaxabs_(amax, x[i]);
-  real nu[7];
-  for (int i = 0; i < 7; ++i) nu[i] = lds[L_NU + i];
-  J += (acc_t)term_cost(tr, x, nu, mu, term_mask, true);
   if (lane < n_cand) {
     TSAT_GLOBAL real* cr = Cg + (size_t)(N - 1) * XUW;
     for (int i = 0; i < 7; ++i) cr[i] = x[i];
     for (int c = 0; c < 3; ++c) cr[7 + c] = 0;
   }
+}
+
+// AL cost and validity of the stored candidates c0 .. c0 + nc - 1 (nc <= CG) of the sweep just finished, for lane c < nc the
+// candidate c0 + c. Lanes = knots: every lane evaluates the stage cost of its knots of each candidate (the very arithmetic the
+// packed builds run inside their sequential sweeps: stage_cost_gated on the stored record) and leaves it in LDS, KB knots at a
+// time; lane c then adds candidate c's costs IN KNOT ORDER, so J is, bit for bit, the sum a sequential roll-out accumulates. A
+// roll-out is valid when no |x_i|, |u_i| exceeded max_state and J is a number (a non-finite roll-out leaves amax = inf or J = NaN).
+template <typename real>
+TSAT_PHASE FwdOut<real> candidate_costs(TPtrs<real> p, int N, int c0, int nc, real mu, int term_mask, real max_state) {
+  real* lds = lds_base<real>();
+  const Traj<real> tr = load_traj<real>(N, 1, p.bt);
+  const int lane = TSAT_LANE();
+  HalfWeights<real> hw;
+  for (int i = 0; i < 7; ++i) hw.hQd[i] = (real)0.5 * tr.Qd[i];
+  for (int i = 0; i < 3; ++i) hw.hRd[i] = (real)0.5 * tr.Rd[i];
+  hw.hmu = (real)0.5 * mu;
+  real* L = lds + L_FWD;                       // [CG][KBS]
+  real am[CG];
+  for (int c = 0; c < CG; ++c) am[c] = 0;
+  acc_t J = 0;
+  const int cme = (lane < nc) ? lane : 0;
+  constexpr int KPL = KB / WAVE;               // knots per lane and block
+  for (int k0 = 0; k0 < N; k0 += KB) {
+    // multipliers and activity gates of this lane's knots: the same for every candidate
+    real lam[KPL][6], gate[KPL][6];
+    for (int i = 0; i < KPL; ++i) {
+      const int k = k0 + lane + WAVE * i, kc = (k < N - 1) ? k : 0;
+      for (int e = 0; e < 6; ++e) { lam[i][e] = p.LAM[(size_t)kc * LMW + e]; gate[i][e] = (lam[i][e] > 0) ? -inf_<real>() : (real)0; }
+    }
+    for (int c = 0; c < CG; ++c) {
+      if (c >= nc) break;
+      const TSAT_GLOBAL real* Cg = p.CAND + (size_t)(c0 + c) * (size_t)N * XUW;
+      // all KPL records of the candidate in flight at once (one exposed memory latency per candidate and block)
+      real r[KPL][10];
+      for (int i = 0; i < KPL; ++i) {
+        const int k = k0 + lane + WAVE * i, kc = (k < N) ? k : N - 1;
+        for (int e = 0; e < 10; ++e) r[i][e] = Cg[(size_t)kc * XUW + e];
+      }
+      real a = am[c];
+      for (int i = 0; i < KPL; ++i) {
+        const int k = k0 + lane + WAVE * i;
+        if (k < N)
+          for (int e = 0; e < 7; ++e) a = fmaxabs_(a, r[i][e]);
+        if (k < N - 1) {
+          for (int e = 7; e < 10; ++e) a = fmaxabs_(a, r[i][e]);
+          L[c * KBS + lane + WAVE * i] = stage_cost_gated(tr, hw, r[i], r[i] + 7, lam[i], gate[i]);
+        }
+      }
+      am[c] = a;
+    }
+    TSAT_SYNC_LDS();
+    if (lane < nc) {
+      // candidate `lane`'s costs in knot order: the reads of a batch are issued together, the adds stay one dependent chain
+      const int n = (N - 1 - k0 < KB) ? (N - 1 - k0) : KB;
+      const real* Lc = L + cme * KBS;
+      int kk = 0;
+      for (; kk + 16 <= n; kk += 16) {
+        real v[16];
+        for (int e = 0; e < 16; ++e) v[e] = Lc[kk + e];
+        for (int e = 0; e < 16; ++e) J += (acc_t)v[e];
+      }
+      for (; kk < n; ++kk) J += (acc_t)Lc[kk];
+    }
+    TSAT_SYNC_LDS();
+  }
+  real amax = 0;
+  for (int c = 0; c < CG; ++c) {
+    if (c >= nc) break;
+    const real m = wave_max(am[c], lds + L_RED);
+    amax = (lane == c) ? m : amax;
+  }
+  real nu[7], xN[7];
+  const TSAT_GLOBAL real* cN = p.CAND + ((size_t)(c0 + cme) * (size_t)N + (size_t)(N - 1)) * XUW;
+  for (int i = 0; i < 7; ++i) { nu[i] = lds[L_NU + i]; xN[i] = cN[i]; }
+  J += (acc_t)term_cost(tr, xN, nu, mu, term_mask, true);
   FwdOut<real> out;
   out.J = J;
-  out.ok = ((amax <= max_state) && (J == J)) ? 1 : 0;   // a non-finite rollout leaves amax = inf or J = NaN
+  out.ok = (lane < nc && (amax <= max_state) && (J == J)) ? 1 : 0;
   return out;
 }
 
@@ -992,16 +1069,17 @@ TSAT_PHASE void jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, 
     const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
     const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
     for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
-    real* rc = lds + L_REC + lane * BwdCfg<ES>::RECS;
+    using R = PkRec<ES>;
+    real* rc = lds + L_REC + lane * R::RECS;
     if (!ES) {
-      rk_jacobian<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, rc + R_F);
-      for (int i = 0; i < 7; ++i) rc[R_LX + i] = tr.Qd[i] * (x[i] - tr.xf[i]);
+      rk_jacobian<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, rc);
+      for (int i = 0; i < 7; ++i) rc[R::LX + i] = tr.Qd[i] * (x[i] - tr.xf[i]);
     } else {
       // error coordinates: A^ = E(q_{k+1})' A E(q_k), B^ = E(q_{k+1})' B column by column (rk_jacobian_es_cols),
       // lx^ = E(q_k)' lx, Qxx^ = E(q_k)' Q E(q_k) (src/quaternion_toolbox.jl:15-36)
       real qk[4], qn[4];
       for (int i = 0; i < 4; ++i) { qk[i] = x[3 + i]; qn[i] = xu[XUW + 3 + i]; }
-      rk_jacobian_es_cols<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, qn, rc + R_F, 0, 9);
+      rk_jacobian_es_cols<real, INTEG, DIAGJ, real*, R::FSR>(tr, x, u, b0, b1, b2, qn, rc, 0, 9);
       real lx[7];
       for (int i = 0; i < 7; ++i) lx[i] = tr.Qd[i] * (x[i] - tr.xf[i]);
       {
@@ -1009,7 +1087,7 @@ TSAT_PHASE void jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, 
         gt_apply(qk, lx[3], lx[4], lx[5], lx[6], o);
         lx[3] = o[0]; lx[4] = o[1]; lx[5] = o[2];
       }
-      for (int i = 0; i < 7; ++i) rc[R_LX + i] = lx[i];
+      for (int i = 0; i < 6; ++i) rc[R::LX + i] = lx[i];
       {  // G' diag(Qd[3:7]) G, upper triangle (0,0)(0,1)(0,2)(1,1)(1,2)(2,2); G rows: [-v'; s I + hat(v)]
         const real sq = qk[0], v0 = qk[1], v1 = qk[2], v2 = qk[3];
         const real G[4][3] = {{-v0, -v1, -v2}, {sq, -v2, v1}, {v2, sq, -v0}, {-v1, v0, sq}};
@@ -1018,11 +1096,11 @@ TSAT_PHASE void jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, 
           for (int l = j; l < 3; ++l) {
             real acc = 0;
             for (int r = 0; r < 4; ++r) acc += G[r][j] * tr.Qd[3 + r] * G[r][l];
-            rc[R_QQ + idx++] = acc;
+            rc[R::QQ + idx++] = acc;
           }
       }
     }
-    al_control_terms(tr, u, lam, mu, rc + R_LU, rc + R_LUU);
+    al_control_terms(tr, u, lam, mu, rc + R::LU, rc + R::LUU);
   }
 }
 
@@ -1038,11 +1116,11 @@ TSAT_DEV void pair_ut(int L, int n, int& i, int& j) {  // L in [0, n(n+1)/2) -> 
 
 // Riccati recursion over one chunk whose Jacobian records are in LDS (last knot first). Its own function, so that
 // the lane-role tables live in registers for exactly this loop (nothing survives the call to jacobian_chunk).
-// NH = 7: plain state differences; NH = 6: error coordinates (records reduced by jacobian_chunk).
-template <typename real, int NH>
+// NH = 7: plain state differences; NH = 6: error coordinates (records reduced by jacobian_chunk). R: layout of the knot record.
+template <typename real, int NH, typename R>
 TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, real rho, acc_t dV1, acc_t dV2) {
   constexpr int ES = (NH == 6) ? 1 : 0;
-  constexpr int RECS = BwdCfg<ES>::RECS;
+  constexpr int RECS = R::RECS, FSR = R::FSR, R_LX = R::LX, R_LU = R::LU, R_LUU = R::LUU, R_QQ = R::QQ;
   constexpr int NC = NH + 3;               // columns of [A|B]
   constexpr int NP = NH * (NH + 1) / 2;    // unique entries of a symmetric NH x NH block
   real* lds = lds_base<real>();
@@ -1053,7 +1131,7 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
   const int r1 = lane & 7, c1 = lane >> 3;
   const int r1c = (r1 <= NH) ? r1 : NH;
   const int s1_st = L_ST + r1c * 9;
-  const int s1_fa = c1 * FS, s1_fb = ((8 + (c1 & 1) < NC) ? (8 + (c1 & 1)) : 0) * FS;   // relative to the knot record
+  const int s1_fa = ((c1 < NC) ? c1 : 0) * FSR, s1_fb = ((8 + (c1 & 1) < NC) ? (8 + (c1 & 1)) : 0) * FSR;   // relative to the knot record
   const int s1_oa = (r1 <= NH) ? (L_WT + c1 * 9 + r1) : L_SINK;
   const int s1_ob = (r1 <= NH && 8 + c1 < NC) ? (L_WT + (8 + c1) * 9 + r1) : L_SINK;
   // step 2: acc = diag + init + dot(F[:,colA], opB[0..NH-1]) -> lds[o1], lds[o2]
@@ -1061,7 +1139,7 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
   real s2_diag = 0;
   if (lane < NP) {                                   // Qxx(i,j), i <= j  = lxx + A'SA
     int i, j; pair_ut(lane, NH, i, j);
-    s2_fa = i * FS; s2_b = L_WT + j * 9; s2_o1 = L_HXX + i * 7 + j; s2_o2 = L_HXX + j * 7 + i;
+    s2_fa = i * FSR; s2_b = L_WT + j * 9; s2_o1 = L_HXX + i * 7 + j; s2_o2 = L_HXX + j * 7 + i;
     if (ES) {   // projected Hessian: diag(Qd[0:3]) on the rate block, G'QG (per-knot record) on the attitude block
       if (i == j && i < 3) s2_diag = lds[L_TR + P_QD + i];
       if (i >= 3) { const int a = i - 3, b = j - 3; s2_init = R_QQ + (a == 0 ? b : (a == 1 ? 2 + b : 5)); }
@@ -1070,16 +1148,16 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
     }
   } else if (lane < NP + 3 * NH) {                   // Qux(a,j) = B'SA
     const int aa = (lane - NP) / NH, j = (lane - NP) % NH;
-    s2_fa = (NH + aa) * FS; s2_b = L_WT + j * 9; s2_o1 = s2_o2 = L_HUX + aa * 8 + j;
+    s2_fa = (NH + aa) * FSR; s2_b = L_WT + j * 9; s2_o1 = s2_o2 = L_HUX + aa * 8 + j;
   } else if (lane < NP + 3 * NH + 6) {               // Quu(a,b), a <= b = luu + B'SB
     const int L = lane - (NP + 3 * NH);              // (0,0)(0,1)(0,2)(1,1)(1,2)(2,2)
     const int aa = (L < 3) ? 0 : (L < 5 ? 1 : 2);
     const int bb = (L < 3) ? L : (L < 5 ? L - 2 : 2);
-    s2_fa = (NH + aa) * FS; s2_b = L_WT + (NH + bb) * 9; s2_o1 = L_HUU + aa * 3 + bb; s2_o2 = L_HUU + bb * 3 + aa;
+    s2_fa = (NH + aa) * FSR; s2_b = L_WT + (NH + bb) * 9; s2_o1 = L_HUU + aa * 3 + bb; s2_o2 = L_HUU + bb * 3 + aa;
     if (aa == bb) s2_init = R_LUU + aa;
   } else if (lane < NP + 3 * NH + 9) {               // Qu(a) = lu + B's'  -> Hux[a][7]
     const int aa = lane - (NP + 3 * NH + 6);
-    s2_fa = (NH + aa) * FS; s2_b = L_ST + NH * 9; s2_init = R_LU + aa; s2_o1 = s2_o2 = L_HUX + aa * 8 + 7;
+    s2_fa = (NH + aa) * FSR; s2_b = L_ST + NH * 9; s2_init = R_LU + aa; s2_o1 = s2_o2 = L_HUX + aa * 8 + 7;
   }
   // step 3: K[a3][j3] (j3 == 7: d[a3]) on the lanes with a3 < 3; with NH = 6 the unused gain column 6 is written as 0
   const int a3 = lane >> 3, j3 = lane & 7;
@@ -1279,7 +1357,7 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
     jacobian_chunk<real, INTEG, DIAGJ, ES>(p, N, n_tab, k0, nk, mu);
     TSAT_SYNC();
     const unsigned long long t_j1 = tick_();
-    acc = riccati_chunk<real, BwdCfg<ES>::NH>(p.KD, k0, nk, rho, acc.dV1, acc.dV2);
+    acc = riccati_chunk<real, BwdCfg<ES>::NH, PkRec<ES>>(p.KD, k0, nk, rho, acc.dV1, acc.dV2);
     TSAT_SYNC();
 #ifdef TSAT_PROFILE
     if (lane == 0) {
@@ -1418,8 +1496,10 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   unsigned long long pc_fwd = 0, pc_par = 0;
 
   // open-loop rollout of U0
-  FwdOut<real> f0 = forward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, 0, 1, 0, mu, tmask, max_state);
+  forward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, 0, 1, 0);
   n_forward++;
+  TSAT_SYNC();
+  const FwdOut<real> f0 = candidate_costs<real>(p, N, 0, 1, mu, tmask, max_state);
   const acc_t J0 = wave_bcast(f0.J, 0, red64());
   const int ok0 = wave_first<real>(!f0.ok, lds + L_RED) > 0;  // lane 0 ok?
   TSAT_SYNC();
@@ -1454,33 +1534,48 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
           rho = (r > (real)o.reg_min) ? r : (real)0;
         }
         TSAT_SYNC();
-        // all backtracking trials in one sweep
+        // Line search. One sweep rolls out the candidates alpha = 2^-(shift + lane) and keeps the first n_store roll-outs; their
+        // costs are then evaluated CG candidates at a time (lanes = knots) until one is accepted — the first accepted index is
+        // exactly what sequential backtracking picks, and the usual winner is among the first CG. Candidates beyond the stored
+        // ones (max_linesearch > n_store) take another sweep with the next n_store.
         const unsigned long long t_f0 = tick_();
         const int n_store = (o.max_linesearch < a.max_ls) ? o.max_linesearch : a.max_ls;
-        const FwdOut<real> fw = forward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, 1, n_store, 0, mu, tmask, max_state);
+        int jw = WAVE, slot = 0;
+        acc_t Jw = 0;
+        unsigned long long t_cost = 0;
+        for (int shift = 0; shift < o.max_linesearch && jw == WAVE; shift += n_store) {
+          const int n_here = (o.max_linesearch - shift < n_store) ? o.max_linesearch - shift : n_store;
+          forward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, 1, n_here, shift);
+          n_forward++;
+          TSAT_SYNC();                   // the candidates' records are in HBM before the cost lanes read them
+          const unsigned long long t_c0 = tick_();
+          for (int c0 = 0; c0 < n_here && jw == WAVE; c0 += CG) {
+            const int nc = (n_here - c0 < CG) ? n_here - c0 : CG;
+            const FwdOut<real> fw = candidate_costs<real>(p, N, c0, nc, mu, tmask, max_state);
+            const int ci = shift + c0 + lane;            // this lane's candidate (lanes < nc)
+            acc_t alpha = 1;
+            for (int j = 0; j < ci && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (acc_t)0.5;
+            const acc_t Jc = fw.J;
+            const acc_t expected = -alpha * (dV1 + alpha * dV2);
+            const acc_t z = (expected > 0) ? (Jprev - Jc) / expected : (acc_t)-1;
+            const bool acc = (lane < nc) && fw.ok && ((z > (acc_t)o.ls_lower && z <= (acc_t)o.ls_upper) || Jc < Jprev);
+            const int jl = wave_first<real>(acc, lds + L_RED);
+            if (jl < WAVE) {
+              jw = shift + c0 + jl;
+              slot = c0 + jl;
+              Jw = wave_bcast(Jc, jl, red64());
+            }
+          }
+          t_cost += tick_() - t_c0;
+        }
         const unsigned long long t_f1 = tick_();
-        pc_fwd += t_f1 - t_f0;
-        n_forward++;
-        const acc_t Jc = fw.J;
-        acc_t alpha = 1;
-        for (int j = 0; j < lane && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (acc_t)0.5;
-        const acc_t expected = -alpha * (dV1 + alpha * dV2);
-        const acc_t z = (expected > 0) ? (Jprev - Jc) / expected : (acc_t)-1;
-        const bool acc = (lane < o.max_linesearch) && fw.ok &&
-                         ((z > (acc_t)o.ls_lower && z <= (acc_t)o.ls_upper) || Jc < Jprev);
-        const int jw = wave_first<real>(acc, lds + L_RED);
+        pc_fwd += (t_f1 - t_f0) - t_cost;
+        pc_par += t_cost;
         acc_t J;
         TSAT_SYNC();
         if (jw < WAVE) {
-          J = wave_bcast(Jc, jw, red64());
+          J = Jw;
           ls_trials += jw + 1;
-          int slot = jw;
-          if (jw >= n_store) {   // the winner's rollout was not kept: roll out that one alpha again, into slot 0
-            (void)forward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, 1, 1, jw, mu, tmask, max_state);
-            n_forward++;
-            slot = 0;
-            TSAT_SYNC();
-          }
           grad = adopt_and_gradient<real>(p, N, slot);
         } else {
           J = Jprev;
@@ -1647,8 +1742,9 @@ TSAT_PHASE void tv_jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int n
     const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5 * (double)frac) * 4;
     const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, (double)frac) * 4;
     for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
-    real* rc = lds + L_REC + lane * BwdCfg<1>::RECS;
-    real* F = rc + R_F;
+    constexpr int R_LX = TvRec::LX, R_LU = TvRec::LU, R_LUU = TvRec::LUU, R_QQ = TvRec::QQ;
+    real* rc = lds + L_REC + lane * TvRec::RECS;
+    real* F = rc;
     rk_jacobian<real, 4, DIAGJ, 1>(tr, x, u, b0, b1, b2, F);
     real qk[4], qn[4];
     for (int i = 0; i < 4; ++i) { qk[i] = x[3 + i]; qn[i] = xu[XUW + 3 + i]; }
@@ -1707,7 +1803,7 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
     if (lane == 0) { lds[L_ZERO] = 0; lds[L_SINK] = 0; }
   }
   TSAT_SYNC();
-  constexpr int CHB = BwdCfg<1>::CHB;
+  constexpr int CHB = TV_CHB;
   BwdOut<real> acc;
   acc.dV1 = 0; acc.dV2 = 0; acc.pd_ok = 1;
   for (int ch = (N - 1 + CHB - 1) / CHB - 1; ch >= 0 && acc.pd_ok; --ch) {
@@ -1715,7 +1811,7 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
     const int nk = (N - 1 - k0 < CHB) ? (N - 1 - k0) : CHB;
     tv_jacobian_chunk<real, DIAGJ>(p, N, n_tab, k0, nk, hl, frac);
     TSAT_SYNC();
-    acc = riccati_chunk<real, 6>(p.KD, k0, nk, (real)0, acc.dV1, acc.dV2);
+    acc = riccati_chunk<real, 6, TvRec>(p.KD, k0, nk, (real)0, acc.dV1, acc.dV2);
     TSAT_SYNC();
   }
   // ---- tracking: x_sim(k+1) = rk4(plant)(x_sim(k), U(k) - K(k) dX(k))   (src/attitude_controller.jl:39-45) -----
@@ -1738,7 +1834,7 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
     if ((k % CK) == 0) {
       const int nk = (N - 1 - k < CK) ? (N - 1 - k) : CK;
       TSAT_SYNC_LDS();
-      fwd_chunk_issue<real>(fb, p.KD, p.XU, p.XU, tr, k, nk, 1);   // the multiplier slot is not used here: any valid source
+      fwd_chunk_issue<real>(fb, p.KD, p.XU, tr, k, nk, 1);
       if (NZg) {
         const int n2 = (nk * 36) >> 1;
         for (int j = 0; j < (CK * 36 + GLDS - 1) / GLDS; ++j) {
@@ -1846,6 +1942,8 @@ struct MpcArgs {
   real* U0;           // [T][N-1][3]    next warm start
   real* HX;           // [T][n_steps+1][7]
   real* HU;           // [T][n_steps][3]
+  const tsat_stats* stats;   // [T] statistics of the solve that has just finished
+  long long* tally;   // [T][4] running sums over the control steps: n_backward, n_forward, outer_iters - 1, inner_iters
 };
 
 template <typename real, int DIAGJ>
@@ -1881,6 +1979,11 @@ TSAT_DEV void mpc_advance_trajectory(const MpcArgs<real>& a, int traj) {
     if (a.step == a.n_steps - 1)
       for (int i = 0; i < 7; ++i) hx[7 + i] = xn[i];
     Pg[P_TAU0] = (real)(tr.tau0 + tr.dtau);
+    if (a.tally) {       // executed counts of this control step's solve, for the measurement (bench.py --config 4)
+      const tsat_stats& st = a.stats[traj];
+      long long* t = a.tally + (size_t)traj * 4;
+      t[0] += st.n_backward; t[1] += st.n_forward; t[2] += (st.outer_iters > 1 ? st.outer_iters - 1 : 0); t[3] += st.inner_iters;
+    }
   }
 }
 

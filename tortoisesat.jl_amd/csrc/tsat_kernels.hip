@@ -132,16 +132,21 @@ struct tsat_handle {
   int solved_precision = 64;
   int64_t bt_T = 0;      // field tables left on the device by the last tsat_btable_batch: [bt_T][bt_rows][3] in slot WS_BT_B
   int bt_rows = 0;
+  int64_t bt_gen = 0;    // bumped by every tsat_btable_batch call that touches the resident tables (tsat_btable_generation)
   // grow-only device workspaces of the stages around the solve (tracking, horizon, field tables, MPC history, export):
   // allocated on first use and kept for the life of the handle, so repeated calls pay no hipMalloc / hipFree
   enum { WS_TV_NZ, WS_TV_KD, WS_TV_XS, WS_TV_NID, WS_TV_ST, WS_TV_P, WS_TVB_P, WS_TVB_BT, WS_TVB_XUR, WS_TVB_BI, WS_TVB_NK,
          WS_HZ_B, WS_HZ_DT, WS_HZ_CUT, WS_HZ_C, WS_HZ_I, WS_BT_COEF, WS_BT_KEP, WS_BT_T0, WS_BT_TF, WS_BT_POS, WS_BT_B,
-         WS_JW, WS_MPC_HX, WS_MPC_HU, WS_DL_X, WS_DL_U, WS_DL_K, WS_AG_X, WS_AG_U, WS_AG_ST, WS_AG_XA, WS_AG_UA, WS_AG_STA, WS_COUNT };
+         WS_JW, WS_MPC_HX, WS_MPC_HU,
+         WS_DL_X, WS_DL_U, WS_DL_K, WS_AG_X, WS_AG_U, WS_AG_ST, WS_AG_XA, WS_AG_UA, WS_AG_STA,   // staging: WS_DL_X .. WS_AG_STA (tsat_workspace_trim)
+         WS_AG_CHK, WS_MPC_TALLY, WS_COUNT };
   void* ws[WS_COUNT] = {};
   size_t ws_bytes[WS_COUNT] = {};
   // RCCL communicator of the sweep (tsat_comm_init): one rank per handle / GPU
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 1;
+  int64_t comm_T = -1; int comm_N = -1;
+  int64_t mpc_tally_T = 0;   // trajectories covered by the tally of the last tsat_mpc_run (slot WS_MPC_TALLY)   // shard shape every rank of the communicator was last found to agree on
 };
 
 namespace {
@@ -195,7 +200,7 @@ int dev_alloc(tsat_handle* h, Tp** p, size_t n) {
 
 extern "C" {
 
-int tsat_version(void) { return 200; }
+int tsat_version(void) { return 300; }
 
 void tsat_default_options(tsat_options* o) {
   std::memset(o, 0, sizeof(*o));
@@ -247,6 +252,30 @@ int tsat_destroy(tsat_handle* h) {
 const char* tsat_last_error(const tsat_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
 int64_t tsat_batch_bytes(const tsat_handle* h) { return h ? h->bytes : 0; }
+
+int64_t tsat_workspace_bytes(const tsat_handle* h) {
+  int64_t b = 0;
+  if (h)
+    for (int i = 0; i < tsat_handle::WS_COUNT; ++i) b += (int64_t)h->ws_bytes[i];
+  return b;
+}
+
+int tsat_workspace_trim(tsat_handle* h, int32_t what) {
+  if (!h) return -1;
+  if (what != 0 && what != 1) return fail(h, -1, "what must be 0 (staging buffers of downloads and gathers) or 1 (every workspace)");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  TSAT_HIP(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < tsat_handle::WS_COUNT; ++i) {
+    const bool staging = i >= tsat_handle::WS_DL_X && i <= tsat_handle::WS_AG_STA;
+    if (!h->ws[i] || !(what == 1 || staging)) continue;
+    (void)hipFree(h->ws[i]);
+    h->ws[i] = nullptr; h->ws_bytes[i] = 0;
+    if (i == tsat_handle::WS_BT_B) { h->bt_T = 0; h->bt_rows = 0; h->bt_gen++; }     // the resident field tables are gone
+  }
+  return 0;
+}
+
+int64_t tsat_btable_generation(const tsat_handle* h) { return h ? h->bt_gen : 0; }
 
 int tsat_batch_reserve(tsat_handle* h, int64_t T, int32_t n_knots, int32_t n_tab, int64_t n_btab,
                        int32_t max_linesearch) {
@@ -392,13 +421,19 @@ void* packed_workspace(tsat_handle* h) {
   return ws_get(h, tsat_handle::WS_JW, (size_t)((h->T + 3) / 4) * TSAT_JW_REALS_PER_4 * sizeof(double));
 }
 
+// does the build that (h->variant, batch size, precision) selects need the packed builds' Jacobian workspace a.JW?
+bool uses_packed_build(const tsat_handle* h, int precision) {
+  if (h->variant == 3 || h->variant == 4) return true;
+  return h->variant == 0 && h->T >= (precision == 32 ? TSAT_PACKED_F32_MIN_T : TSAT_PACKED_MIN_T);
+}
+
 KArgs<double> solve_args(tsat_handle* h, const tsat_options* o) {
   KArgs<double> a;
   a.T = (int)h->T; a.N = h->N; a.n_tab = h->n_tab; a.max_ls = h->max_ls < NSTORE ? h->max_ls : NSTORE; a.opt = *o;
   a.P = h->P; a.BT = h->BT; a.bidx = h->bidx; a.nk = h->ragged ? h->nk : nullptr; a.U0 = h->U0;
   a.XU = h->XU; a.KD = h->KD; a.LAM = h->LAM; a.CAND = h->CAND;
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
-  a.JW = (h->variant == 3 || h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T)) ? (double*)packed_workspace(h) : nullptr;
+  a.JW = uses_packed_build(h, 64) ? (double*)packed_workspace(h) : nullptr;
   return a;
 }
 
@@ -423,8 +458,8 @@ int launch_solve_f32(tsat_handle* h, const tsat_options* o) {
   a.P = h->P32; a.BT = h->BT32; a.bidx = h->bidx; a.nk = h->ragged ? h->nk : nullptr; a.U0 = h->U032;
   a.XU = (float*)h->XU; a.KD = (float*)h->KD; a.LAM = (float*)h->LAM; a.CAND = (float*)h->CAND;
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
-  a.JW = (h->variant == 3 || h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED_F32_MIN_T)) ? (float*)packed_workspace(h) : nullptr;
-  if ((h->variant == 3 || h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED_F32_MIN_T)) && !a.JW) return -10;
+  a.JW = uses_packed_build(h, 32) ? (float*)packed_workspace(h) : nullptr;
+  if (uses_packed_build(h, 32) && !a.JW) return -10;
   // build by batch size: the layout for two wavefronts per SIMD while the batch fits the GPU that way (256 CUs x 4 SIMDs x 2),
   // else the one for four; tsat_set_kernel_variant(h, 12 | 13 | 14) forces one (tuning, tests)
   // batches several times larger than the machine: the packed build (tsat_kernels_packed_f32.hip), as in fp64
@@ -446,7 +481,7 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
   if (!why.empty()) return fail(h, -1, why);
   TSAT_HIP(h, hipSetDevice(h->dev));
   const KArgs<double> a = solve_args(h, o);
-  if (!a.JW && (h->variant == 3 || h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T)))
+  if (!a.JW && uses_packed_build(h, 64))
     return fail(h, -10, "device allocation of the packed builds' Jacobian workspace failed");
   if (h->trace) TSAT_HIP(h, hipMemsetAsync(h->trace, 0, (size_t)h->T * h->trace_rows * 8 * sizeof(double), h->stream));
   if (o->precision == 32) {
@@ -488,12 +523,17 @@ int tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t
   const size_t T = (size_t)h->T, nX = T * ((size_t)n_steps + 1) * 7, nU = T * (size_t)n_steps * 3;
   double* dHX = (double*)ws_get(h, tsat_handle::WS_MPC_HX, nX * 8);
   double* dHU = (double*)ws_get(h, tsat_handle::WS_MPC_HU, nU * 8);
-  if (!dHX || !dHU) return fail(h, -10, "device allocation failed in tsat_mpc_run");
+  long long* dTally = (long long*)ws_get(h, tsat_handle::WS_MPC_TALLY, T * 4 * sizeof(long long));
+  if (!dHX || !dHU || !dTally) return fail(h, -10, "device allocation failed in tsat_mpc_run");
+  TSAT_HIP(h, hipMemsetAsync(dTally, 0, T * 4 * sizeof(long long), h->stream));
+  h->mpc_tally_T = (int64_t)T;
   const KArgs<double> a = solve_args(h, o);
+  if (!a.JW && uses_packed_build(h, 64))     // a packed kernel launched with JW = nullptr would fault on the device
+    return fail(h, -10, "device allocation of the packed builds' Jacobian workspace failed");
   MpcArgs<double> m;
   m.T = (int)h->T; m.N = h->N; m.n_tab = h->n_tab; m.plant_integ = plant_integrator; m.n_steps = n_steps; m.us = o->u_scale;
   m.P = h->P; m.BT = h->BT; m.bidx = h->bidx; m.nk = h->ragged ? h->nk : nullptr; m.XU = h->XU; m.U0 = h->U0;
-  m.HX = dHX; m.HU = dHU;
+  m.HX = dHX; m.HU = dHU; m.stats = h->stats; m.tally = dTally;
   auto adv = h->inertia_class == 2 ? tsat_mpc_advance_kernel<double, 2>
                                    : (h->inertia_class == 1 ? tsat_mpc_advance_kernel<double, 1> : tsat_mpc_advance_kernel<double, 0>);
   int rc = 0;
@@ -528,6 +568,15 @@ int tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t
   h->f32_ready = false;
   h->solved = true;
   h->solved_precision = 64;
+  return 0;
+}
+
+int tsat_mpc_tally(tsat_handle* h, int64_t* tally) {
+  if (!h || !tally) return -1;
+  if (h->mpc_tally_T != h->T || h->T < 1 || !h->ws[tsat_handle::WS_MPC_TALLY]) return fail(h, -1, "tsat_mpc_run has not been called on this batch");
+  TSAT_HIP(h, hipSetDevice(h->dev));
+  static_assert(sizeof(long long) == sizeof(int64_t), "tally element");
+  TSAT_HIP(h, hipMemcpy(tally, h->ws[tsat_handle::WS_MPC_TALLY], (size_t)h->T * 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -795,6 +844,8 @@ int rccl_fail(tsat_handle* h, const char* what, ncclResult_t r) {
 }  // namespace
 extern "C" {
 
+int tsat_comm_available(void) { return rccl().lib ? 0 : -11; }
+
 int tsat_comm_unique_id(void* id_out) {
   if (!id_out) return -1;
   RcclApi& a = rccl();
@@ -819,6 +870,7 @@ int tsat_comm_init(tsat_handle* h, const void* id_in, int32_t rank, int32_t worl
   const ncclResult_t r = a.CommInitRank(&c, world, id, rank);
   if (r != ncclSuccess) return rccl_fail(h, "ncclCommInitRank", r);
   h->comm = c; h->comm_rank = rank; h->comm_world = world;
+  h->comm_T = -1; h->comm_N = -1;
   return 0;
 }
 
@@ -829,6 +881,7 @@ int tsat_comm_destroy(tsat_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     (void)rccl().CommDestroy((ncclComm_t)h->comm);
     h->comm = nullptr; h->comm_rank = 0; h->comm_world = 1;
+    h->comm_T = -1; h->comm_N = -1;
   }
   return 0;
 }
@@ -841,6 +894,26 @@ int tsat_sweep_allgather(tsat_handle* h, void* X_all, void* U_all, void* stats_a
   RcclApi& a = rccl();
   const size_t T = (size_t)h->T, N = (size_t)h->N, W = (size_t)h->comm_world;
   const size_t nX = T * N * 7, nU = T * (N - 1) * 3, nS = T * sizeof(tsat_stats);
+  // Every rank must hold a shard of the same shape (T, N): the receive buffers are sized world x this rank's shard and the
+  // collective sends this rank's count. Checked by a 16-byte all-gather of (T, N) whenever the shape is new to the communicator;
+  // every rank sees the same gathered list, so a mismatch fails on all of them alike instead of corrupting memory on some.
+  if (h->comm_T != h->T || h->comm_N != h->N) {
+    int64_t* chk = (int64_t*)ws_get(h, tsat_handle::WS_AG_CHK, (W + 1) * 2 * sizeof(int64_t));
+    if (!chk) return fail(h, -10, "device allocation failed in tsat_sweep_allgather");
+    const int64_t mine[2] = {h->T, (int64_t)h->N};
+    std::vector<int64_t> all(2 * W);
+    TSAT_HIP(h, hipMemcpyAsync(chk + 2 * W, mine, sizeof(mine), hipMemcpyHostToDevice, h->stream));
+    const ncclResult_t rc0 = a.AllGather(chk + 2 * W, chk, 2, ncclInt64, (ncclComm_t)h->comm, h->stream);
+    if (rc0 != ncclSuccess) return rccl_fail(h, "ncclAllGather (shard shapes)", rc0);
+    TSAT_HIP(h, hipMemcpyAsync(all.data(), chk, 2 * W * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    TSAT_HIP(h, hipStreamSynchronize(h->stream));
+    for (size_t r = 0; r < W; ++r)
+      if (all[2 * r] != h->T || all[2 * r + 1] != h->N)
+        return fail(h, -1, "tsat_sweep_allgather: rank " + std::to_string(r) + " holds a " + std::to_string(all[2 * r]) + " x " +
+                               std::to_string(all[2 * r + 1]) + " shard, this rank " + std::to_string(h->T) + " x " + std::to_string(h->N) +
+                               ": shards must have equal shapes (pad the last one)");
+    h->comm_T = h->T; h->comm_N = h->N;
+  }
   // this rank's shard in the ABI layout (export kernel, device to device), then one ncclAllGather per array on the same
   // stream; with host outputs the gathered arrays land in library workspaces and are copied down afterwards
   double* dX = X_all ? (double*)ws_get(h, tsat_handle::WS_AG_X, nX * 8) : nullptr;
@@ -934,6 +1007,9 @@ int tsat_bryson_eigen_axis_batch(int64_t T, const int32_t* n_knots, double t0, d
 int tsat_btable_batch(tsat_handle* h, const tsat_btable_options* o, int64_t T, const double* kep, const double* t0,
                       const double* tf, double* Btab, double* pos) {
   if (!h || !o) return -1;
+  // whatever happens below, the tables of an earlier call are no longer "the last call's": a consumer with Btab = NULL must
+  // never pick up stale ones by shape alone (a failed call leaves none)
+  h->bt_T = 0; h->bt_rows = 0; h->bt_gen++;
   if (T < 1 || o->n_half < 1) return fail(h, -1, "bad dimensions");
   if (!(o->date >= 2015.0 && o->date < 2020.0)) return fail(h, -1, "date must be in [2015, 2020): IGRF-12 epoch 2015 + secular variation");
   if (!kep || !t0 || !tf) return fail(h, -1, "null array");

@@ -78,16 +78,7 @@ constexpr int PK_RING = (sizeof(cfg_real) == 8) ? 4 : 8;   // knots of every tra
 constexpr int PK_BC = 16;                         // lanes per trajectory in a backward pass
 constexpr int PK_BG = WAVE / PK_BC;               // trajectories per backward pass (4); a wave of PK_G trajectories takes PK_G / PK_BG passes
 static_assert(PK_G % PK_BG == 0 && PK_JCH == PK_BC, "Jacobian lanes: the 16 lanes of a trajectory linearise 16 knots");
-// Knot record. Full state: F = [A|B] 7 x 10 column-major (70), lx (7), lu (3), luu (3), pad (1) = 84 reals. Error coordinates: F
-// 6 x 9 with column stride 6 (54; 48-byte columns: 16-byte LDS reads), G'QG (6), lx (6), lu (3), luu (3) = 72 reals. Both are
-// whole numbers of 16-byte units in either precision.
-template <int ES> struct PkRec {
-  static constexpr int FSR = ES ? 6 : FS;
-  static constexpr int QQ = 54;
-  static constexpr int LX = ES ? 60 : 70, LU = ES ? 66 : 77, LUU = ES ? 69 : 80;
-  static constexpr int RECS = ES ? 72 : 84;
-  static constexpr int SLOT = (WAVE / 16) * RECS;   // one ring slot: the records of ONE knot of the pass's four trajectories, contiguous
-};
+// Knot record: PkRec<ES> (tsat_device.hpp) — 84 reals in the full state, 72 in error coordinates.
 constexpr int PK_RECS = 84;                       // the larger of the two: LDS ring and workspace are sized for it
 constexpr int PK_GTRW = 88;                       // per-trajectory constants: staged parameter record (76), nu (8), pad
 constexpr int PK_GT_NU = 76;

@@ -10,9 +10,16 @@ import os
 import numpy as np
 
 _LIB = None
-_CANDIDATES = (os.environ.get("TSAT_HDF5_LIB"), ctypes.util.find_library("hdf5"), "/opt/conda/lib/libhdf5.so", "libhdf5.so",
-               "libhdf5_serial.so")
-hid_t = C.c_int64
+hid_t = C.c_int64      # HDF5 >= 1.10; a 1.8 library (32-bit ids) is refused by _lib(), not mis-called
+
+
+def _candidates():
+    """resolved on first use, not at import: find_library spawns ldconfig / gcc subprocesses, which every process that merely
+    imports the package (GPU workers included) should not pay for"""
+    return (os.environ.get("TSAT_HDF5_LIB"), ctypes.util.find_library("hdf5"), "/opt/conda/lib/libhdf5.so", "libhdf5.so",
+            "libhdf5_serial.so")
+
+
 H5F_ACC_RDONLY, H5F_ACC_RDWR, H5F_ACC_TRUNC = 0, 1, 2
 H5T_INTEGER, H5T_FLOAT = 0, 1
 
@@ -30,7 +37,7 @@ def _lib():
     if _LIB is not None:
         return _LIB
     last = None
-    for name in _CANDIDATES:
+    for name in _candidates():
         if not name:
             continue
         try:
@@ -55,6 +62,11 @@ def _lib():
         if lib.H5open() < 0:
             last = OSError("H5open failed")
             continue
+        maj, mnr, rel = C.c_uint(0), C.c_uint(0), C.c_uint(0)
+        lib.H5get_libversion.restype, lib.H5get_libversion.argtypes = C.c_int, [C.POINTER(C.c_uint)] * 3
+        if lib.H5get_libversion(C.byref(maj), C.byref(mnr), C.byref(rel)) < 0 or (maj.value, mnr.value) < (1, 10):
+            last = OSError(f"{name}: HDF5 {maj.value}.{mnr.value}.{rel.value} has 32-bit identifiers; 1.10 or newer is needed")
+            continue
         _LIB = lib
         return lib
     raise OSError(f"no usable libhdf5 ({last}); set TSAT_HDF5_LIB")
@@ -77,18 +89,23 @@ def h5write(path, name, data):
     f = lib.H5Fopen(path.encode(), H5F_ACC_RDWR, 0) if os.path.exists(path) else lib.H5Fcreate(path.encode(), H5F_ACC_TRUNC, 0, 0)
     if f < 0:
         raise OSError(f"h5write: cannot open {path}")
+    sp = ds = -1
     try:
+        ty = _native(lib, a.dtype)
         dims = (C.c_uint64 * max(a.ndim, 1))(*(a.shape if a.ndim else (1,)))
         sp = lib.H5Screate_simple(max(a.ndim, 1), dims, None)
-        ds = lib.H5Dcreate2(f, name.encode(), _native(lib, a.dtype), sp, 0, 0, 0)
+        if sp < 0:
+            raise OSError(f"h5write: cannot create the dataspace of {name}")
+        ds = lib.H5Dcreate2(f, name.encode(), ty, sp, 0, 0, 0)
         if ds < 0:
-            lib.H5Sclose(sp)
             raise OSError(f"h5write: cannot create dataset {name} in {path} (does it exist already?)")
-        rc = lib.H5Dwrite(ds, _native(lib, a.dtype), 0, 0, 0, a.ctypes.data_as(C.c_void_p))
-        lib.H5Dclose(ds); lib.H5Sclose(sp)
-        if rc < 0:
+        if lib.H5Dwrite(ds, ty, 0, 0, 0, a.ctypes.data_as(C.c_void_p)) < 0:
             raise OSError(f"h5write: write of {name} failed")
     finally:
+        if ds >= 0:
+            lib.H5Dclose(ds)
+        if sp >= 0:
+            lib.H5Sclose(sp)
         lib.H5Fclose(f)
 
 
@@ -97,11 +114,14 @@ def h5read(path, name):
     f = lib.H5Fopen(path.encode(), H5F_ACC_RDONLY, 0)
     if f < 0:
         raise OSError(f"h5read: cannot open {path}")
+    ds = sp = ty = -1
     try:
         ds = lib.H5Dopen2(f, name.encode(), 0)
         if ds < 0:
             raise KeyError(name)
         sp, ty = lib.H5Dget_space(ds), lib.H5Dget_type(ds)
+        if sp < 0 or ty < 0:
+            raise OSError(f"h5read: cannot query {name}")
         nd = lib.H5Sget_simple_extent_ndims(sp)
         dims = (C.c_uint64 * max(nd, 1))()
         lib.H5Sget_simple_extent_dims(sp, dims, None)
@@ -110,10 +130,14 @@ def h5read(path, name):
         if dt is None:
             raise TypeError(f"h5read: unsupported stored type (class {cls}, {size} bytes)")
         out = np.empty(tuple(dims[i] for i in range(nd)), dtype=dt)
-        rc = lib.H5Dread(ds, _native(lib, dt), 0, 0, 0, out.ctypes.data_as(C.c_void_p))
-        lib.H5Tclose(ty); lib.H5Sclose(sp); lib.H5Dclose(ds)
-        if rc < 0:
+        if lib.H5Dread(ds, _native(lib, dt), 0, 0, 0, out.ctypes.data_as(C.c_void_p)) < 0:
             raise OSError(f"h5read: read of {name} failed")
         return out
     finally:
+        if ty >= 0:
+            lib.H5Tclose(ty)
+        if sp >= 0:
+            lib.H5Sclose(sp)
+        if ds >= 0:
+            lib.H5Dclose(ds)
         lib.H5Fclose(f)

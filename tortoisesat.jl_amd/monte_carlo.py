@@ -64,16 +64,30 @@ class GpuStages:
     def __init__(self, solver):
         self.solver = solver
         self._resident_shape = None
+        self._resident_gen = None
 
     def magnetic_simulation(self, kep, t0, tf, N, s, host=True):
         self._resident_shape = (len(kep), 2 * N)
-        return mg.magnetic_simulation(self.solver, kep, t0, tf, N, mjd=s.mjd, gm=s.GM, alt=s.alt, R_E=s.R_E, date=s.igrf_date,
-                                      want_pos=False, host=host)[0]
+        B = mg.magnetic_simulation(self.solver, kep, t0, tf, N, mjd=s.mjd, gm=s.GM, alt=s.alt, R_E=s.R_E, date=s.igrf_date,
+                                   want_pos=False, host=host)[0]
+        self._resident_gen = self.solver.btable_generation()       # identifies THESE tables to the consumers below
+        return B
+
+    def _resident_tables_are_mine(self, what):
+        # the library identifies resident tables by shape only; any other tsat_btable_batch on the handle in between (a second
+        # experiment, attach_igrf_tables) would be picked up silently — the generation counter tells (include/tortoise_hip.h)
+        if self.solver.btable_generation() != self._resident_gen:
+            raise RuntimeError(f"{what}: the field tables resident on the device are not the ones this experiment generated "
+                               "(another tsat_btable_batch ran on the handle in between)")
 
     def condition_based_time(self, B, dt_row, cutoff):
+        if B is None:
+            self._resident_tables_are_mine("condition_based_time")
         return hz.condition_based_time(self.solver, B, dt_row, cutoff, resident_shape=self._resident_shape)[0]
 
     def solve(self, batch, s, want_trajectories=True):
+        if batch.Btab is None:
+            self._resident_tables_are_mine("solve")
         opts = to.AugmentedLagrangianSolverOptions()
         opts.iterations, opts.opts_uncon.iterations, opts.opts_uncon.dJ_counter_limit = s.outer, s.inner, s.dJ_counter_limit
         self.solver.opts = opts

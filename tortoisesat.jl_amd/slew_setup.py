@@ -90,16 +90,21 @@ def eigen_axis_slew(x0, xf, t, rates_only=False):
     return w_guess, q_guess
 
 
-def bryson_weights(w_guess, J, dt, alpha, beta, degenerate_rd=None):
+def bryson_weights(w_guess, J, dt, alpha, beta, degenerate_rd=None, r_scale=1.0, signed_w_max=False):
     """Diagonal (Qd(7), Qfd(7), Rd(3)) per src/TortoiseSat.jl:157-168 / src/monte_carlo.jl:165-176.
+
+    ``r_scale`` multiplies R and ``signed_w_max`` takes ``maximum(X[1:3,:])`` without the ``abs.``: the inclination-sweep
+    script's variants (``R = (1/m_max^2)*.1``, src/paper_images/heatmap.jl:172; ``omega_max``, :164).
 
     ``tau_max`` is the *signed* maximum, as written in the reference (``maximum(J*diff(w)/dt)``). A guess without an
     acceleration sample (two knots, or a constant rate) has ``tau_max <= 0`` and the reference's ``R = 1/m_max^2`` is
     infinite: that raises here, unless ``degenerate_rd`` names the control weight to use instead.
     """
-    w_max = np.max(np.abs(w_guess))
+    w_max = np.max(w_guess) if signed_w_max else np.max(np.abs(w_guess))
     if not w_max > 0.0:
-        raise ValueError("bryson_weights: the rate guess is identically zero (w_max = 0): Q = alpha/w_max^2 is undefined")
+        raise ValueError("bryson_weights: the rate guess has no positive maximum (w_max <= 0): Q = alpha/w_max^2 is undefined"
+                         if signed_w_max else
+                         "bryson_weights: the rate guess is identically zero (w_max = 0): Q = alpha/w_max^2 is undefined")
     dw = np.diff(w_guess, axis=0)
     tau_max = np.max((J @ dw.T) / dt) if dw.shape[0] > 0 else 0.0
     if not tau_max > 0.0:
@@ -111,7 +116,7 @@ def bryson_weights(w_guess, J, dt, alpha, beta, degenerate_rd=None):
     m_max = tau_max / 1.0e-5 * 1.0e2
     Qd = np.concatenate([np.full(3, alpha / w_max**2), np.full(4, alpha * beta)])
     Qfd = 10.0 * Qd
-    Rd = np.full(3, 1.0 / m_max**2)
+    Rd = np.full(3, 1.0 / m_max**2 * r_scale)
     return Qd, Qfd, Rd
 
 
@@ -212,7 +217,8 @@ def jmat_cm(J):
     return np.ascontiguousarray(np.transpose(J, (0, 2, 1)).reshape(-1, 9))
 
 
-def make_batch(N, dt, q0, qf, J, Btab, btab_idx, alpha, beta, u_bnd, U0, w0=None, wf=None, degenerate_rd=None):
+def make_batch(N, dt, q0, qf, J, Btab, btab_idx, alpha, beta, u_bnd, U0, w0=None, wf=None, degenerate_rd=None, r_scale=1.0,
+               signed_w_max=False):
     """Assemble a SlewBatch from per-trajectory initial/goal quaternions (T,4); weights per trajectory from
     each trajectory's own eigen-axis guess (src/monte_carlo.jl:161-176)."""
     q0 = np.atleast_2d(np.asarray(q0, dtype=np.float64))
@@ -226,9 +232,13 @@ def make_batch(N, dt, q0, qf, J, Btab, btab_idx, alpha, beta, u_bnd, U0, w0=None
     xf = np.ascontiguousarray(np.concatenate([wf, qf], axis=1))
     t = dt * np.arange(N + 1)  # t0:dt:t_final has N+1 points for N knots (src/TortoiseSat.jl:85-86)
     Qd = np.empty((T, 7)); Qfd = np.empty((T, 7)); Rd = np.empty((T, 3))
+    same = T > 1 and np.all(x0 == x0[0]) and np.all(xf == xf[0])      # one guess serves a sweep from a fixed attitude
     for i in range(T):
-        wg, _ = eigen_axis_slew(x0[i], xf[i], t)
-        Qd[i], Qfd[i], Rd[i] = bryson_weights(wg, J, dt, alpha, beta, degenerate_rd)
+        if same and i > 0:
+            Qd[i], Qfd[i], Rd[i] = Qd[0], Qfd[0], Rd[0]
+            continue
+        wg, _ = eigen_axis_slew(x0[i], xf[i], t, rates_only=True)
+        Qd[i], Qfd[i], Rd[i] = bryson_weights(wg, J, dt, alpha, beta, degenerate_rd, r_scale, signed_w_max)
     Btab = np.ascontiguousarray(np.asarray(Btab, dtype=np.float64))
     if Btab.ndim == 2:
         Btab = Btab[None]
@@ -302,7 +312,11 @@ def workload_monte_carlo(T=1024, N=1000, seed=20190530, random_orbit=False, dege
 def workload_inclination_sweep(T=8192, N=1000, seed=20190601, j0=0, T_total=65536, tables=True):
     """configs[3] shard: deterministic inclination sweep i = 90 (j + 1/2)/T_total deg (the reference draws
     rand*90, src/paper_images/heatmap.jl:120), random RAAN / true anomaly, q0 = [0,0,1,0] (heatmap.jl:106),
-    budget 3 x 50 (heatmap.jl:197-198). ``j0`` is the first global index of this shard."""
+    Bryson weights with that script's R scaled by 0.1 (:172) — its ``omega_max = maximum(X[1:3,:])`` without ``abs.`` (:164) is
+    NOT followed: for this fixed q0 / qf pair the eigen-axis guess has no positive rate component (axis (0, -c, -c)), so the
+    line as written gives omega_max = 0 and an infinite Q; the ``abs.`` of src/monte_carlo.jl:167 is used instead —
+    budget 3 x 50 (heatmap.jl:197-198), the quaternion hooks of ``Model(DerivFunction,n,m,quaternion_error,
+    quaternion_expansion)`` (:154; ``meta["error_state"] = 1``). ``j0`` is the first global index of this shard."""
     dt = 0.2
     a_km = R_EARTH_KM + 400.0
     rng = np.random.Generator(np.random.PCG64([seed, j0]))
@@ -313,9 +327,9 @@ def workload_inclination_sweep(T=8192, N=1000, seed=20190601, j0=0, T_total=6553
     q0 = np.repeat(np.array([[0.0, 0.0, 1.0, 0.0]]), T, axis=0)
     qf = np.array([np.sqrt(2.0) / 2.0, np.sqrt(2.0) / 2.0, 0.0, 0.0])
     U0 = rng.random((T, N - 1, 3)) / 1000.0
-    b = make_batch(N, dt, q0, qf[None], INERTIA["1U"], B, np.arange(T, dtype=np.int32), 0.1, 1.0e3, 19.0, U0)
+    b = make_batch(N, dt, q0, qf[None], INERTIA["1U"], B, np.arange(T, dtype=np.int32), 0.1, 1.0e3, 19.0, U0, r_scale=0.1)
     kep = np.zeros((T, 6))
     kep[:, 1], kep[:, 2], kep[:, 3], kep[:, 5] = a_km, inc, raan, nu
-    b.meta = dict(name="inclination_sweep", max_outer=3, max_inner=50, dj_counter_limit=1, seed=seed, kep=kep,
+    b.meta = dict(name="inclination_sweep", max_outer=3, max_inner=50, dj_counter_limit=1, error_state=1, seed=seed, kep=kep,
                   field="tilted dipole (surrogate)")
     return b

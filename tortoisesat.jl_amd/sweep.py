@@ -100,7 +100,7 @@ class ResultGather:
         import torch
         import torch.distributed as dist
 
-        if self.collective:
+        if self.collective and self.stats.is_cuda:
             # the previous step's all-gather (asynchronous, it overlaps the solve that ran since) must have drained
             # before its source buffers are overwritten by this export
             torch.cuda.current_stream().synchronize()
@@ -109,29 +109,86 @@ class ResultGather:
                                   None, self.stats.data_ptr())
         if not self.collective:
             return dict(X=self.X, U=self.U, stats=self.stats)
-        dist.all_gather_into_tensor(self.gathered["stats"], self.stats, group=self.group)
-        if self.mode == "full":
-            dist.all_gather_into_tensor(self.gathered["X"], self.X, group=self.group)
-            dist.all_gather_into_tensor(self.gathered["U"], self.U, group=self.group)
+        for k, src in (("stats", self.stats), ("X", self.X), ("U", self.U)):
+            if k in self.gathered:
+                if src.is_cuda:
+                    dist.all_gather_into_tensor(self.gathered[k], src, group=self.group)
+                else:                    # gloo (CPU tests)
+                    self.gathered[k].copy_(_all_gather_rows(src, self.world, self.group))
         return self.gathered
+
+
+def _agree(flag, world, device, group=None):
+    """True iff `flag` holds on EVERY rank (all-reduce MIN of a 0/1 flag): the ranks take the same branch afterwards"""
+    if world == 1:
+        return bool(flag)
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
 
 
 class NativeGather:
     """The same per-step exchange through the library's own collective (``tsat_sweep_allgather``: export kernel +
     ncclAllGather on the solver's stream) — what a Julia host without torch calls. torch.distributed is used here only to
-    hand the 128-byte communicator id from rank 0 to the other ranks; the gathered arrays land in torch device tensors."""
+    hand the 128-byte communicator id from rank 0 to the other ranks and to agree on the outcome of every step of the set-up;
+    the gathered arrays land in torch device tensors.
 
-    def __init__(self, solver, T, N, world, rank, device, mode="full"):
+    The set-up is COLLECTIVE and so is its failure: every step that can fail on one rank alone (RCCL not loadable, the id
+    cannot be made, ``ncclCommInitRank`` reports an error, the shards have different shapes) is followed by an agreement
+    (all-reduce MIN of a success flag), and either every rank ends up with a working gatherer or every rank raises
+    ``NativeGatherUnavailable`` having left no collective half-entered — a caller's fallback (``make_gatherer``) then takes
+    the same branch everywhere. A rank deciding on its own would leave the others inside ``dist.broadcast`` or
+    ``ncclCommInitRank``."""
+
+    def __init__(self, solver, T, N, world, rank, device, mode="full", group=None):
         import torch
         import torch.distributed as dist
 
         self.solver, self.world, self.mode = solver, world, mode
-        idt = torch.zeros(_abi.TSAT_COMM_ID_BYTES, dtype=torch.uint8, device=device)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(solver.comm_unique_id()), dtype=torch.uint8))
+        # 1. can every rank load RCCL behind the C ABI? (local probe, then agreement: nobody has entered a collective of the library yet)
+        try:
+            ok = bool(solver.comm_available())
+        except Exception:
+            ok = False
+        if not _agree(ok, world, device, group):
+            raise NativeGatherUnavailable("RCCL is not loadable behind the C ABI on at least one rank")
+        # 2. equal shard shapes on every rank (the receive buffers are world x the local shard)
         if world > 1:
-            dist.broadcast(idt, src=0)
-        solver.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+            shp = torch.tensor([T, N, -T, -N], dtype=torch.int64, device=device)
+            dist.all_reduce(shp, op=dist.ReduceOp.MAX, group=group)
+            if int(shp[0]) != -int(shp[2]) or int(shp[1]) != -int(shp[3]):
+                raise ValueError(f"NativeGather: the ranks hold shards of different shapes (this rank {T} x {N}; largest "
+                                 f"{int(shp[0])} x {int(shp[1])}, smallest {-int(shp[2])} x {-int(shp[3])}): pad the shards to equal size")
+        # 3. rank 0 makes the id and broadcasts it together with a status byte (zeros = it could not)
+        buf = torch.zeros(1 + _abi.TSAT_COMM_ID_BYTES, dtype=torch.uint8, device=device)
+        if rank == 0:
+            try:
+                cid = bytes(solver.comm_unique_id())
+                buf[1:] = torch.frombuffer(bytearray(cid), dtype=torch.uint8).to(device)
+                buf[0] = 1
+            except Exception:
+                pass
+        if world > 1:
+            dist.broadcast(buf, src=0, group=group)
+        host = buf.cpu().numpy()
+        if not host[0]:
+            raise NativeGatherUnavailable("rank 0 could not create the communicator id")
+        self.comm_id = host[1:].tobytes()
+        # 4. the collective comm_init, then agreement on its outcome
+        try:
+            solver.comm_init(self.comm_id, rank, world)
+            ok, why = True, ""
+        except Exception as e:
+            ok, why = False, str(e)
+        if not _agree(ok, world, device, group):
+            try:
+                solver.comm_destroy()
+            except Exception:
+                pass
+            raise NativeGatherUnavailable(f"tsat_comm_init failed on at least one rank{': ' + why if why else ''}")
         self.gathered = {}
         if mode != "none":
             self.gathered["stats"] = torch.empty((world * T, _abi.STATS_DTYPE.itemsize), dtype=torch.uint8, device=device)
@@ -146,3 +203,21 @@ class NativeGather:
         self.solver.sweep_allgather(g["X"].data_ptr() if "X" in g else None, g["U"].data_ptr() if "U" in g else None,
                                     g["stats"].data_ptr(), on_device=True)
         return g
+
+
+class NativeGatherUnavailable(RuntimeError):
+    """raised by NativeGather on EVERY rank alike when the library's own collective cannot be set up"""
+
+
+def make_gatherer(solver, T, N, world, rank, device, mode="full", impl="native", group=None, force_collective=False):
+    """(gatherer, impl actually used). ``impl = "native"``: the library's RCCL all-gather, falling back — on every rank together —
+    to torch.distributed's communicator when it cannot be set up; ``"torch"``: torch.distributed straight away."""
+    collective = world > 1 or force_collective
+    if collective and impl == "native":
+        try:
+            return NativeGather(solver, T, N, world, rank, device, mode=mode, group=group), "native"
+        except NativeGatherUnavailable as e:
+            import sys
+            print(f"[sweep] native gather unavailable on every rank ({e}); using torch.distributed", file=sys.stderr)
+    g = ResultGather(solver, T, N, world, device, mode=mode, group=group, force_collective=collective)
+    return g, ("torch" if collective else "export-only")

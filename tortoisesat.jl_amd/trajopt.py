@@ -314,6 +314,11 @@ class AugmentedLagrangianSolver:
             raise RuntimeError(f"tsat_comm_unique_id failed ({rc}): RCCL not available")
         return buf.raw
 
+    @staticmethod
+    def comm_available():
+        """local probe, no communication: can this process load RCCL behind the C ABI?"""
+        return _abi.load().tsat_comm_available() == 0
+
     def comm_init(self, id_bytes, rank, world):
         self._check(self._lib.tsat_comm_init(self._h, bytes(id_bytes), int(rank), int(world)), "tsat_comm_init")
         self._comm = (int(rank), int(world))
@@ -346,6 +351,18 @@ class AugmentedLagrangianSolver:
 
     def reserved_bytes(self):
         return int(self._lib.tsat_batch_bytes(self._h))
+
+    def workspace_bytes(self):
+        """HBM held by the grow-only workspaces of the stages around the solve (downloads, gathers, tracking, tables ...)"""
+        return int(self._lib.tsat_workspace_bytes(self._h))
+
+    def workspace_trim(self, everything=False):
+        """free the staging buffers of downloads / gathers (``everything``: all workspaces, resident field tables included)"""
+        self._check(self._lib.tsat_workspace_trim(self._h, 1 if everything else 0), "tsat_workspace_trim")
+
+    def btable_generation(self):
+        """counter bumped by every ``tsat_btable_batch`` on this handle: identifies the resident field tables"""
+        return int(self._lib.tsat_btable_generation(self._h))
 
 
 # ------------------------------------------------------------------------------------------------------
