@@ -31,6 +31,7 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 #define TSAT_SYNC() (tsat_emu::sync())
 #define TSAT_SYNC_LDS() (tsat_emu::sync())
 #define TSAT_SCHED_FENCE() ((void)0)
+#define TSAT_WAIT_LDS() ((void)0)
 #else
 #define TSAT_DEV __device__ __forceinline__
 // Each sweep is its own (non-inlined) function: the register allocator then works on one hot loop at a time
@@ -62,15 +63,22 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
   } while (0)
 #define TSAT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// s_waitcnt lgkmcnt(0) as an instruction the compiler's own wait-count pass sees (vmcnt / expcnt fields at their maxima: no wait).
+// Placed BEFORE a batch of LDS reads that is to stay in flight across the code that follows: lgkmcnt has four bits, so a use of
+// OLDER data behind more than 15 newer reads can only be expressed as lgkmcnt(0), which would wait for the new batch as well.
+#define TSAT_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)
 #endif
 
-// The float builds contract a*b + c ONLY where the source writes it in one expression (the language's own rule, decided by the front end
-// per expression): every float build — one trajectory per wavefront in its three LDS layouts, packed, packed8 — then rounds
-// the same source expression the same way and they agree bit for bit on the GPU as they do on the emulator. hipcc's default
-// (fast: the back end fuses across statements, differently in different code shapes) made the packed float builds differ from
-// the one-trajectory float build by rounding, which a budget-limited solve amplifies into another iteration path on five
-// trajectories in six. The double builds keep the default: their fused operations are spelled out where a choice exists.
-#if defined(TSAT_F32) && !defined(TSAT_EMU)
+// Every build contracts a*b + c ONLY where the source writes it in one expression (the language's own rule, decided by the front end
+// per expression): all builds of the solve kernel — one trajectory per wavefront in its LDS layouts, packed, packed8, both
+// precisions — then round the same source expression the same way and agree bit for bit on the GPU as they do on the emulator.
+// hipcc's default (fast: the back end fuses across statements, and picks which product of a*b + c*d to fuse differently in
+// different code shapes) made builds differ by rounding whenever a loop was restructured — the packed float builds from the
+// one-trajectory float build in round 2, the double builds from each other when the forward sweep got its two-knot read-ahead
+// in round 3 — and a budget-limited solve amplifies a rounding into another iteration path. Costs seven more fp64 instructions
+// per knot of the forward sweep (2.7 %) and nine per Jacobian knot. Where one expression holds two products, the fused one is
+// still spelled out (dmm_, dot3_, fma_ chains): the emulator, compiled without any contraction, keeps exactly those.
+#if !defined(TSAT_EMU)
 #pragma clang fp contract(on)
 #endif
 
@@ -219,7 +227,7 @@ constexpr int FB_BA = FB_XU + ((CK * XUW + GLDS - 1) / GLDS) * GLDS;   // 3 CK s
 constexpr int FB_BB = FB_BA + ((CK * 3 * RPU + GLDS - 1) / GLDS) * GLDS; // 3 CK stage rows, (b2, pad) [double only]
 constexpr int FB_SIZE = FB_BB + (BROW_UNITS == 2 ? ((CK * 3 * RPU + GLDS - 1) / GLDS) * GLDS : 0);
 // candidate_costs: per-knot costs of CG candidates x KB knots (+2: the CG summing lanes read different banks)
-constexpr int CG = 4, KB = 4 * WAVE, KBS = KB + 2;
+constexpr int CG = 2, KB = 4 * WAVE, KBS = KB + 2;
 #if defined(TSAT_DENSE) || (defined(TSAT_F32) && TSAT_OCC >= 3)
 constexpr int FWD_NBUF = 1;   // 20 KB budget: one buffer; the second wavefront on the SIMD covers the copy latency
 #else
@@ -870,6 +878,19 @@ TSAT_DEV void fwd_chunk_issue(real* fb, const TSAT_GLOBAL real* KDg, const TSAT_
 template <typename real> struct FwdOut { acc_t J; int ok; };
 template <typename real> struct BwdOut { acc_t dV1, dV2; int pd_ok; };
 
+// what the roll-out of one knot reads from the staged chunk: nominal (x,u) record, gains K (3 x 7 row-major) and d, three field rows
+template <typename real> struct KnotIn { real xu[XUW], kd[KDW], b0[3], b1[3], b2[3]; };
+template <typename real>
+TSAT_DEV KnotIn<real> fwd_knot_load(const real* fb, int kk) {
+  KnotIn<real> in;
+  const real* xu = fb + FB_XU + kk * XUW;
+  const real* kd = fb + FB_KD + kk * KDW;
+  for (int i = 0; i < XUW; ++i) in.xu[i] = xu[i];
+  for (int i = 0; i < KDW; ++i) in.kd[i] = kd[i];
+  fwd_brows<real>(fb, kk, in.b0, in.b1, in.b2);
+  return in;
+}
+
 // --------------------------------------------------------------------------------------------------
 // forward sweep: all line-search candidates at once (lane j: alpha = 2^-(j + alpha_shift)). The first n_cand lanes keep their
 // roll-outs in HBM (CAND[lane]); NOTHING else is computed in the sequential loop — the AL cost and the validity of a candidate are
@@ -900,13 +921,14 @@ TSAT_FWD void forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_c
     real* fb = lds + L_FWD + cur * FB_SIZE;
     real* fbn = lds + L_FWD + ((FWD_NBUF == 2) ? (1 - cur) : 0) * FB_SIZE;
     if (FWD_NBUF == 2 && nkn > 0) fwd_chunk_issue<real>(fbn, KDg, XUg, tr, kn, nkn, closed);
-    const real* KDc = fb + FB_KD;
-    const real* XUc = fb + FB_XU;
-    for (int kk = 0; kk < nk; ++kk) {
-      const real* xu = XUc + kk * XUW;
+    // The staged records are read one knot AHEAD: knot kk + 1's nominal record, gains and field rows are requested from LDS
+    // before knot kk is rolled out and have long arrived when its turn comes. Left to the compiler the reads sit right in front
+    // of their first use (register pressure), nine exposed LDS latencies per knot on the critical path of the launch.
+    auto knot = [&](const KnotIn<real>& kin, int kk) {
+      const real* xu = kin.xu;
       real u[3] = {xu[7], xu[8], xu[9]};
       if (closed) {
-        const real* kd = KDc + kk * KDW;
+        const real* kd = kin.kd;
         real dx[7];
         if (ES) {
           // quaternion_error(new, nominal) = [dw; MRP(q_nom^-1 (x) q_new)]  (src/quaternion_toolbox.jl:58-75)
@@ -933,10 +955,24 @@ TSAT_FWD void forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_c
         for (int i = 0; i < 7; ++i) cr[i] = x[i];
         for (int c = 0; c < 3; ++c) cr[7 + c] = u[c];
       }
-      real xn[7], b0[3], b1[3], b2[3];
-      fwd_brows<real>(fb, kk, b0, b1, b2);    // stage rows tau, tau + dtau/2, tau + dtau
-      rk_step<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, xn);
+      real xn[7];
+      rk_step<real, INTEG, DIAGJ, ES>(tr, x, u, kin.b0, kin.b1, kin.b2, xn);    // stage rows tau, tau + dtau/2, tau + dtau
       for (int i = 0; i < 7; ++i) x[i] = xn[i];
+    };
+    // two knots per turn, two register sets A / B: while one is rolled out the other is on its way from LDS (a single set would
+    // have to be copied, forty register moves per knot)
+    KnotIn<real> A = fwd_knot_load<real>(fb, 0);
+    for (int kk = 0; kk < nk; kk += 2) {
+      TSAT_WAIT_LDS();               // A has arrived (requested a whole knot ago); only then the next batch is put in flight
+      const KnotIn<real> B = fwd_knot_load<real>(fb, (kk + 1 < nk) ? kk + 1 : kk);
+      TSAT_SCHED_FENCE();
+      knot(A, kk);
+      if (kk + 1 < nk) {
+        TSAT_WAIT_LDS();
+        A = fwd_knot_load<real>(fb, (kk + 2 < nk) ? kk + 2 : kk + 1);
+        TSAT_SCHED_FENCE();
+        knot(B, kk + 1);
+      }
     }
     if (nkn > 0) {
       if (FWD_NBUF == 1) {          // single buffer: copy the next chunk now that this one has been consumed
@@ -959,6 +995,9 @@ TSAT_FWD void forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_c
 // packed builds run inside their sequential sweeps: stage_cost_gated on the stored record) and leaves it in LDS, KB knots at a
 // time; lane c then adds candidate c's costs IN KNOT ORDER, so J is, bit for bit, the sum a sequential roll-out accumulates. A
 // roll-out is valid when no |x_i|, |u_i| exceeded max_state and J is a number (a non-finite roll-out leaves amax = inf or J = NaN).
+// The records come from HBM: a step's loads (64 knots: multipliers + the candidates' records) are issued one step ahead of
+// their use, two register sets taking turns.
+template <typename real> struct CostIn { real lam[6], r[CG][XUW]; };
 template <typename real>
 TSAT_PHASE FwdOut<real> candidate_costs(TPtrs<real> p, int N, int c0, int nc, real mu, int term_mask, real max_state) {
   real* lds = lds_base<real>();
@@ -973,49 +1012,57 @@ TSAT_PHASE FwdOut<real> candidate_costs(TPtrs<real> p, int N, int c0, int nc, re
   for (int c = 0; c < CG; ++c) am[c] = 0;
   acc_t J = 0;
   const int cme = (lane < nc) ? lane : 0;
-  constexpr int KPL = KB / WAVE;               // knots per lane and block
-  for (int k0 = 0; k0 < N; k0 += KB) {
-    // multipliers and activity gates of this lane's knots: the same for every candidate
-    real lam[KPL][6], gate[KPL][6];
-    for (int i = 0; i < KPL; ++i) {
-      const int k = k0 + lane + WAVE * i, kc = (k < N - 1) ? k : 0;
-      for (int e = 0; e < 6; ++e) { lam[i][e] = p.LAM[(size_t)kc * LMW + e]; gate[i][e] = (lam[i][e] > 0) ? -inf_<real>() : (real)0; }
-    }
+  const TSAT_GLOBAL real* C0 = p.CAND + (size_t)c0 * (size_t)N * XUW;
+  const int S = (N + WAVE - 1) / WAVE;         // steps of 64 knots
+  constexpr int SPB = KB / WAVE;               // steps per summed block
+  auto load = [&](int st) {
+    CostIn<real> in;
+    const int k = st * WAVE + lane, kx = (k < N) ? k : N - 1, kl = (k < N - 1) ? k : 0;
+    for (int e = 0; e < 6; ++e) in.lam[e] = p.LAM[(size_t)kl * LMW + e];
+    for (int c = 0; c < CG; ++c)
+      for (int e = 0; e < XUW; ++e) in.r[c][e] = (c < nc) ? C0[((size_t)c * N + kx) * XUW + e] : (real)0;
+    return in;
+  };
+  auto step = [&](const CostIn<real>& in, int st) {
+    const int k = st * WAVE + lane;
+    real gate[6];
+    for (int e = 0; e < 6; ++e) gate[e] = (in.lam[e] > 0) ? -inf_<real>() : (real)0;
     for (int c = 0; c < CG; ++c) {
       if (c >= nc) break;
-      const TSAT_GLOBAL real* Cg = p.CAND + (size_t)(c0 + c) * (size_t)N * XUW;
-      // all KPL records of the candidate in flight at once (one exposed memory latency per candidate and block)
-      real r[KPL][10];
-      for (int i = 0; i < KPL; ++i) {
-        const int k = k0 + lane + WAVE * i, kc = (k < N) ? k : N - 1;
-        for (int e = 0; e < 10; ++e) r[i][e] = Cg[(size_t)kc * XUW + e];
-      }
       real a = am[c];
-      for (int i = 0; i < KPL; ++i) {
-        const int k = k0 + lane + WAVE * i;
-        if (k < N)
-          for (int e = 0; e < 7; ++e) a = fmaxabs_(a, r[i][e]);
-        if (k < N - 1) {
-          for (int e = 7; e < 10; ++e) a = fmaxabs_(a, r[i][e]);
-          L[c * KBS + lane + WAVE * i] = stage_cost_gated(tr, hw, r[i], r[i] + 7, lam[i], gate[i]);
-        }
+      if (k < N)
+        for (int e = 0; e < 7; ++e) a = fmaxabs_(a, in.r[c][e]);
+      if (k < N - 1) {
+        for (int e = 7; e < 10; ++e) a = fmaxabs_(a, in.r[c][e]);
+        L[c * KBS + (st % SPB) * WAVE + lane] = stage_cost_gated(tr, hw, in.r[c], in.r[c] + 7, in.lam, gate);
       }
       am[c] = a;
     }
-    TSAT_SYNC_LDS();
-    if (lane < nc) {
-      // candidate `lane`'s costs in knot order: the reads of a batch are issued together, the adds stay one dependent chain
-      const int n = (N - 1 - k0 < KB) ? (N - 1 - k0) : KB;
-      const real* Lc = L + cme * KBS;
-      int kk = 0;
-      for (; kk + 16 <= n; kk += 16) {
-        real v[16];
-        for (int e = 0; e < 16; ++e) v[e] = Lc[kk + e];
-        for (int e = 0; e < 16; ++e) J += (acc_t)v[e];
+    if ((st % SPB) == SPB - 1 || st == S - 1) {          // a block is complete: candidate `lane` adds its costs in knot order
+      TSAT_SYNC_LDS();
+      if (lane < nc) {
+        const int k0 = (st / SPB) * KB;
+        const int n = (N - 1 - k0 < KB) ? (N - 1 - k0) : KB;
+        const real* Lc = L + cme * KBS;
+        int kk = 0;
+        for (; kk + 16 <= n; kk += 16) {                 // the reads of a batch are issued together, the adds stay one chain
+          real v[16];
+          for (int e = 0; e < 16; ++e) v[e] = Lc[kk + e];
+          for (int e = 0; e < 16; ++e) J += (acc_t)v[e];
+        }
+        for (; kk < n; ++kk) J += (acc_t)Lc[kk];
       }
-      for (; kk < n; ++kk) J += (acc_t)Lc[kk];
+      TSAT_SYNC_LDS();
     }
-    TSAT_SYNC_LDS();
+  };
+  CostIn<real> A = load(0);
+  for (int st = 0; st < S; st += 2) {
+    const CostIn<real> B = load((st + 1 < S) ? st + 1 : st);
+    step(A, st);
+    if (st + 1 < S) {
+      A = load((st + 2 < S) ? st + 2 : st + 1);
+      step(B, st + 1);
+    }
   }
   real amax = 0;
   for (int c = 0; c < CG; ++c) {
