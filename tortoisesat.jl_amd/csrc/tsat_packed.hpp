@@ -148,20 +148,6 @@ TSAT_DEV TPtrs<real> group_ptrs(const KArgs<real>& a, int traj) {
 #else
 #define TSAT_PK_FWD TSAT_PHASE
 #endif
-// what the roll-out of one knot reads from the staged chunk (this lane's trajectory g): nominal (x,u) record, gains, three field rows
-template <typename real> struct PkKnotIn { real xu[XUW], kd[KDW], b0[3], b1[3], b2[3]; };
-template <typename real>
-TSAT_DEV PkKnotIn<real> pk_knot_load(const real* fb, int g, int kk) {
-  PkKnotIn<real> in;
-  const real* xu = fb + PK_R_XU + g * PK_SXU + kk * XUW;
-  const real* kd = fb + PK_R_KD + g * PK_SKD + kk * KDW;
-  const real* br = fb + PK_R_B + g * PK_SB + kk * 12;
-  for (int i = 0; i < XUW; ++i) in.xu[i] = xu[i];
-  for (int i = 0; i < KDW; ++i) in.kd[i] = kd[i];
-  for (int i = 0; i < 3; ++i) { in.b0[i] = br[i]; in.b1[i] = br[4 + i]; in.b2[i] = br[8 + i]; }
-  return in;
-}
-
 template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, int closed, int shift, int n_store, bool live, int N,
                                            real mu, const real nu[7], int term_mask, real max_state) {
@@ -294,25 +280,13 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
     real* fb = lds + L_FWD + cur * PK_FB;
     real* fbn = lds + L_FWD + ((PK_NBUF == 2) ? (1 - cur) : 0) * PK_FB;
     if (PK_NBUF == 2 && more) issue(fbn, kn);
-    // the staged nominal record, gains and field rows of knot kk + 1 are requested from LDS before knot kk is rolled out
-    // (TSAT_PK_READ_AHEAD; see forward_sweep in tsat_device.hpp): the reads of a knot otherwise sit right in front of their uses
-    PkKnotIn<real> in = pk_knot_load<real>(fb, myg, 0);
-#ifndef TSAT_EMU
-#pragma unroll
-#endif
     for (int kk = 0; kk < PK_CK; ++kk) {
       const int k = k0 + kk;
-      PkKnotIn<real> nx = in;
-      if (kk + 1 < PK_CK) {
-        TSAT_WAIT_LDS();
-        nx = pk_knot_load<real>(fb, myg, kk + 1);
-        TSAT_SCHED_FENCE();
-      }
       if (live && k < N - 1) {
-        const real* xu = in.xu;
+        const real* xu = fb + PK_R_XU + myg * PK_SXU + kk * XUW;
         real u[3] = {xu[7], xu[8], xu[9]};
         if (closed) {
-          const real* kd = in.kd;
+          const real* kd = fb + PK_R_KD + myg * PK_SKD + kk * KDW;
           real dx[7];
           if (ES) {
             // quaternion_error(new, nominal) = [dw; MRP(q_nom^-1 (x) q_new)]  (src/quaternion_toolbox.jl:58-75)
@@ -342,11 +316,12 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
 #else
         if (store) store_record5<real>(Cg + (size_t)k * XUW, x, u);   // REC_STORES store instructions (counted below)
 #endif
+        const real* br = fb + PK_R_B + myg * PK_SB + kk * 12;
+        const real b0[3] = {br[0], br[1], br[2]}, b1[3] = {br[4], br[5], br[6]}, b2[3] = {br[8], br[9], br[10]};
         real xn[7];
-        rk_step<real, INTEG, DIAGJ, ES>(tr, x, u, in.b0, in.b1, in.b2, xn);
+        rk_step<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, xn);
         for (int i = 0; i < 7; ++i) x[i] = xn[i];
       }
-      in = nx;
     }
     if (more) {
       if (PK_NBUF == 1) {          // single buffer: copy the next chunk now that this one has been consumed
