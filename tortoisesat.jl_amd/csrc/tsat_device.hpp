@@ -32,6 +32,7 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 #define TSAT_SYNC_LDS() (tsat_emu::sync())
 #define TSAT_SCHED_FENCE() ((void)0)
 #define TSAT_WAIT_LDS() ((void)0)
+#define TSAT_NO_UNROLL
 #else
 #define TSAT_DEV __device__ __forceinline__
 // Each sweep is its own (non-inlined) function: the register allocator then works on one hot loop at a time
@@ -67,6 +68,7 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 // Placed BEFORE a batch of LDS reads that is to stay in flight across the code that follows: lgkmcnt has four bits, so a use of
 // OLDER data behind more than 15 newer reads can only be expressed as lgkmcnt(0), which would wait for the new batch as well.
 #define TSAT_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)
+#define TSAT_NO_UNROLL _Pragma("unroll 1")
 #endif
 
 // Every build contracts a*b + c ONLY where the source writes it in one expression (the language's own rule, decided by the front end
@@ -114,6 +116,7 @@ constexpr int PSTRIDE = 64;
 // slowest wavefront, so re-rolls must stay rare: on the reference Monte-Carlo workload the accepted step is
 // alpha = 2^-j with j <= 5 in 99.8 % and j <= 11 in 99.96 % of the iterations.
 constexpr int NSTORE = 12;
+constexpr int N_FEW = 4;    // roll-outs a sweep keeps while the trajectory's line searches end early (solve_trajectory)
 // per-trajectory parameter record (reals)
 enum { P_X0 = 0, P_XF = 7, P_QD = 14, P_QFD = 21, P_RD = 28, P_ULO = 31, P_UHI = 34, P_J = 37, P_JI = 46,
        P_TAU0 = 55, P_DTAU = 56, P_DT = 57,
@@ -197,7 +200,19 @@ struct TPtrs {
   TSAT_GLOBAL real* LAM;         // [N-1][6]
   TSAT_GLOBAL real* CAND;        // [max_ls][N][10]
   const TSAT_GLOBAL real* bt;    // [n_tab][4]
+  // One-trajectory builds: the nominal trajectory is ADOPTED BY POINTER, not copied. The trajectory owns 1 + max_ls slabs of
+  // [N][10] records — slab 0 is its slot of a.XU (XU0), slabs 1 .. max_ls its candidate slots (CAND) — of which `cur` holds the
+  // nominal one (XU points at it) and the others, in order, take the stored candidates of a sweep (cand_slab). solve_trajectory
+  // copies the final nominal back into slab 0 once, at the end. The packed builds copy per iteration and leave cur = 0.
+  TSAT_GLOBAL real* XU0;
+  int cur;
 };
+// slab that holds stored candidate c (c-th slab other than the nominal one), and its address
+TSAT_DEV int cand_slab(int cur, int c) { return (c < cur) ? c : c + 1; }
+template <typename real>
+TSAT_DEV TSAT_GLOBAL real* slab_ptr(const TPtrs<real>& p, int N, int id) {
+  return (id == 0) ? p.XU0 : p.CAND + (size_t)(id - 1) * (size_t)N * XUW;
+}
 
 // LDS carve-up (in reals)
 constexpr int L_RED = 0;                 // 64 reduction scratch
@@ -441,6 +456,7 @@ struct Traj {
   real J[9];    // row-major J(r,c) = J[3r+c]
   real hJi[9];  // h * inv(J), row-major
   real h, hh, us;
+  real usj;     // us * hJi[0]: control scale of the isotropic-inertia variants (DIAGJ == 2), where h inv(J) = (h / j) I is folded into it
   double tau0, dtau;
   int N, n_tab;
   const TSAT_GLOBAL real* bt;  // [n_tab][4]
@@ -454,7 +470,7 @@ TSAT_DEV Traj<real> load_traj_at(const real* t, int N, int n_tab, const TSAT_GLO
   for (int i = 0; i < 7; ++i) { tr.xf[i] = t[P_XF + i]; tr.Qd[i] = t[P_QD + i]; tr.Qfd[i] = t[P_QFD + i]; }
   for (int i = 0; i < 3; ++i) { tr.Rd[i] = t[P_RD + i]; tr.ulo[i] = t[P_ULO + i]; tr.uhi[i] = t[P_UHI + i]; }
   for (int i = 0; i < 9; ++i) { tr.J[i] = t[P_J + i]; tr.hJi[i] = t[TR_HJI + i]; }
-  tr.h = t[P_DT]; tr.hh = t[TR_HH]; tr.us = t[TR_US];
+  tr.h = t[P_DT]; tr.hh = t[TR_HH]; tr.us = t[TR_US]; tr.usj = tr.us * tr.hJi[0];
   tr.tau0 = (double)t[P_TAU0] + (double)t[P_TAU0L]; tr.dtau = (double)t[P_DTAU] + (double)t[P_DTAUL];
   tr.N = N; tr.n_tab = n_tab; tr.bt = bt;
   return tr;
@@ -485,8 +501,11 @@ TSAT_DEV int brow_index(const Traj<real>& tr, int k, double c) {
   return i;
 }
 
-// h * f(x,u;b): src/DerivFunction.jl:4-44 on the 7-state. `us` = u * u_scale (:37). Intermediates needed by the
+// h * f(x,u;b): src/DerivFunction.jl:4-44 on the 7-state. `us` = u * u_scale (:37) — times h / j in the isotropic-inertia variant
+// (DIAGJ == 2: inv(J) is a multiple of the identity and w x Jw vanishes, so wdot = (h / j) (us x B_B) and the factor is folded
+// into the control once per knot, control_scale(), instead of into every stage's three components). Intermediates needed by the
 // tangent pass are returned in `sb`.
+template <typename real, int DIAGJ> TSAT_DEV real control_scale(const Traj<real>& tr) { return (DIAGJ == 2) ? tr.usj : tr.us; }
 template <typename real>
 struct StageBase {
   real w[3], qh[4], rn, c[3], BB[3], Jw[3];
@@ -524,9 +543,9 @@ TSAT_DEV void dyn_h(const Traj<real>& tr, const real x[7], const real us[3], con
   const real r0 = (DIAGJ == 2) ? t0 : t0 - (w1 * Jw2 - w2 * Jw1);
   const real r1 = (DIAGJ == 2) ? t1 : t1 - (w2 * Jw0 - w0 * Jw2);
   const real r2 = (DIAGJ == 2) ? t2 : t2 - (w0 * Jw1 - w1 * Jw0);
-  k[0] = DIAGJ ? tr.hJi[0] * r0 : tr.hJi[0] * r0 + tr.hJi[1] * r1 + tr.hJi[2] * r2;
-  k[1] = DIAGJ ? tr.hJi[4] * r1 : tr.hJi[3] * r0 + tr.hJi[4] * r1 + tr.hJi[5] * r2;
-  k[2] = DIAGJ ? tr.hJi[8] * r2 : tr.hJi[6] * r0 + tr.hJi[7] * r1 + tr.hJi[8] * r2;
+  k[0] = (DIAGJ == 2) ? r0 : DIAGJ ? tr.hJi[0] * r0 : tr.hJi[0] * r0 + tr.hJi[1] * r1 + tr.hJi[2] * r2;
+  k[1] = (DIAGJ == 2) ? r1 : DIAGJ ? tr.hJi[4] * r1 : tr.hJi[3] * r0 + tr.hJi[4] * r1 + tr.hJi[5] * r2;
+  k[2] = (DIAGJ == 2) ? r2 : DIAGJ ? tr.hJi[8] * r2 : tr.hJi[6] * r0 + tr.hJi[7] * r1 + tr.hJi[8] * r2;
   sb.w[0] = w0; sb.w[1] = w1; sb.w[2] = w2;
   sb.qh[0] = q0; sb.qh[1] = q1; sb.qh[2] = q2; sb.qh[3] = q3;
   sb.rn = rn;
@@ -536,51 +555,89 @@ TSAT_DEV void dyn_h(const Traj<real>& tr, const real x[7], const real us[3], con
 }
 
 // directional derivative of h*f at a stage (applied to a tangent instead of forming F):
-// dx = [dw; dq] tangent of the stage state, dus = u_scale * du.
-template <typename real, int DIAGJ>
+// dx = [dw; dq] tangent of the stage state, dus = (control scale) * du.
+// ZW / ZQ / ZU: the rate part, the quaternion part, the control part of the tangent is identically zero (the FIRST stage of a
+// seeded column: a unit rate has no attitude or control component, and so on) — the terms it would feed are left out instead of
+// being multiplied by zeros; what remains is evaluated exactly as in the general case, so a column has the same value either way
+// (up to the sign of a zero).
+template <typename real, int DIAGJ, bool ZW = false, bool ZQ = false, bool ZU = false>
 TSAT_DEV void dyn_h_jvp(const Traj<real>& tr, const StageBase<real>& sb, const real us[3], const real b[3],
                         const real dx[7], const real dus[3], real dk[7]) {
-  const real dw0 = dx[0], dw1 = dx[1], dw2 = dx[2];
   const real q0 = sb.qh[0], q1 = sb.qh[1], q2 = sb.qh[2], q3 = sb.qh[3];
-  // d qhat = rn (dq - qhat (qhat . dq))   (normalisation inside f, src/DerivFunction.jl:5)
-  const real t = q0 * dx[3] + q1 * dx[4] + q2 * dx[5] + q3 * dx[6];
-  const real e0 = sb.rn * (dx[3] - q0 * t);
-  const real e1 = sb.rn * (dx[4] - q1 * t);
-  const real e2 = sb.rn * (dx[5] - q2 * t);
-  const real e3 = sb.rn * (dx[6] - q3 * t);
   const real w0 = sb.w[0], w1 = sb.w[1], w2 = sb.w[2];
-  dk[3] = -tr.hh * ((e1 * w0 + e2 * w1 + e3 * w2) + (q1 * dw0 + q2 * dw1 + q3 * dw2));
-  dk[4] = tr.hh * ((e0 * w0 + (e2 * w2 - e3 * w1)) + (q0 * dw0 + (q2 * dw2 - q3 * dw1)));
-  dk[5] = tr.hh * ((e0 * w1 + (e3 * w0 - e1 * w2)) + (q0 * dw1 + (q3 * dw0 - q1 * dw2)));
-  dk[6] = tr.hh * ((e0 * w2 + (e1 * w1 - e2 * w0)) + (q0 * dw2 + (q1 * dw1 - q2 * dw0)));
-  // dc = dv x b + ds b ; dBB = 2 (dv x c + v x dc)
-  const real dc0 = (e2 * b[2] - e3 * b[1]) + e0 * b[0];
-  const real dc1 = (e3 * b[0] - e1 * b[2]) + e0 * b[1];
-  const real dc2 = (e1 * b[1] - e2 * b[0]) + e0 * b[2];
-  const real dB0 = 2 * ((e2 * sb.c[2] - e3 * sb.c[1]) + (q2 * dc2 - q3 * dc1));
-  const real dB1 = 2 * ((e3 * sb.c[0] - e1 * sb.c[2]) + (q3 * dc0 - q1 * dc2));
-  const real dB2 = 2 * ((e1 * sb.c[1] - e2 * sb.c[0]) + (q1 * dc1 - q2 * dc0));
-  // dtau = dus x BB + us x dBB
-  const real t0 = (dus[1] * sb.BB[2] - dus[2] * sb.BB[1]) + (us[1] * dB2 - us[2] * dB1);
-  const real t1 = (dus[2] * sb.BB[0] - dus[0] * sb.BB[2]) + (us[2] * dB0 - us[0] * dB2);
-  const real t2 = (dus[0] * sb.BB[1] - dus[1] * sb.BB[0]) + (us[0] * dB1 - us[1] * dB0);
+  real dw0 = 0, dw1 = 0, dw2 = 0;
+  if (!ZW) { dw0 = dx[0]; dw1 = dx[1]; dw2 = dx[2]; }
+  real e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+  if (!ZQ) {
+    // d qhat = rn (dq - qhat (qhat . dq))   (normalisation inside f, src/DerivFunction.jl:5)
+    const real t = q0 * dx[3] + q1 * dx[4] + q2 * dx[5] + q3 * dx[6];
+    e0 = sb.rn * (dx[3] - q0 * t);
+    e1 = sb.rn * (dx[4] - q1 * t);
+    e2 = sb.rn * (dx[5] - q2 * t);
+    e3 = sb.rn * (dx[6] - q3 * t);
+  }
+  if (!ZQ && !ZW) {
+    dk[3] = -tr.hh * ((e1 * w0 + e2 * w1 + e3 * w2) + (q1 * dw0 + q2 * dw1 + q3 * dw2));
+    dk[4] = tr.hh * ((e0 * w0 + (e2 * w2 - e3 * w1)) + (q0 * dw0 + (q2 * dw2 - q3 * dw1)));
+    dk[5] = tr.hh * ((e0 * w1 + (e3 * w0 - e1 * w2)) + (q0 * dw1 + (q3 * dw0 - q1 * dw2)));
+    dk[6] = tr.hh * ((e0 * w2 + (e1 * w1 - e2 * w0)) + (q0 * dw2 + (q1 * dw1 - q2 * dw0)));
+  } else if (!ZQ) {
+    dk[3] = -tr.hh * (e1 * w0 + e2 * w1 + e3 * w2);
+    dk[4] = tr.hh * (e0 * w0 + (e2 * w2 - e3 * w1));
+    dk[5] = tr.hh * (e0 * w1 + (e3 * w0 - e1 * w2));
+    dk[6] = tr.hh * (e0 * w2 + (e1 * w1 - e2 * w0));
+  } else if (!ZW) {
+    dk[3] = -tr.hh * (q1 * dw0 + q2 * dw1 + q3 * dw2);
+    dk[4] = tr.hh * (q0 * dw0 + (q2 * dw2 - q3 * dw1));
+    dk[5] = tr.hh * (q0 * dw1 + (q3 * dw0 - q1 * dw2));
+    dk[6] = tr.hh * (q0 * dw2 + (q1 * dw1 - q2 * dw0));
+  } else {
+    dk[3] = 0; dk[4] = 0; dk[5] = 0; dk[6] = 0;
+  }
+  // dtau = dus x BB + us x dBB, dBB = 2 (dv x c + v x dc), dc = dv x b + ds b
+  real t0 = 0, t1 = 0, t2 = 0;
+  if (!ZQ) {
+    const real dc0 = (e2 * b[2] - e3 * b[1]) + e0 * b[0];
+    const real dc1 = (e3 * b[0] - e1 * b[2]) + e0 * b[1];
+    const real dc2 = (e1 * b[1] - e2 * b[0]) + e0 * b[2];
+    const real dB0 = 2 * ((e2 * sb.c[2] - e3 * sb.c[1]) + (q2 * dc2 - q3 * dc1));
+    const real dB1 = 2 * ((e3 * sb.c[0] - e1 * sb.c[2]) + (q3 * dc0 - q1 * dc2));
+    const real dB2 = 2 * ((e1 * sb.c[1] - e2 * sb.c[0]) + (q1 * dc1 - q2 * dc0));
+    if (!ZU) {
+      t0 = (dus[1] * sb.BB[2] - dus[2] * sb.BB[1]) + (us[1] * dB2 - us[2] * dB1);
+      t1 = (dus[2] * sb.BB[0] - dus[0] * sb.BB[2]) + (us[2] * dB0 - us[0] * dB2);
+      t2 = (dus[0] * sb.BB[1] - dus[1] * sb.BB[0]) + (us[0] * dB1 - us[1] * dB0);
+    } else {
+      t0 = us[1] * dB2 - us[2] * dB1;
+      t1 = us[2] * dB0 - us[0] * dB2;
+      t2 = us[0] * dB1 - us[1] * dB0;
+    }
+  } else if (!ZU) {
+    t0 = dus[1] * sb.BB[2] - dus[2] * sb.BB[1];
+    t1 = dus[2] * sb.BB[0] - dus[0] * sb.BB[2];
+    t2 = dus[0] * sb.BB[1] - dus[1] * sb.BB[0];
+  }
   // d(w x Jw) = dw x Jw + w x J dw
-  const real dJ0 = DIAGJ ? tr.J[0] * dw0 : tr.J[0] * dw0 + tr.J[1] * dw1 + tr.J[2] * dw2;
-  const real dJ1 = DIAGJ ? tr.J[4] * dw1 : tr.J[3] * dw0 + tr.J[4] * dw1 + tr.J[5] * dw2;
-  const real dJ2 = DIAGJ ? tr.J[8] * dw2 : tr.J[6] * dw0 + tr.J[7] * dw1 + tr.J[8] * dw2;
-  const real r0 = (DIAGJ == 2) ? t0 : t0 - ((dw1 * sb.Jw[2] - dw2 * sb.Jw[1]) + (w1 * dJ2 - w2 * dJ1));
-  const real r1 = (DIAGJ == 2) ? t1 : t1 - ((dw2 * sb.Jw[0] - dw0 * sb.Jw[2]) + (w2 * dJ0 - w0 * dJ2));
-  const real r2 = (DIAGJ == 2) ? t2 : t2 - ((dw0 * sb.Jw[1] - dw1 * sb.Jw[0]) + (w0 * dJ1 - w1 * dJ0));
-  dk[0] = DIAGJ ? tr.hJi[0] * r0 : tr.hJi[0] * r0 + tr.hJi[1] * r1 + tr.hJi[2] * r2;
-  dk[1] = DIAGJ ? tr.hJi[4] * r1 : tr.hJi[3] * r0 + tr.hJi[4] * r1 + tr.hJi[5] * r2;
-  dk[2] = DIAGJ ? tr.hJi[8] * r2 : tr.hJi[6] * r0 + tr.hJi[7] * r1 + tr.hJi[8] * r2;
+  real r0 = t0, r1 = t1, r2 = t2;
+  if (DIAGJ != 2 && !ZW) {
+    const real dJ0 = DIAGJ ? tr.J[0] * dw0 : tr.J[0] * dw0 + tr.J[1] * dw1 + tr.J[2] * dw2;
+    const real dJ1 = DIAGJ ? tr.J[4] * dw1 : tr.J[3] * dw0 + tr.J[4] * dw1 + tr.J[5] * dw2;
+    const real dJ2 = DIAGJ ? tr.J[8] * dw2 : tr.J[6] * dw0 + tr.J[7] * dw1 + tr.J[8] * dw2;
+    r0 = t0 - ((dw1 * sb.Jw[2] - dw2 * sb.Jw[1]) + (w1 * dJ2 - w2 * dJ1));
+    r1 = t1 - ((dw2 * sb.Jw[0] - dw0 * sb.Jw[2]) + (w2 * dJ0 - w0 * dJ2));
+    r2 = t2 - ((dw0 * sb.Jw[1] - dw1 * sb.Jw[0]) + (w0 * dJ1 - w1 * dJ0));
+  }
+  dk[0] = (DIAGJ == 2) ? r0 : DIAGJ ? tr.hJi[0] * r0 : tr.hJi[0] * r0 + tr.hJi[1] * r1 + tr.hJi[2] * r2;
+  dk[1] = (DIAGJ == 2) ? r1 : DIAGJ ? tr.hJi[4] * r1 : tr.hJi[3] * r0 + tr.hJi[4] * r1 + tr.hJi[5] * r2;
+  dk[2] = (DIAGJ == 2) ? r2 : DIAGJ ? tr.hJi[8] * r2 : tr.hJi[6] * r0 + tr.hJi[7] * r1 + tr.hJi[8] * r2;
 }
 
 // one RK step (rk3: src/attitude_controller.jl:178-187; rk4: :122-132); b0/b1/b2 = rows at tau, tau+dtau/2, tau+dtau
 template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_DEV void rk_step(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3], const real b1[3],
                       const real b2[3], real xn[7]) {
-  const real us[3] = {u[0] * tr.us, u[1] * tr.us, u[2] * tr.us};
+  const real cs = control_scale<real, DIAGJ>(tr);
+  const real us[3] = {u[0] * cs, u[1] * cs, u[2] * cs};
   real k1[7], k2[7], k3[7], t[7];
   StageBase<real> sb;
   dyn_h<real, DIAGJ>(tr, x, us, b0, k1, sb);
@@ -606,10 +663,11 @@ TSAT_DEV void rk_step(const Traj<real>& tr, const real x[7], const real u[3], co
 // splitting the columns over lanes (the packed build's Jacobian lanes, tsat_packed.hpp) leaves every column's arithmetic
 // untouched.
 template <typename real> struct RkStages { StageBase<real> s1, s2, s3, s4; real us[3]; };
+template <int S> struct SeedTag { static constexpr int value = S; };
 template <typename real, int INTEG, int DIAGJ>
 TSAT_DEV void rk_primal(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3], const real b1[3],
                         const real b2[3], RkStages<real>& st) {
-  for (int a = 0; a < 3; ++a) st.us[a] = u[a] * tr.us;
+  for (int a = 0; a < 3; ++a) st.us[a] = u[a] * control_scale<real, DIAGJ>(tr);
   real k1[7], k2[7], k3[7], t[7];
   dyn_h<real, DIAGJ>(tr, x, st.us, b0, k1, st.s1);
   for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k1[i];
@@ -625,14 +683,21 @@ TSAT_DEV void rk_primal(const Traj<real>& tr, const real x[7], const real u[3], 
     dyn_h<real, DIAGJ>(tr, t, st.us, b2, k4, st.s4);
   }
 }
-// directional derivative of the RK step along (ex, du): out = ex + (weighted sum of the stage tangents)
-template <typename real, int INTEG, int DIAGJ>
+// directional derivative of the RK step along (ex, du): out = ex + (weighted sum of the stage tangents).
+// SEED: what the seed (ex, du) is known to be — 0 anything; 1 a rate direction (no attitude, no control part); 2 an attitude
+// direction (no rate, no control part); 3 a control direction (ex = 0). The first stage sees the seed itself and leaves the terms
+// of its zero parts out; a control seed reaches the second stage still without an attitude part.
+template <typename real, int INTEG, int DIAGJ, int SEED = 0>
 TSAT_DEV void rk_tangent(const Traj<real>& tr, const RkStages<real>& st, const real b0[3], const real b1[3], const real b2[3],
                          const real ex[7], const real du[3], real out[7]) {
   real v1[7], v2[7], v3[7], arg[7];
-  dyn_h_jvp<real, DIAGJ>(tr, st.s1, st.us, b0, ex, du, v1);
+  if (SEED == 1) dyn_h_jvp<real, DIAGJ, false, true, true>(tr, st.s1, st.us, b0, ex, du, v1);
+  else if (SEED == 2) dyn_h_jvp<real, DIAGJ, true, false, true>(tr, st.s1, st.us, b0, ex, du, v1);
+  else if (SEED == 3) dyn_h_jvp<real, DIAGJ, true, true, false>(tr, st.s1, st.us, b0, ex, du, v1);
+  else dyn_h_jvp<real, DIAGJ>(tr, st.s1, st.us, b0, ex, du, v1);
   for (int i = 0; i < 7; ++i) arg[i] = ex[i] + (real)0.5 * v1[i];
-  dyn_h_jvp<real, DIAGJ>(tr, st.s2, st.us, b1, arg, du, v2);
+  if (SEED == 3) dyn_h_jvp<real, DIAGJ, false, true, false>(tr, st.s2, st.us, b1, arg, du, v2);
+  else dyn_h_jvp<real, DIAGJ>(tr, st.s2, st.us, b1, arg, du, v2);
   if (INTEG == 3) {
     for (int i = 0; i < 7; ++i) arg[i] = ex[i] - v1[i] + 2 * v2[i];
     dyn_h_jvp<real, DIAGJ>(tr, st.s3, st.us, b2, arg, du, v3);
@@ -652,16 +717,20 @@ TSAT_DEV void rk_jacobian_cols(const Traj<real>& tr, const real x[7], const real
                                const real b1[3], const real b2[3], FP F, int c_lo, int c_hi) {
   RkStages<real> st;
   rk_primal<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, st);
-#ifndef TSAT_EMU
-#pragma unroll 1
-#endif
-  for (int c = c_lo; c < c_hi; ++c) {
+  auto column = [&](auto seed, int c) {
     real ex[7], du[3], out[7];
     for (int i = 0; i < 7; ++i) ex[i] = (i == c) ? (real)1 : (real)0;
-    for (int a = 0; a < 3; ++a) du[a] = (c == 7 + a) ? tr.us : (real)0;
-    rk_tangent<real, INTEG, DIAGJ>(tr, st, b0, b1, b2, ex, du, out);
+    for (int a = 0; a < 3; ++a) du[a] = (c == 7 + a) ? control_scale<real, DIAGJ>(tr) : (real)0;
+    rk_tangent<real, INTEG, DIAGJ, decltype(seed)::value>(tr, st, b0, b1, b2, ex, du, out);
     for (int i = 0; i < 7; ++i) F[c * FSS + i] = out[i];
-  }
+  };
+  // one loop per kind of seed (rate, quaternion, control): each gets the tangent pass without the terms of its zero parts
+  TSAT_NO_UNROLL
+  for (int c = c_lo; c < (c_hi < 3 ? c_hi : 3); ++c) column(SeedTag<1>{}, c);
+  TSAT_NO_UNROLL
+  for (int c = (c_lo > 3 ? c_lo : 3); c < (c_hi < 7 ? c_hi : 7); ++c) column(SeedTag<2>{}, c);
+  TSAT_NO_UNROLL
+  for (int c = (c_lo > 7 ? c_lo : 7); c < c_hi; ++c) column(SeedTag<3>{}, c);
 }
 template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_DEV void rk_jacobian(const Traj<real>& tr, const real x[7], const real u[3], const real b0[3],
@@ -691,10 +760,7 @@ TSAT_DEV void rk_jacobian_es_cols(const Traj<real>& tr, const real x[7], const r
   RkStages<real> st;
   rk_primal<real, INTEG, DIAGJ>(tr, x, u, b0, b1, b2, st);
   const real sq = x[3], v0 = x[4], v1 = x[5], v2 = x[6];
-#ifndef TSAT_EMU
-#pragma unroll 1
-#endif
-  for (int c = c_lo; c < c_hi; ++c) {
+  auto column = [&](auto seed, int c) {
     real ex[7], du[3], out[7], o[3];
     const int t = c - 3;      // column of G(q_k) = [-v'; s I + hat(v)] on the attitude columns
     for (int i = 0; i < 3; ++i) ex[i] = (i == c) ? (real)1 : (real)0;
@@ -702,11 +768,18 @@ TSAT_DEV void rk_jacobian_es_cols(const Traj<real>& tr, const real x[7], const r
     ex[4] = (t == 0) ? sq : (t == 1 ? -v2 : (t == 2 ? v1 : (real)0));
     ex[5] = (t == 0) ? v2 : (t == 1 ? sq : (t == 2 ? -v0 : (real)0));
     ex[6] = (t == 0) ? -v1 : (t == 1 ? v0 : (t == 2 ? sq : (real)0));
-    for (int a = 0; a < 3; ++a) du[a] = (c == 6 + a) ? tr.us : (real)0;
-    rk_tangent<real, INTEG, DIAGJ>(tr, st, b0, b1, b2, ex, du, out);
+    for (int a = 0; a < 3; ++a) du[a] = (c == 6 + a) ? control_scale<real, DIAGJ>(tr) : (real)0;
+    rk_tangent<real, INTEG, DIAGJ, decltype(seed)::value>(tr, st, b0, b1, b2, ex, du, out);
     gt_apply(qn, out[3], out[4], out[5], out[6], o);
     for (int i = 0; i < 3; ++i) { F[c * FSS + i] = out[i]; F[c * FSS + 3 + i] = o[i]; }
-  }
+  };
+  // one loop per kind of seed (rate, attitude, control): each gets the tangent pass without the terms of its zero parts
+  TSAT_NO_UNROLL
+  for (int c = c_lo; c < (c_hi < 3 ? c_hi : 3); ++c) column(SeedTag<1>{}, c);
+  TSAT_NO_UNROLL
+  for (int c = (c_lo > 3 ? c_lo : 3); c < (c_hi < 6 ? c_hi : 6); ++c) column(SeedTag<2>{}, c);
+  TSAT_NO_UNROLL
+  for (int c = (c_lo > 6 ? c_lo : 6); c < c_hi; ++c) column(SeedTag<3>{}, c);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -909,7 +982,7 @@ TSAT_FWD void forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_c
   for (int i = 0; i < 7; ++i) x[i] = lds[L_TR + P_X0 + i];
   const TSAT_GLOBAL real* XUg = p.XU;
   const TSAT_GLOBAL real* KDg = p.KD;
-  TSAT_GLOBAL real* Cg = p.CAND + (size_t)(lane < n_cand ? lane : 0) * (size_t)N * XUW;
+  TSAT_GLOBAL real* Cg = slab_ptr<real>(p, N, cand_slab(p.cur, lane < n_cand ? lane : 0));
   // chunk pipeline: buffer `cur` holds the chunk being rolled out; with two buffers the copy of the next chunk is issued
   // before the roll-out and has landed long before it ends (32 knots ~ 30 us against ~1 us of memory latency)
   int cur = 0;
@@ -1012,7 +1085,8 @@ TSAT_PHASE FwdOut<real> candidate_costs(TPtrs<real> p, int N, int c0, int nc, re
   for (int c = 0; c < CG; ++c) am[c] = 0;
   acc_t J = 0;
   const int cme = (lane < nc) ? lane : 0;
-  const TSAT_GLOBAL real* C0 = p.CAND + (size_t)c0 * (size_t)N * XUW;
+  const TSAT_GLOBAL real* Cc[CG];
+  for (int c = 0; c < CG; ++c) Cc[c] = slab_ptr<real>(p, N, cand_slab(p.cur, c0 + (c < nc ? c : 0)));
   const int S = (N + WAVE - 1) / WAVE;         // steps of 64 knots
   constexpr int SPB = KB / WAVE;               // steps per summed block
   auto load = [&](int st) {
@@ -1020,7 +1094,7 @@ TSAT_PHASE FwdOut<real> candidate_costs(TPtrs<real> p, int N, int c0, int nc, re
     const int k = st * WAVE + lane, kx = (k < N) ? k : N - 1, kl = (k < N - 1) ? k : 0;
     for (int e = 0; e < 6; ++e) in.lam[e] = p.LAM[(size_t)kl * LMW + e];
     for (int c = 0; c < CG; ++c)
-      for (int e = 0; e < XUW; ++e) in.r[c][e] = (c < nc) ? C0[((size_t)c * N + kx) * XUW + e] : (real)0;
+      for (int e = 0; e < XUW; ++e) in.r[c][e] = (c < nc) ? Cc[c][(size_t)kx * XUW + e] : (real)0;
     return in;
   };
   auto step = [&](const CostIn<real>& in, int st) {
@@ -1071,7 +1145,7 @@ TSAT_PHASE FwdOut<real> candidate_costs(TPtrs<real> p, int N, int c0, int nc, re
     amax = (lane == c) ? m : amax;
   }
   real nu[7], xN[7];
-  const TSAT_GLOBAL real* cN = p.CAND + ((size_t)(c0 + cme) * (size_t)N + (size_t)(N - 1)) * XUW;
+  const TSAT_GLOBAL real* cN = slab_ptr<real>(p, N, cand_slab(p.cur, c0 + cme)) + (size_t)(N - 1) * XUW;
   for (int i = 0; i < 7; ++i) { nu[i] = lds[L_NU + i]; xN[i] = cN[i]; }
   J += (acc_t)term_cost(tr, xN, nu, mu, term_mask, true);
   FwdOut<real> out;
@@ -1175,12 +1249,15 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
   // ---- lane roles. Every step is branch-free: each lane owns LDS offsets for its operands and outputs; lanes
   // without a role in a step compute on harmless operands and write to L_SINK. -----------------------------
   // step 1: W~[r1][c1] = sum_m S~[r1][m] F[m][c1] (row NH of S~ is s'), plus columns >= 8 on the lanes with small c1
-  const int r1 = lane & 7, c1 = lane >> 3;
+  // (NH = 6: the 7 x 9 elements of W~ are exactly 63 lanes, one dot product each; NH = 7: 8 x 10 = 80 elements, lane (r, c) of
+  // an 8 x 8 grid takes column c and, for small c, column 8 + c as well)
+  constexpr bool ONE_DOT = (NH + 1) * NC <= WAVE;
+  const int r1 = ONE_DOT ? lane % (NH + 1) : (lane & 7), c1 = ONE_DOT ? lane / (NH + 1) : (lane >> 3);
   const int r1c = (r1 <= NH) ? r1 : NH;
   const int s1_st = L_ST + r1c * 9;
   const int s1_fa = ((c1 < NC) ? c1 : 0) * FSR, s1_fb = ((8 + (c1 & 1) < NC) ? (8 + (c1 & 1)) : 0) * FSR;   // relative to the knot record
-  const int s1_oa = (r1 <= NH) ? (L_WT + c1 * 9 + r1) : L_SINK;
-  const int s1_ob = (r1 <= NH && 8 + c1 < NC) ? (L_WT + (8 + c1) * 9 + r1) : L_SINK;
+  const int s1_oa = (r1 <= NH && c1 < NC) ? (L_WT + c1 * 9 + r1) : L_SINK;
+  const int s1_ob = (!ONE_DOT && r1 <= NH && 8 + c1 < NC) ? (L_WT + (8 + c1) * 9 + r1) : L_SINK;
   // step 2: acc = diag + init + dot(F[:,colA], opB[0..NH-1]) -> lds[o1], lds[o2]
   int s2_fa = 0, s2_b = L_WT, s2_init = -1, s2_o1 = L_SINK, s2_o2 = L_SINK;
   real s2_diag = 0;
@@ -1231,7 +1308,7 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
   real fa1[NH], fb1[NH], fa2[NH], ini2;
   {
     const int rcb = L_REC + (nk - 1) * RECS;
-    for (int m = 0; m < NH; ++m) { fa1[m] = lds[rcb + s1_fa + m]; fb1[m] = lds[rcb + s1_fb + m]; fa2[m] = lds[rcb + s2_fa + m]; }
+    for (int m = 0; m < NH; ++m) { fa1[m] = lds[rcb + s1_fa + m]; fb1[m] = ONE_DOT ? (real)0 : lds[rcb + s1_fb + m]; fa2[m] = lds[rcb + s2_fa + m]; }
     ini2 = lds[(s2_init >= 0) ? (rcb + s2_init) : L_ZERO];
   }
   for (int l = nk - 1; l >= 0; --l) {
@@ -1242,9 +1319,12 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
       for (int m = 0; m < NH; ++m) sv[m] = lds[s1_st + m];
       TSAT_SCHED_FENCE();
       real acc = 0, acc2 = 0;
-      for (int m = 0; m < NH; ++m) { acc = fma_(sv[m], fa1[m], acc); acc2 = fma_(sv[m], fb1[m], acc2); }
+      for (int m = 0; m < NH; ++m) {
+        acc = fma_(sv[m], fa1[m], acc);
+        if (!ONE_DOT) acc2 = fma_(sv[m], fb1[m], acc2);
+      }
       role_store(lds, s1_oa, L_SINK, acc);
-      role_store(lds, s1_ob, L_SINK, acc2);
+      if (!ONE_DOT) role_store(lds, s1_ob, L_SINK, acc2);
     }
     TSAT_SYNC_LDS();
     // step 2: Qxx = lxx + A'SA, Qux = B'SA, Quu = luu + B'SB, Qu = lu + B's
@@ -1303,7 +1383,7 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
       for (int c = 0; c < 3; ++c) { ki[c] = lds[s4_ki + c * 8]; kj[c] = lds[s4_kj + c * 8]; }
       if (l > 0) {   // prefetch the next knot's Jacobian columns (written by jacobian_chunk, never by this loop)
         const int rcn = rcb - RECS;
-        for (int m = 0; m < NH; ++m) { fa1[m] = lds[rcn + s1_fa + m]; fb1[m] = lds[rcn + s1_fb + m]; fa2[m] = lds[rcn + s2_fa + m]; }
+        for (int m = 0; m < NH; ++m) { fa1[m] = lds[rcn + s1_fa + m]; if (!ONE_DOT) fb1[m] = lds[rcn + s1_fb + m]; fa2[m] = lds[rcn + s2_fa + m]; }
         ini2 = lds[(s2_init >= 0) ? (rcn + s2_init) : L_ZERO];
       }
       TSAT_SCHED_FENCE();
@@ -1501,6 +1581,22 @@ TSAT_PHASE real adopt_and_gradient(TPtrs<real> p, int N, int jw) {
   return g / (real)(N - 1);
 }
 
+// Todorov gradient mean_k max_i |d_k,i| / (|u_k,i| + 1) with the controls of the record slab `XUs` (the nominal trajectory, or
+// the candidate about to become it): what adopt_and_gradient returns, without the copy
+template <typename real>
+TSAT_PHASE real todorov_gradient(const TSAT_GLOBAL real* XUs, const TSAT_GLOBAL real* KDg, int N) {
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE();
+  real g = 0;
+  for (int k = lane; k < N - 1; k += WAVE) {
+    real m = 0;
+    for (int c = 0; c < 3; ++c) m = fmax_(m, fabs_(KDg[(size_t)k * KDW + 21 + c]) / (fabs_(XUs[(size_t)k * XUW + 7 + c]) + (real)1));
+    g += m;
+  }
+  g = wave_sum(g, lds + L_RED);
+  return g / (real)(N - 1);
+}
+
 // --------------------------------------------------------------------------------------------------
 // the whole AL-iLQR solve of one trajectory by one wavefront
 // --------------------------------------------------------------------------------------------------
@@ -1519,6 +1615,12 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   p.LAM = (TSAT_GLOBAL real*)(a.LAM + (size_t)traj * lam_stride<real>(NS));
   p.CAND = (TSAT_GLOBAL real*)(a.CAND + (size_t)traj * a.max_ls * xu_stride<real>(NS));
   p.bt = (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[traj] * n_tab * 4);
+  p.XU0 = p.XU; p.cur = 0;
+  // the stored candidate `slot` of the sweep just evaluated becomes the nominal trajectory: a pointer swap
+  auto adopt = [&](int slot) {
+    p.cur = cand_slab(p.cur, slot);
+    p.XU = slab_ptr<real>(p, N, p.cur);
+  };
   stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)traj * PSTRIDE), (real)o.u_scale);
 
   const real* U0g = a.U0 + (size_t)traj * u0_stride<real>(NS);
@@ -1540,6 +1642,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   int status = TSAT_MAX_OUTER, outer_iters = 0, inner_iters = 0, ls_trials = 0, n_backward = 0, n_forward = 0,
       bp_restarts = 0, fp_fails = 0;
   real grad = 0;
+  int last_jw = 0;                  // accepted line-search index of the previous iteration (first iteration: a shallow search is assumed)
   unsigned long long pc_fwd = 0, pc_par = 0;
 
   // open-loop rollout of U0
@@ -1550,8 +1653,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   const acc_t J0 = wave_bcast(f0.J, 0, red64());
   const int ok0 = wave_first<real>(!f0.ok, lds + L_RED) > 0;  // lane 0 ok?
   TSAT_SYNC();
-  (void)adopt_and_gradient<real>(p, N, 0);
-  TSAT_SYNC();
+  adopt(0);
   if (!ok0 || !(J0 - J0 == 0)) {
     status = TSAT_DIVERGED;
   } else {
@@ -1586,11 +1688,16 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
         // exactly what sequential backtracking picks, and the usual winner is among the first CG. Candidates beyond the stored
         // ones (max_linesearch > n_store) take another sweep with the next n_store.
         const unsigned long long t_f0 = tick_();
-        const int n_store = (o.max_linesearch < a.max_ls) ? o.max_linesearch : a.max_ls;
+        // How many roll-outs a sweep keeps costs nothing in time (the stores are never waited on) but is most of the launch's HBM
+        // writes, so a trajectory whose last accepted step was among the first few keeps only N_FEW at first and takes the rest in
+        // a further sweep if it has to; one that has been searching deep keeps all the slots at once. The accepted candidate — and
+        // with it every result — is the same either way.
+        const int n_slots = (o.max_linesearch < a.max_ls) ? o.max_linesearch : a.max_ls;
         int jw = WAVE, slot = 0;
         acc_t Jw = 0;
         unsigned long long t_cost = 0;
-        for (int shift = 0; shift < o.max_linesearch && jw == WAVE; shift += n_store) {
+        int n_store = (last_jw >= N_FEW - 1 || n_slots < N_FEW) ? n_slots : N_FEW;
+        for (int shift = 0; shift < o.max_linesearch && jw == WAVE; shift += n_store, n_store = n_slots) {
           const int n_here = (o.max_linesearch - shift < n_store) ? o.max_linesearch - shift : n_store;
           forward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, 1, n_here, shift);
           n_forward++;
@@ -1620,10 +1727,12 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
         pc_par += t_cost;
         acc_t J;
         TSAT_SYNC();
+        last_jw = (jw < WAVE) ? jw : o.max_linesearch;
         if (jw < WAVE) {
           J = Jw;
           ls_trials += jw + 1;
-          grad = adopt_and_gradient<real>(p, N, slot);
+          adopt(slot);
+          grad = todorov_gradient<real>(p.XU, p.KD, N);
         } else {
           J = Jprev;
           ls_trials += o.max_linesearch;
@@ -1631,7 +1740,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
           drho = (drho * (real)o.reg_scale > (real)o.reg_scale) ? drho * (real)o.reg_scale : (real)o.reg_scale;
           rho = (rho * drho > (real)o.reg_min) ? rho * drho : (real)o.reg_min;
           rho += (real)o.reg_fp;
-          grad = adopt_and_gradient<real>(p, N, -1);
+          grad = todorov_gradient<real>(p.XU, p.KD, N);
         }
         TSAT_SYNC();
         pc_par += tick_() - t_f1;
@@ -1667,6 +1776,12 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
     }
   }
   TSAT_SYNC();
+  if (p.cur != 0) {     // the nominal trajectory lives in one of the candidate slabs: bring it home, once per solve
+    for (int k = lane; k < N; k += WAVE)
+      for (int i = 0; i < XUW; ++i) p.XU0[(size_t)k * XUW + i] = p.XU[(size_t)k * XUW + i];
+    p.XU = p.XU0; p.cur = 0;
+    TSAT_SYNC();
+  }
   const real cmax = violation_and_duals<real>(p, N, mu, tmask, 0, (real)o.dual_max);
   const acc_t cost = nominal_cost<real>(p, N, mu, tmask, 0);
   const acc_t cost_al = nominal_cost<real>(p, N, mu, tmask, 1);
@@ -1780,6 +1895,7 @@ TSAT_PHASE void tv_jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int n
     Traj<real> tr = load_traj<real>(N, n_tab, p.bt);
     tr.h = hl; tr.hh = (real)0.5 * hl;
     for (int i = 0; i < 9; ++i) tr.hJi[i] = hl * lds[L_TR + P_JI + i];
+    tr.usj = tr.us * tr.hJi[0];
     const int k = k0 + lane;
     const TSAT_GLOBAL real* xu = p.XU + (size_t)k * XUW;
     real x[7], u[3], b0[3], b1[3], b2[3];
@@ -1836,7 +1952,7 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
   TPtrs<real> p;
   p.XU = (TSAT_GLOBAL real*)(a.XUR + (size_t)traj * NS * XUW);
   p.KD = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * (NS - 1) * KDW);
-  p.LAM = nullptr; p.CAND = nullptr;
+  p.LAM = nullptr; p.CAND = nullptr; p.XU0 = p.XU; p.cur = 0;
   p.bt = (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[traj] * n_tab * 4);
   stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)traj * PSTRIDE), a.us);   // whole record, P_QATT slots included
   TSAT_SYNC();
@@ -1929,7 +2045,8 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
     } else {
       for (int i = 0; i < 36; ++i) nz[i] = 0;
     }
-    const real us[3] = {u[0] * tr.us, u[1] * tr.us, u[2] * tr.us};
+    const real cs = control_scale<real, DIAGJ>(tr);
+    const real us[3] = {u[0] * cs, u[1] * cs, u[2] * cs};
     real k1[7], k2[7], k3[7], k4[7], t[7];
     dyn_sim_h<real, DIAGJ>(tr, x, us, b0, noisy, nz, k1);
     for (int i = 0; i < 7; ++i) t[i] = x[i] + (real)0.5 * k1[i];

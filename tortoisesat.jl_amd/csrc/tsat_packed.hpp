@@ -134,6 +134,7 @@ TSAT_DEV TPtrs<real> group_ptrs(const KArgs<real>& a, int traj) {
   p.LAM = (TSAT_GLOBAL real*)(a.LAM + (size_t)traj * lam_stride<real>(NS));
   p.CAND = (TSAT_GLOBAL real*)(a.CAND + (size_t)traj * a.max_ls * xu_stride<real>(NS));
   p.bt = (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[traj] * a.n_tab * 4);
+  p.XU0 = p.XU; p.cur = 0;
   return p;
 }
 
@@ -165,7 +166,7 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
     for (int i = 0; i < 3; ++i) { tr.Rd[i] = P[P_RD + i]; tr.ulo[i] = P[P_ULO + i]; tr.uhi[i] = P[P_UHI + i]; }
     tr.h = P[P_DT];
     for (int i = 0; i < 9; ++i) { tr.J[i] = P[P_J + i]; tr.hJi[i] = tr.h * P[P_JI + i]; }
-    tr.hh = (real)0.5 * tr.h; tr.us = (real)a.opt.u_scale;
+    tr.hh = (real)0.5 * tr.h; tr.us = (real)a.opt.u_scale; tr.usj = tr.us * tr.hJi[0];
     tr.tau0 = (double)P[P_TAU0] + (double)P[P_TAU0L]; tr.dtau = (double)P[P_DTAU] + (double)P[P_DTAUL];
     tr.N = N; tr.n_tab = n_tab; tr.bt = nullptr;
   }
