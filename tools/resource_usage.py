@@ -75,6 +75,21 @@ def function_info(path):
     return out
 
 
+def own_name(full):
+    """`tsat::name<args>` of a demangled signature (return type, parameter list and nested tsat:: qualifiers in the arguments
+    set aside), or None for kernels and foreign functions"""
+    sig = full.split("(")[0]
+    depth, start = 0, None
+    for i, ch in enumerate(sig):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif depth == 0 and sig.startswith("tsat::", i):
+            start = i + 6
+    return sig[start:].strip() if start is not None else None
+
+
 def main():
     dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03", "resource_usage.txt")
     lines = ["Register / scratch / LDS budget of every build of the solve kernel (tools/resource_usage.py; hipcc "
@@ -98,19 +113,20 @@ def main():
             by_name = collections.OrderedDict()
             for f, d in fi.items():
                 full = dm.get(f, f)
-                if "tsat::" not in full or "NumVgprs" not in d:
+                own = own_name(full)
+                if own is None or "NumVgprs" not in d:
                     continue
-                base = re.sub(r"<.*", "", full.split("tsat::")[1])
-                by_name.setdefault(base, []).append((full, d))
+                base = re.sub(r"<.*", "", own)
+                by_name.setdefault(base, []).append((own, d))
             for base, lst in by_name.items():
-                bench = [x for x in lst if any(b in x[0] for b in BENCH) or "<double>" in x[0] or "<float>" in x[0] or re.search(r"<(double|float), [67]>", x[0])]
+                bench = [x for x in lst if any(b in x[0] for b in BENCH) or re.fullmatch(r"\w+<(double|float)(, 6(, tsat::\w+(<1>)?)?)?\s?>", x[0])]
                 worst = max(lst, key=lambda x: x[1]["scratch_insts"])
                 shown = []
-                for full, d in (bench[:2] + [worst]):
+                for full, d in (bench[:3] + [worst]):
                     if full in shown:
                         continue
                     shown.append(full)
-                    nm = re.sub(r"\(.*", "", full.split("tsat::", 1)[1])[:100]
+                    nm = full[:100]
                     lines.append(f"  {nm:<100} {d['NumVgprs']:>5} {d.get('NumAgprs', 0):>5} {d.get('ScratchSize', 0):>9} {d['scratch_insts']:>13} {d['n']:>6}")
             lines.append("")
     os.makedirs(os.path.dirname(dst), exist_ok=True)

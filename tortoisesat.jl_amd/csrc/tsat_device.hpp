@@ -39,8 +39,14 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 // instead of on the whole solve, which otherwise spills loop invariants of every phase into every other phase.
 #define TSAT_PHASE __device__ __noinline__
 // the forward sweep is inlined into the kernel body: there the register allocator can park values in AGPRs
-// (one-instruction reload), while a called function has to spill to scratch memory
+// (one-instruction reload), while a called function has to spill to scratch memory. The dense build has no AGPRs to park
+// anything in (256 registers in all, two wavefronts per SIMD): there the sweep is a function of its own like the other phases,
+// with its own register allocation, and the kernel body around it keeps its counters and pointers out of scratch.
+#if defined(TSAT_DENSE) && !defined(TSAT_PACKED)
+#define TSAT_FWD __device__ __noinline__
+#else
 #define TSAT_FWD __device__ __forceinline__
+#endif
 // HBM pointers that cross a (non-inlined) function boundary must carry their address space, otherwise every
 // access through them is a flat_* instruction (both memory pipes, both wait counters) instead of global_*.
 #if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
@@ -1034,6 +1040,14 @@ TSAT_FWD void forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_c
     };
     // two knots per turn, two register sets A / B: while one is rolled out the other is on its way from LDS (a single set would
     // have to be copied, forty register moves per knot)
+#if defined(TSAT_DENSE) && !defined(TSAT_F32)
+    // the dense double build (256 registers in all, no AGPRs) cannot hold two read-ahead sets of 43 doubles without spilling
+    // into this loop; its second wavefront per SIMD covers part of the LDS latency instead
+    for (int kk = 0; kk < nk; ++kk) {
+      const KnotIn<real> A = fwd_knot_load<real>(fb, kk);
+      knot(A, kk);
+    }
+#else
     KnotIn<real> A = fwd_knot_load<real>(fb, 0);
     for (int kk = 0; kk < nk; kk += 2) {
       TSAT_WAIT_LDS();               // A has arrived (requested a whole knot ago); only then the next batch is put in flight
@@ -1047,6 +1061,7 @@ TSAT_FWD void forward_sweep(TPtrs<real> p, int N, int n_tab, int closed, int n_c
         knot(B, kk + 1);
       }
     }
+#endif
     if (nkn > 0) {
       if (FWD_NBUF == 1) {          // single buffer: copy the next chunk now that this one has been consumed
         TSAT_SYNC_LDS();
@@ -1616,11 +1631,8 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   p.CAND = (TSAT_GLOBAL real*)(a.CAND + (size_t)traj * a.max_ls * xu_stride<real>(NS));
   p.bt = (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[traj] * n_tab * 4);
   p.XU0 = p.XU; p.cur = 0;
-  // the stored candidate `slot` of the sweep just evaluated becomes the nominal trajectory: a pointer swap
-  auto adopt = [&](int slot) {
-    p.cur = cand_slab(p.cur, slot);
-    p.XU = slab_ptr<real>(p, N, p.cur);
-  };
+// the stored candidate `slot` of the sweep just evaluated becomes the nominal trajectory: a pointer swap
+#define TSAT_ADOPT(slot) do { p.cur = cand_slab(p.cur, (slot)); p.XU = slab_ptr<real>(p, N, p.cur); } while (0)
   stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)traj * PSTRIDE), (real)o.u_scale);
 
   const real* U0g = a.U0 + (size_t)traj * u0_stride<real>(NS);
@@ -1653,7 +1665,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   const acc_t J0 = wave_bcast(f0.J, 0, red64());
   const int ok0 = wave_first<real>(!f0.ok, lds + L_RED) > 0;  // lane 0 ok?
   TSAT_SYNC();
-  adopt(0);
+  TSAT_ADOPT(0);
   if (!ok0 || !(J0 - J0 == 0)) {
     status = TSAT_DIVERGED;
   } else {
@@ -1731,7 +1743,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
         if (jw < WAVE) {
           J = Jw;
           ls_trials += jw + 1;
-          adopt(slot);
+          TSAT_ADOPT(slot);
           grad = todorov_gradient<real>(p.XU, p.KD, N);
         } else {
           J = Jprev;
