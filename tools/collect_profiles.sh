@@ -7,6 +7,8 @@ set -e -o pipefail
 OUT=$(realpath -m "${1:-gpurun_out/final}")
 ROOT=$(pwd)
 mkdir -p "$OUT"
+PART="${PART:-AB}"     # A: configs[1], pipeline, experiment, batch sizes; B: configs[2] (fp64, fp32), [3], [4] — one gpurun call each fits 20 minutes
+if [[ "$PART" == *A* ]]; then
 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
@@ -18,17 +20,19 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY
   --output-format csv -d "$OUT/pmc_sq" -o run -- $B2 > /dev/null 2> "$OUT/pmc_sq.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pipeline" -o run -- python3 $ROOT/tools/pipeline_timing.py > "$OUT/pipeline.log" 2> "$OUT/pipeline.err"
 cd "$ROOT"
-python3 tools/phase_profile.py > "$OUT/phase_clocks.txt" 2> "$OUT/phase_clocks.err"
+python3 tools/phase_profile.py 1024 1000 1 1 > "$OUT/phase_clocks.txt" 2> "$OUT/phase_clocks.err"
 python3 tools/monte_carlo_timing.py 1024 1024 > "$OUT/monte_carlo.txt" 2> "$OUT/monte_carlo.err"
 TSAT_VARIANTS=2,3,4 python3 tools/large_batch.py > "$OUT/large_batch.txt" 2> "$OUT/large_batch.err"
 python3 tools/threshold_timing.py > "$OUT/build_by_batch_size.txt" 2> "$OUT/build_by_batch_size.err"
 python3 tools/fp32_eval.py 16384 512 > "$OUT/fp32_eval.txt" 2> "$OUT/fp32_eval.err"
 { python3 tools/mpc_timing.py 512 500; python3 tools/mpc_timing.py 4096 200; } > "$OUT/mpc_timing.txt" 2> "$OUT/mpc_timing.err"
+fi
+if [[ "$PART" == *B* ]]; then
 # larger configurations on this one GPU: configs[2] shape in fp64 (packed build) and as quoted (fp32), a configs[3] shard of
 # 8192 trajectories per GPU (what each of 8 GPUs gets), configs[4]; kernel statistics and PMC passes of the fp64 16384 run
 python3 bench.py --config 2 --precision 64 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c2_fp64.json" 2> "$OUT/bench_c2_fp64.err"
 python3 bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c2_fp32.json" 2> "$OUT/bench_c2_fp32.err"
-python3 bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 bench.py --config 4 --steps 2 --warmup 1 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
 cd /tmp
 C2="python3 $ROOT/bench.py --config 2 --precision 64 --steps 2 --warmup 1 --no-cpu-baseline --gather none"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -o run -- $C2 > /dev/null 2> "$OUT/stats_c2.err"
@@ -36,8 +40,31 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c2" -o run -- $C2 > /dev/null 2> "$OUT/pmc_write_c2.err"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
   --output-format csv -d "$OUT/pmc_sq_c2" -o run -- $C2 > /dev/null 2> "$OUT/pmc_sq_c2.err"
+# the same four passes for configs[2] as BASELINE.json quotes it (fp32) and for configs[3] (the whole 65536-trajectory sweep on this one GPU)
+C2F="python3 $ROOT/bench.py --config 2 --steps 2 --warmup 1 --no-cpu-baseline --gather none"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2f32" -o run -- $C2F > /dev/null 2> "$OUT/stats_c2f32.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_c2f32" -o run -- $C2F > /dev/null 2> "$OUT/pmc_fetch_c2f32.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c2f32" -o run -- $C2F > /dev/null 2> "$OUT/pmc_write_c2f32.err"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
+  --output-format csv -d "$OUT/pmc_sq_c2f32" -o run -- $C2F > /dev/null 2> "$OUT/pmc_sq_c2f32.err"
+echo "configs[2] fp32 passes done" > "$OUT/progress.txt"
 cd "$ROOT"
+python3 bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline --gather none > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"
+cd /tmp
+C3="python3 $ROOT/bench.py --config 3 --steps 1 --warmup 1 --no-cpu-baseline --gather none"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c3" -o run -- $C3 > /dev/null 2> "$OUT/stats_c3.err"
+echo "configs[3] stats pass done" >> "$OUT/progress.txt"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_c3" -o run -- $C3 > /dev/null 2> "$OUT/pmc_fetch_c3.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c3" -o run -- $C3 > /dev/null 2> "$OUT/pmc_write_c3.err"
+echo "configs[3] fetch / write passes done" >> "$OUT/progress.txt"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
+  --output-format csv -d "$OUT/pmc_sq_c3" -o run -- $C3 > /dev/null 2> "$OUT/pmc_sq_c3.err"
+echo "configs[3] passes done" >> "$OUT/progress.txt"
+cd "$ROOT"
+python3 tools/straggler_stats.py 8192 > "$OUT/straggler_stats.txt" 2> "$OUT/straggler_stats.err"
+python3 tools/fp32_paths.py 512 > "$OUT/fp32_paths.txt" 2> "$OUT/fp32_paths.err"
 TSAT_PK_G=4 python3 tools/phase_profile.py 16384 1000 3 1 > "$OUT/phase_clocks_packed.txt" 2> "$OUT/phase_clocks_packed.err"
 TSAT_PK_G=8 python3 tools/phase_profile.py 16384 1000 4 1 > "$OUT/phase_clocks_packed8.txt" 2> "$OUT/phase_clocks_packed8.err"
 python3 tools/phase_profile.py 16384 1000 2 1 > "$OUT/phase_clocks_dense.txt" 2> "$OUT/phase_clocks_dense.err"
+fi
 echo done

@@ -54,7 +54,8 @@ wr, _ = counters("pmc_write")
 sq, _ = counters("pmc_sq")
 rd_raw, wr_b = fe["FETCH_SIZE"] * 1024.0, wr["WRITE_SIZE"] * 1024.0
 out = {
-    "kernel": kern, "workload": bench["config"]["workload"], "bench_config": bench["config"].get("bench_config", 1),
+    "kernel": kern, "workload": bench["config"]["workload"], "bench_config": bench["config"].get("bench_config", 1), "dtype": bench["dtype"],
+    "traffic_over_algorithmic": (2 * rd_raw + wr_b) / bench["roofline"]["algorithmic_bytes_per_launch"],
     "kernel_source_sha256_16": kernel_source_hash(),
     "FETCH_SIZE_KB": fe["FETCH_SIZE"], "WRITE_SIZE_KB": wr["WRITE_SIZE"],
     "read_bytes_raw": rd_raw, "read_bytes_x2": 2 * rd_raw, "write_bytes": wr_b,
@@ -68,26 +69,40 @@ with open(os.path.join(root, "profiles", "pmc_summary.json"), "w") as f:
     json.dump(out, f, indent=1)
 print(json.dumps(out, indent=1))
 
-# the same counters for the fp64 run of configs[2] (16384 x 1000, the packed build), when collected
-if glob.glob(os.path.join(src, "pmc_fetch_c2", "**", "*counter_collection.csv"), recursive=True):
-    shutil.copy(one("stats_c2/**/*kernel_stats.csv"), os.path.join(dst, "kernel_stats_c2_fp64.csv"))
-    b2 = json.loads(open(os.path.join(src, "bench_c2_fp64.json")).read().strip().splitlines()[-1])
-    fe, kern = counters("pmc_fetch_c2")
-    wr, _ = counters("pmc_write_c2")
-    sq, _ = counters("pmc_sq_c2")
+# the same counters for the other configurations, when collected: configs[2] in fp64 and as quoted (fp32), configs[3]
+def other(tag, bench_file, cfg, stats_csv):
+    if not glob.glob(os.path.join(src, f"pmc_fetch_{tag}", "**", "*counter_collection.csv"), recursive=True):
+        return
+    shutil.copy(one(f"stats_{tag}/**/*kernel_stats.csv"), os.path.join(dst, stats_csv))
+    b2 = json.loads(open(os.path.join(src, bench_file)).read().strip().splitlines()[-1])
+    fe, kern = counters(f"pmc_fetch_{tag}")
+    wr, _ = counters(f"pmc_write_{tag}")
+    sq, _ = counters(f"pmc_sq_{tag}")
     rd_raw, wr_b = fe["FETCH_SIZE"] * 1024.0, wr["WRITE_SIZE"] * 1024.0
     ms = b2["roofline"]["kernel_ms"]
     out2 = {
-        "kernel": kern, "workload": b2["config"]["workload"], "bench_config": 2, "kernel_source_sha256_16": kernel_source_hash(),
+        "kernel": kern, "workload": b2["config"]["workload"], "bench_config": cfg, "dtype": b2["dtype"], "kernel_source_sha256_16": kernel_source_hash(),
         "kernel_ms": ms, "FETCH_SIZE_KB": fe["FETCH_SIZE"], "WRITE_SIZE_KB": wr["WRITE_SIZE"],
         "read_bytes_raw": rd_raw, "read_bytes_x2": 2 * rd_raw, "write_bytes": wr_b,
         "hbm_bytes_per_launch": 2 * rd_raw + wr_b, "hbm_bytes_per_launch_lower": rd_raw + wr_b,
         "algorithmic_bytes_per_launch": b2["roofline"]["algorithmic_bytes_per_launch"],
+        "traffic_over_algorithmic": (2 * rd_raw + wr_b) / b2["roofline"]["algorithmic_bytes_per_launch"],
         "hbm_GBs_upper": (2 * rd_raw + wr_b) / (ms * 1e-3) / 1e9,
         "valu_issue_frac_of_4_cycle_peak": sq["SQ_INSTS_VALU"] / (1024 * 2.4e9 * ms * 1e-3 / 4.0),
         "note": "as pmc_summary.json; valu_issue_frac: SQ_INSTS_VALU against one VALU instruction per 4 cycles on each of the 1024 SIMDs at 2.4 GHz",
         "sq": sq,
     }
-    with open(os.path.join(root, "profiles", "pmc_summary_c2.json"), "w") as f:
+    with open(os.path.join(root, "profiles", f"pmc_summary_{tag}.json"), "w") as f:
         json.dump(out2, f, indent=1)
     print(json.dumps(out2, indent=1))
+
+
+other("c2", "bench_c2_fp64.json", 2, "kernel_stats_c2_fp64.csv")
+other("c2f32", "bench_c2_fp32.json", 2, "kernel_stats_c2_fp32.csv")
+other("c3", "bench_c3.json", 3, "kernel_stats_c3.csv")
+for a, b in (("bench_c3.json", "bench_c3.json"), ("straggler_stats.txt", "straggler_stats.txt"), ("fp32_paths.txt", "fp32_paths.txt")):
+    if os.path.exists(os.path.join(src, a)):
+        with open(os.path.join(src, a)) as f:
+            keep = [ln for ln in f if not ln.startswith(("W20", "E20", "I20")) and "amdgpu.ids" not in ln]
+        with open(os.path.join(dst, b), "w") as f:
+            f.writelines(keep)

@@ -40,9 +40,10 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 #define TSAT_PHASE __device__ __noinline__
 // the forward sweep is inlined into the kernel body: there the register allocator can park values in AGPRs
 // (one-instruction reload), while a called function has to spill to scratch memory. The dense build has no AGPRs to park
-// anything in (256 registers in all, two wavefronts per SIMD): there the sweep is a function of its own like the other phases,
-// with its own register allocation, and the kernel body around it keeps its counters and pointers out of scratch.
-#if defined(TSAT_DENSE) && !defined(TSAT_PACKED)
+// anything in (256 registers in all, two wavefronts per SIMD): there — and in the packed builds, which hand a wavefront's last live
+// trajectory over to this mapping — the sweep is a function of its own like the other phases, with its own register allocation,
+// and the code around it keeps its counters and pointers out of scratch.
+#if defined(TSAT_DENSE)
 #define TSAT_FWD __device__ __noinline__
 #else
 #define TSAT_FWD __device__ __forceinline__
@@ -1615,8 +1616,18 @@ TSAT_PHASE real todorov_gradient(const TSAT_GLOBAL real* XUs, const TSAT_GLOBAL 
 // --------------------------------------------------------------------------------------------------
 // the whole AL-iLQR solve of one trajectory by one wavefront
 // --------------------------------------------------------------------------------------------------
+// Where a trajectory stands at the top of an inner iteration (its backward sweep is next): what solve_trajectory needs to carry
+// on a solve that another mapping began. The packed builds hand the LAST live trajectory of a wavefront over to this
+// one-trajectory mapping (tsat_packed.hpp): every build gives the same bits, so the hand-over changes the time only.
+template <typename real>
+struct Resume {
+  acc_t Jprev;
+  real mu, rho, drho, grad, nu[7];
+  int outer, it, djz, inner_iters, ls_trials, n_backward, n_forward, bp_restarts, fp_fails, trow;
+};
+
 template <typename real, int INTEG, int DIAGJ, int ES>
-TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
+TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, const Resume<real>* rs = nullptr) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
   const tsat_options& o = a.opt;
@@ -1638,43 +1649,59 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj) {
   const real* U0g = a.U0 + (size_t)traj * u0_stride<real>(NS);
   double* trace = a.trace ? a.trace + (size_t)traj * a.trace_rows * 8 : nullptr;
   int trow = 0;
-
-  // initial_controls!(prob, U0) (src/TortoiseSat.jl:191) + zero multipliers
-  for (int k = lane; k < N; k += WAVE) {
-    for (int i = 0; i < 7; ++i) p.XU[(size_t)k * XUW + i] = 0;
-    for (int c = 0; c < 3; ++c) p.XU[(size_t)k * XUW + 7 + c] = (k < N - 1) ? U0g[(size_t)k * 3 + c] : (real)0;
-    if (k < N - 1)
-      for (int c = 0; c < 6; ++c) p.LAM[(size_t)k * LMW + c] = 0;
-  }
   real mu = (real)o.penalty_init;
   const real max_state = (real)o.max_state;
   const int tmask = o.terminal_mask;
-  TSAT_SYNC();
-
   int status = TSAT_MAX_OUTER, outer_iters = 0, inner_iters = 0, ls_trials = 0, n_backward = 0, n_forward = 0,
       bp_restarts = 0, fp_fails = 0;
   real grad = 0;
   int last_jw = 0;                  // accepted line-search index of the previous iteration (first iteration: a shallow search is assumed)
   unsigned long long pc_fwd = 0, pc_par = 0;
+  bool start_ok = true;
 
-  // open-loop rollout of U0
-  forward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, 0, 1, 0);
-  n_forward++;
-  TSAT_SYNC();
-  const FwdOut<real> f0 = candidate_costs<real>(p, N, 0, 1, mu, tmask, max_state);
-  const acc_t J0 = wave_bcast(f0.J, 0, red64());
-  const int ok0 = wave_first<real>(!f0.ok, lds + L_RED) > 0;  // lane 0 ok?
-  TSAT_SYNC();
-  TSAT_ADOPT(0);
-  if (!ok0 || !(J0 - J0 == 0)) {
+  if (rs) {
+    // carry on: the nominal trajectory, gains' inputs and multipliers are in HBM; counters and terminal multipliers come along
+    trow = rs->trow; mu = rs->mu; grad = rs->grad;
+    inner_iters = rs->inner_iters; ls_trials = rs->ls_trials; n_backward = rs->n_backward; n_forward = rs->n_forward;
+    bp_restarts = rs->bp_restarts; fp_fails = rs->fp_fails;
+    if (lane < 7) lds[L_NU + lane] = rs->nu[lane];
+    TSAT_SYNC();
+  } else {
+    // initial_controls!(prob, U0) (src/TortoiseSat.jl:191) + zero multipliers
+    for (int k = lane; k < N; k += WAVE) {
+      for (int i = 0; i < 7; ++i) p.XU[(size_t)k * XUW + i] = 0;
+      for (int c = 0; c < 3; ++c) p.XU[(size_t)k * XUW + 7 + c] = (k < N - 1) ? U0g[(size_t)k * 3 + c] : (real)0;
+      if (k < N - 1)
+        for (int c = 0; c < 6; ++c) p.LAM[(size_t)k * LMW + c] = 0;
+    }
+    TSAT_SYNC();
+    // open-loop rollout of U0
+    forward_sweep<real, INTEG, DIAGJ, ES>(p, N, n_tab, 0, 1, 0);
+    n_forward++;
+    TSAT_SYNC();
+    const FwdOut<real> f0 = candidate_costs<real>(p, N, 0, 1, mu, tmask, max_state);
+    const acc_t J0 = wave_bcast(f0.J, 0, red64());
+    const int ok0 = wave_first<real>(!f0.ok, lds + L_RED) > 0;  // lane 0 ok?
+    TSAT_SYNC();
+    TSAT_ADOPT(0);
+    start_ok = ok0 && (J0 - J0 == 0);
+  }
+  if (!start_ok) {
     status = TSAT_DIVERGED;
   } else {
-    for (int outer = 1; outer <= o.max_outer; ++outer) {
-      acc_t Jprev = nominal_cost<real>(p, N, mu, tmask, 1);
+    bool resumed = rs != nullptr;
+    for (int outer = rs ? rs->outer : 1; outer <= o.max_outer; ++outer) {
+      acc_t Jprev;
       real rho = (real)o.reg_init, drho = 0;
-      int djz = 0;
+      int djz = 0, it0 = 1;
+      if (resumed) {      // the outer iteration was begun by the other mapping: its cost, regularisation and counters stand
+        Jprev = rs->Jprev; rho = rs->rho; drho = rs->drho; djz = rs->djz; it0 = rs->it;
+        resumed = false;
+      } else {
+        Jprev = nominal_cost<real>(p, N, mu, tmask, 1);
+      }
       bool regfail = false;
-      for (int it = 1; it <= o.max_inner; ++it) {
+      for (int it = it0; it <= o.max_inner; ++it) {
         BwdOut<real> bw;
         for (;;) {
           n_backward++;

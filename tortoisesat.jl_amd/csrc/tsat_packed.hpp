@@ -644,6 +644,18 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
   return out;
 }
 
+// The rest of ONE trajectory's solve in the one-trajectory mapping (solve_trajectory, tsat_device.hpp, in the layout of the dense
+// build: this translation unit's LDS block holds it), from the top of an inner iteration on. A wavefront whose other trajectories
+// have finished runs its last one this way: a joint iteration costs the same whether four trajectories of the wave are live or
+// one (the forward sweep and the Riccati lanes are per wavefront), while the one-trajectory mapping spends all 64 lanes on
+// that trajectory — Jacobian passes of 29 knots, 64 candidates per sweep, the 64-lane Riccati step — and iterates 2 - 3 times faster. With an
+// iteration budget that spreads the trajectories' iteration counts (3 x 50: 21 ... 150), most wavefronts are down to one live
+// trajectory for the last third of the launch. Same bits either way (every build is the same solve).
+template <typename real, int INTEG, int DIAGJ, int ES>
+TSAT_PHASE void continue_trajectory(const KArgs<real>& a, int traj, Resume<real> r) {
+  solve_trajectory<real, INTEG, DIAGJ, ES>(a, traj, &r);
+}
+
 // the whole AL-iLQR solve of trajectories traj0 .. traj0 + PK_G - 1 (traj0 = wave * PK_G) by one wavefront
 template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
@@ -872,6 +884,32 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
     }
   };
   auto any_lane = [&](bool f) { return wave_first<real>(f, lds + L_RED) < WAVE; };
+  // If exactly one trajectory of the wave is still iterating (it stands at the top of an inner iteration: its backward sweep is
+  // next), the one-trajectory mapping takes it to the end (continue_trajectory) and the wave is done.
+  auto hand_over_last = [&]() {
+    static_assert(L_BWD_END <= LDS_REALS && L_FWD_END <= LDS_REALS, "the one-trajectory phases (dense layout) fit this build's LDS block");
+    int* flags = reinterpret_cast<int*>(lds + L_ST);
+    TSAT_SYNC_LDS();
+    if (myc == 0) flags[myg] = (mine.active && mine.need_bwd && !mine.regfail) ? 1 : (mine.active ? 2 : 0);
+    TSAT_SYNC_LDS();
+    int n_live = 0, gl = 0;
+    for (int g = 0; g < PK_G; ++g) {
+      const int f = flags[g];
+      if (f) { n_live += (f == 1) ? 1 : 2; gl = g; }        // a live trajectory in any other state keeps the wave in the joint loop
+    }
+    TSAT_SYNC_LDS();
+    if (n_live != 1) return;
+    const GState<real> u = gstate_bcast(mine, gl * PK_C);
+    Resume<real> r;
+    r.Jprev = u.Jprev; r.mu = u.mu; r.rho = u.rho; r.drho = u.drho; r.grad = u.grad;
+    for (int i = 0; i < 7; ++i) r.nu[i] = u.nu[i];
+    r.outer = u.outer; r.it = u.it; r.djz = u.djz; r.inner_iters = u.inner_iters; r.ls_trials = u.ls_trials;
+    r.n_backward = u.n_backward; r.n_forward = u.n_forward; r.bp_restarts = u.bp_restarts; r.fp_fails = u.fp_fails; r.trow = u.trow;
+    TSAT_SYNC();
+    continue_trajectory<real, INTEG, DIAGJ, ES>(a, traj0 + gl, r);
+    TSAT_SYNC();
+    if (myg == gl) { mine.active = 0; mine.need_bwd = 0; }
+  };
 
   unsigned long long pc_fwd = 0, pc_adv = 0;   // diagnostic build (-DTSAT_PROFILE): shader clocks in forward sweeps / everything else
   // ---- open-loop rollout of U0 for every trajectory of the wave, then the first backward sweeps ------------------------
@@ -898,6 +936,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       }
       if (myg == g) mine = u;
     }
+    hand_over_last();
     joint_backward();
   }
   // ---- main loop: one forward sweep for all trajectories that are still iterating, then each of them moves on ------------
@@ -962,6 +1001,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       if (u.active) advance(g, u, true);
       if (myg == g) mine = u;
     }
+    hand_over_last();
     joint_backward();
     pc_adv += tick_() - t_a0;
   }
