@@ -5,18 +5,143 @@
 // Lets the CPU-only test tier check the kernel's indexing / lane roles / control flow against the oracle;
 // it is never used by the product and says nothing about performance.
 #define TSAT_EMU
+#include <atomic>
 #include <barrier>
+#include <cstdint>
+#include <functional>
 #include <thread>
 #include <vector>
 #include <memory>
 
+// Two ways of running the 64 lanes of an emulated wavefront:
+//  * TSAT_EMU_THREADS (the ThreadSanitizer drivers, tests/sanitize): 64 host threads, a barrier is std::barrier — real
+//    concurrency, so that a missing barrier shows as a data race; one wavefront at a time;
+//  * default (the functional tests): 64 FIBERS on one host thread, switched round-robin at the barriers — a barrier costs 64
+//    user-level context switches instead of 64 futex round trips on an oversubscribed machine (5 - 10x faster), and
+//    wavefronts run side by side on the host's cores. Same lane code, same barrier semantics, deterministic.
 namespace tsat_emu {
+#ifdef TSAT_EMU_THREADS
 thread_local int g_lane = 0;
 std::barrier<>* g_bar = nullptr;
 void* g_lds = nullptr;     // one emulated wavefront at a time
 int lane() { return g_lane; }
 void sync() { g_bar->arrive_and_wait(); }
 void* lds() { return g_lds; }
+template <typename F>
+void run_wave(size_t lds_bytes, F&& body) {
+  std::vector<double> lds((lds_bytes + 7) / 8, 0.0);
+  std::barrier<> bar(64);
+  g_bar = &bar;
+  g_lds = lds.data();
+  std::vector<std::thread> th;
+  for (int l = 0; l < 64; ++l)
+    th.emplace_back([&, l]() { g_lane = l; body(); });
+  for (auto& t : th) t.join();
+}
+template <typename F>
+void for_each_wave(int n, F&& fn) { for (int w = 0; w < n; ++w) fn(w); }
+#else
+extern "C" void tsat_ctx_switch(void** save_sp, void* to_sp);
+// x86-64 SysV: callee-saved registers on the outgoing stack, swap stack pointers, restore, return into the other fiber
+asm(R"(
+.text
+.globl tsat_ctx_switch
+.type tsat_ctx_switch,@function
+tsat_ctx_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size tsat_ctx_switch,.-tsat_ctx_switch
+)");
+struct Wave {
+  static constexpr int W = 64;
+  static constexpr size_t STACK = 512 * 1024;
+  void* sp[W + 1] = {};                 // saved stack pointers of the lanes; [W] = the host thread's own
+  bool done[W] = {};
+  int cur = 0, arrived = 0, n_done = 0;
+  unsigned gen = 0;
+  void* lds = nullptr;
+  std::function<void()> body;
+  std::unique_ptr<char[]> stacks;
+};
+thread_local Wave* g_w = nullptr;
+int lane() { return g_w->cur; }
+void* lds() { return g_w->lds; }
+static void yield_from(int from) {      // to the next lane that has not finished (round-robin); back here when it is our turn
+  Wave* w = g_w;
+  int to = from;
+  do { to = (to + 1) % Wave::W; } while (w->done[to] && to != from);
+  if (to == from) return;
+  w->cur = to;
+  tsat_ctx_switch(&w->sp[from], w->sp[to]);
+}
+void sync() {
+  Wave* w = g_w;
+  const unsigned g = w->gen;
+  if (++w->arrived >= Wave::W - w->n_done) { w->arrived = 0; ++w->gen; }
+  while (w->gen == g) yield_from(w->cur);
+}
+static void lane_entry() {
+  Wave* w = g_w;
+  w->body();
+  const int me = w->cur;
+  w->done[me] = true;
+  ++w->n_done;
+  if (w->arrived > 0 && w->arrived >= Wave::W - w->n_done) { w->arrived = 0; ++w->gen; }   // the others were waiting for a lane that has left
+  void* dummy;
+  if (w->n_done == Wave::W) tsat_ctx_switch(&dummy, w->sp[Wave::W]);      // the last lane returns to the host thread
+  for (;;) {                                                              // a finished lane never runs again
+    int to = me;
+    do { to = (to + 1) % Wave::W; } while (w->done[to]);
+    w->cur = to;
+    tsat_ctx_switch(&dummy, w->sp[to]);
+  }
+}
+template <typename F>
+void run_wave(size_t lds_bytes, F&& body) {
+  Wave w;
+  std::vector<double> lds((lds_bytes + 7) / 8, 0.0);
+  w.lds = lds.data();
+  w.body = body;
+  w.stacks.reset(new char[Wave::W * Wave::STACK]);
+  for (int l = 0; l < Wave::W; ++l) {
+    uintptr_t top = (reinterpret_cast<uintptr_t>(w.stacks.get()) + (size_t)(l + 1) * Wave::STACK) & ~(uintptr_t)15;
+    void** s = reinterpret_cast<void**>(top);
+    *--s = nullptr;                                  // return address of lane_entry (it never returns)
+    *--s = reinterpret_cast<void*>(&lane_entry);     // `ret` of the first switch lands here, stack aligned as after a call
+    for (int r = 0; r < 6; ++r) *--s = nullptr;      // rbp rbx r12 r13 r14 r15
+    w.sp[l] = s;
+  }
+  Wave* prev = g_w;
+  g_w = &w;
+  w.cur = 0;
+  tsat_ctx_switch(&w.sp[Wave::W], w.sp[0]);
+  g_w = prev;
+}
+// wavefronts side by side on the host's cores (each host thread runs whole wavefronts, one after the other)
+template <typename F>
+void for_each_wave(int n, F&& fn) {
+  const int nt = (int)std::min<unsigned>((unsigned)n, std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+  if (nt <= 1) { for (int w = 0; w < n; ++w) fn(w); return; }
+  std::atomic<int> next{0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&]() { for (int w = next++; w < n; w = next++) fn(w); });
+  for (auto& t : th) t.join();
+}
+#endif
 }  // namespace tsat_emu
 
 #include "../../tortoisesat.jl_amd/csrc/tsat_host_pack.hpp"
@@ -30,21 +155,13 @@ using R = tsat::cfg_real;   // storage type of this build of the solve kernel: d
 
 template <int INTEG, int DIAGJ, int ES>
 static void run_block(const KArgs<R>& a, int traj) {
-  std::vector<double> lds((LDS_BYTES + 7) / 8, 0.0);
-  std::barrier<> bar(WAVE);
-  tsat_emu::g_bar = &bar;
-  tsat_emu::g_lds = lds.data();
-  std::vector<std::thread> th;
-  for (int l = 0; l < WAVE; ++l)
-    th.emplace_back([&, l]() {
-      tsat_emu::g_lane = l;
+  tsat_emu::run_wave(LDS_BYTES, [&]() {
 #ifdef TSAT_PACKED
-      solve_group<R, INTEG, DIAGJ, ES>(a, traj);      // `traj` = wave index
+    solve_group<R, INTEG, DIAGJ, ES>(a, traj);      // `traj` = wave index
 #else
-      solve_trajectory<R, INTEG, DIAGJ, ES>(a, traj);
+    solve_trajectory<R, INTEG, DIAGJ, ES>(a, traj);
 #endif
-    });
-  for (auto& t : th) t.join();
+  });
 }
 
 extern "C" int emu_lds_bytes(void) { return LDS_BYTES; }
@@ -82,9 +199,9 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
       {{run_block<4, 0, 0>, run_block<4, 0, 1>}, {run_block<4, 1, 0>, run_block<4, 1, 1>}, {run_block<4, 2, 0>, run_block<4, 2, 1>}}};
   const blk_t blk = variants[o->integrator == 4 ? 1 : 0][cls][o->error_state ? 1 : 0];
 #ifdef TSAT_PACKED
-  for (int w = 0; w * PK_G < (int)T; ++w) blk(a, w);
+  tsat_emu::for_each_wave(((int)T + PK_G - 1) / PK_G, [&](int w) { blk(a, w); });
 #else
-  for (int t = 0; t < (int)T; ++t) blk(a, t);
+  tsat_emu::for_each_wave((int)T, [&](int t) { blk(a, t); });
 #endif
   for (int64_t e = 0; e < T * (int64_t)N; ++e) export_record<R>(e, N, n_knots, XU.data(), KD.data(), X, U, K);
   return 0;
@@ -93,17 +210,7 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
 #if !defined(TSAT_DENSE) && !defined(TSAT_F32)   // the dense build exists for the solve kernel only (tortoisesat.jl_amd/csrc/tsat_kernels_dense.hip)
 template <int DIAGJ>
 static void run_mpc_block(const MpcArgs<double>& a, int traj) {
-  std::vector<double> lds(LDS_REALS, 0.0);
-  std::barrier<> bar(WAVE);
-  tsat_emu::g_bar = &bar;
-  tsat_emu::g_lds = lds.data();
-  std::vector<std::thread> th;
-  for (int l = 0; l < WAVE; ++l)
-    th.emplace_back([&, l]() {
-      tsat_emu::g_lane = l;
-      mpc_advance_trajectory<double, DIAGJ>(a, traj);
-    });
-  for (auto& t : th) t.join();
+  tsat_emu::run_wave((size_t)LDS_REALS * 8, [&]() { mpc_advance_trajectory<double, DIAGJ>(a, traj); });
 }
 
 // the loop of tsat_mpc_run: solve blocks, then advance blocks, n_steps times, on emulated device buffers
@@ -139,10 +246,10 @@ extern "C" int emu_mpc_batch(const tsat_options* o, int64_t T, int64_t n_btab, c
       {{run_block<4, 0, 0>, run_block<4, 0, 1>}, {run_block<4, 1, 0>, run_block<4, 1, 1>}, {run_block<4, 2, 0>, run_block<4, 2, 1>}}};
   const blk_t blk = variants[o->integrator == 4 ? 1 : 0][cls][o->error_state ? 1 : 0];
   for (int s = 0; s < n_steps; ++s) {
-    for (int t = 0; t < (int)T; ++t) blk(a, t);
+    tsat_emu::for_each_wave((int)T, [&](int t) { blk(a, t); });
     m.step = s;
     for (int t = 0; t < (int)T; ++t) {
-      if (cls == 2) run_mpc_block<2>(m, t); else if (cls == 1) run_mpc_block<1>(m, t); else run_mpc_block<0>(m, t);
+      { if (cls == 2) run_mpc_block<2>(m, t); else if (cls == 1) run_mpc_block<1>(m, t); else run_mpc_block<0>(m, t); }
     }
   }
   for (int64_t e = 0; e < T * (int64_t)N; ++e) export_record<double>(e, N, n_knots, XU.data(), KD.data(), X_last, U_last, nullptr);
@@ -151,17 +258,7 @@ extern "C" int emu_mpc_batch(const tsat_options* o, int64_t T, int64_t n_btab, c
 
 template <int DIAGJ>
 static void run_tv_block(const TvArgs<double>& a, int traj) {
-  std::vector<double> lds(LDS_REALS, 0.0);
-  std::barrier<> bar(WAVE);
-  tsat_emu::g_bar = &bar;
-  tsat_emu::g_lds = lds.data();
-  std::vector<std::thread> th;
-  for (int l = 0; l < WAVE; ++l)
-    th.emplace_back([&, l]() {
-      tsat_emu::g_lane = l;
-      tvlqr_trajectory<double, DIAGJ>(a, traj);
-    });
-  for (auto& t : th) t.join();
+  tsat_emu::run_wave((size_t)LDS_REALS * 8, [&]() { tvlqr_trajectory<double, DIAGJ>(a, traj); });
 }
 
 extern "C" int emu_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, const double* X, const double* U,
@@ -186,9 +283,9 @@ extern "C" int emu_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n
   a.P = P.data(); a.BT = BT.data(); a.bidx = bidx.data(); a.nk = n_knots; a.XUR = XUR.data(); a.NZ = noise; a.KD = KD.data(); a.XS = XS.data();
   a.stats = stats;
   const int cls = inertia_class(T, Jmat);
-  for (int t = 0; t < (int)T; ++t) {
+  tsat_emu::for_each_wave((int)T, [&](int t) {
     if (cls == 2) run_tv_block<2>(a, t); else if (cls == 1) run_tv_block<1>(a, t); else run_tv_block<0>(a, t);
-  }
+  });
   unpack_tv<double>(T, N, XS.data(), KD.data(), X_sim, U_sim, K_lqr);
   return 0;
 }
@@ -197,16 +294,7 @@ extern "C" int emu_horizon_batch(int64_t T, int32_t n_rows, const double* Btab, 
                                  int32_t* tf_index, double* cond_at) {
   HzArgs<double> a;
   a.T = (int)T; a.n_rows = n_rows; a.BT = Btab; a.dt_row = dt_row; a.cutoff = cutoff; a.tf_index = tf_index; a.cond_at = cond_at;
-  for (int t = 0; t < (int)T; ++t) {
-    std::vector<double> lds(LDS_REALS, 0.0);
-    std::barrier<> bar(WAVE);
-    tsat_emu::g_bar = &bar;
-    tsat_emu::g_lds = lds.data();
-    std::vector<std::thread> th;
-    for (int l = 0; l < WAVE; ++l)
-      th.emplace_back([&, l]() { tsat_emu::g_lane = l; horizon_trajectory<double>(a, t); });
-    for (auto& x : th) x.join();
-  }
+  tsat_emu::for_each_wave((int)T, [&](int t) { tsat_emu::run_wave((size_t)LDS_REALS * 8, [&]() { horizon_trajectory<double>(a, t); }); });
   return 0;
 }
 
@@ -218,16 +306,7 @@ extern "C" int emu_btable_batch(const tsat_btable_options* o, int64_t T, const d
   BtArgs<double> a;
   a.T = (int)T; a.n_half = N; a.mjd = o->mjd; a.gm = o->gm; a.r_igrf_km = o->r_igrf_km;
   a.tab = coef.data(); a.kep = kep; a.t0 = t0; a.tf = tf; a.pos = P.data(); a.B = Btab;
-  for (int t = 0; t < (int)T; ++t) {
-    std::vector<double> lds(LDS_REALS, 0.0);
-    std::barrier<> bar(WAVE);
-    tsat_emu::g_bar = &bar;
-    tsat_emu::g_lds = lds.data();
-    std::vector<std::thread> th;
-    for (int l = 0; l < WAVE; ++l)
-      th.emplace_back([&, l]() { tsat_emu::g_lane = l; btable_trajectory<double>(a, t); });
-    for (auto& x : th) x.join();
-  }
+  tsat_emu::for_each_wave((int)T, [&](int t) { tsat_emu::run_wave((size_t)LDS_REALS * 8, [&]() { btable_trajectory<double>(a, t); }); });
   if (pos) std::memcpy(pos, P.data(), P.size() * sizeof(double));
   return 0;
 }
