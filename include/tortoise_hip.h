@@ -252,6 +252,18 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
  * differs). The switch exists for tuning and for the tests. */
 int  tsat_set_kernel_variant(tsat_handle* h, int32_t variant);
 
+/* Endgame of the packed builds (variants 3 and 4). The trajectories of one launch need different numbers of iterations (21 .. 150
+ * on the inclination sweep of src/paper_images/heatmap.jl:139-185 with its 3 x 50 budget), and a wavefront that holds four or
+ * eight of them lasts as long as its slowest: towards the end of a launch a few wavefronts with several long trajectories keep
+ * running while the rest of the machine is idle. Once at most `suspend_at` trajectories of the batch are still iterating, every
+ * wavefront therefore parks its live ones (state in HBM) and ends, and a second kernel, queued behind the first on the same
+ * stream, continues each of them on a wavefront of its own.
+ *   -1  automatic (default): a quarter of the batch, at most 2048, when max_outer * max_inner >= 20; never otherwise;
+ *    0  never;  n > 0: at n live trajectories.
+ * Results do not depend on it (X, U, K, costs, iteration counts: bit-identical); `n_forward`, the sweeps that were executed,
+ * does. For tuning and for the tests. */
+int  tsat_set_endgame(tsat_handle* h, int32_t suspend_at);
+
 /* The same tracking for the RESIDENT batch right after tsat_batch_run: reference trajectories, field tables, table
  * clocks, inertias, goal states and per-trajectory horizons are the ones already on the device — nothing of the solve
  * travels back and forth between the two calls (src/monte_carlo.jl:196 -> :230). n_knots / n_tab of `o` are ignored. */

@@ -80,6 +80,10 @@ end
 set_kernel_variant!(s::HIPSolver, v::Integer) =
     check(s, ccall((:tsat_set_kernel_variant, LIB), Cint, (Ptr{Cvoid}, Int32), s.handle, v), "tsat_set_kernel_variant")
 
+"set_endgame!(s, n) — packed builds: park the last n live trajectories for a one-per-wavefront launch (-1 automatic, 0 never)"
+set_endgame!(s::HIPSolver, n::Integer) =
+    check(s, ccall((:tsat_set_endgame, LIB), Cint, (Ptr{Cvoid}, Int32), s.handle, n), "tsat_set_endgame")
+
 """
 BatchProblem: T independent slews, arrays in the reference's own shapes.
   x0, xf :: 7×T   (ω; q scalar-first — the 8th time state of src/TortoiseSat.jl:124 is dropped)

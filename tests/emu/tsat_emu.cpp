@@ -8,6 +8,7 @@
 #include <atomic>
 #include <barrier>
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
 #include <thread>
 #include <vector>
@@ -164,6 +165,17 @@ static void run_block(const KArgs<R>& a, int traj) {
   });
 }
 
+#ifdef TSAT_PACKED
+template <int INTEG, int DIAGJ, int ES>
+static void resume_block(const KArgs<R>& a, int w) {      // tsat_resume_kernel_packed
+  tsat_emu::run_wave(LDS_BYTES, [&]() {
+    (void)continue_trajectory<R, INTEG, DIAGJ, ES>(a, a.susp_ids[w], reinterpret_cast<const Resume<R>*>(a.susp_state)[w]);
+  });
+}
+#endif
+static int emu_parked_last = 0;
+extern "C" int emu_parked(void) { return emu_parked_last; }     // trajectories the last packed emu_solve_batch parked
+
 extern "C" int emu_lds_bytes(void) { return LDS_BYTES; }
 
 extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab, const double* x0, const double* xf,
@@ -199,7 +211,25 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
       {{run_block<4, 0, 0>, run_block<4, 0, 1>}, {run_block<4, 1, 0>, run_block<4, 1, 1>}, {run_block<4, 2, 0>, run_block<4, 2, 1>}}};
   const blk_t blk = variants[o->integrator == 4 ? 1 : 0][cls][o->error_state ? 1 : 0];
 #ifdef TSAT_PACKED
+  // endgame of the launch as tsat_launch_solve_packed queues it (TSAT_EMU_SUSPEND_AT=n: park at n live trajectories)
+  const char* sa = std::getenv("TSAT_EMU_SUSPEND_AT");
+  int counters[2] = {(int)T, 0};
+  std::vector<int> ids((size_t)T);
+  std::vector<Resume<R>> parked((size_t)T);
+  if (sa && std::atoi(sa) > 0) {
+    a.suspend_at = std::atoi(sa); a.live = &counters[0]; a.susp_n = &counters[1]; a.susp_ids = ids.data(); a.susp_state = parked.data();
+  }
   tsat_emu::for_each_wave(((int)T + PK_G - 1) / PK_G, [&](int w) { blk(a, w); });
+  if (a.suspend_at) {
+    using res_t = void (*)(const KArgs<R>&, int);
+    static const res_t resume[2][3][2] = {
+        {{resume_block<3, 0, 0>, resume_block<3, 0, 1>}, {resume_block<3, 1, 0>, resume_block<3, 1, 1>}, {resume_block<3, 2, 0>, resume_block<3, 2, 1>}},
+        {{resume_block<4, 0, 0>, resume_block<4, 0, 1>}, {resume_block<4, 1, 0>, resume_block<4, 1, 1>}, {resume_block<4, 2, 0>, resume_block<4, 2, 1>}}};
+    const res_t res = resume[o->integrator == 4 ? 1 : 0][cls][o->error_state ? 1 : 0];
+    emu_parked_last = counters[1];
+    a.live = nullptr;          // nothing parks in the second launch
+    tsat_emu::for_each_wave(counters[1], [&](int w) { res(a, w); });
+  }
 #else
   tsat_emu::for_each_wave((int)T, [&](int t) { blk(a, t); });
 #endif

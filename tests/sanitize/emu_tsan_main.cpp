@@ -21,7 +21,9 @@ int main() {
                  const double* tau0, const double* dtau, const double* dt, const double* J, const double* Qd, const double* Qfd,
                  const double* Rd, const double* ulo, const double* uhi, const double* U0, double* X, double* U, double* K,
                  tsat_stats* st, const int32_t* nk) {
-    return emu_solve_batch(o, T, nb, x0, xf, B, bi, tau0, dtau, dt, J, Qd, Qfd, Rd, ulo, uhi, U0, X, U, K, st, nullptr, 0, nk);
+    const int rc = emu_solve_batch(o, T, nb, x0, xf, B, bi, tau0, dtau, dt, J, Qd, Qfd, Rd, ulo, uhi, U0, X, U, K, st, nullptr, 0, nk);
+    if (std::getenv("TSAT_EMU_SUSPEND_AT")) std::fprintf(stderr, "endgame parked %d\n", emu_parked());   // packed builds (tests/test_sanitizers.py)
+    return rc;
   };
   tsat_options o;
   std::memset(&o, 0, sizeof(o));

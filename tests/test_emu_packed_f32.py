@@ -82,6 +82,32 @@ def test_packed_build_mixed_fates_in_one_group(pkg, ol, emu, emu_packed):
     _same_bits(w3, p3)
 
 
+@pytest.mark.parametrize("which,T,N,at", [("emu_packed", 11, 33, 6), ("emu_packed", 7, 20, 100), ("emu_packed8", 19, 21, 9),
+                                          ("emu_packed_f32", 10, 30, 5)])
+def test_packed_endgame_is_the_same_solve(pkg, ol, request, monkeypatch, which, T, N, at):
+    """tsat_set_endgame: once `at` trajectories are left, the wavefronts park theirs and a second launch finishes each on a
+    wavefront of its own (tsat_resume_kernel_packed). Which ones get parked depends on how the waves were scheduled — here: on
+    the emulator's threads —, the results do not: bit-identical to the launch without it, for a spread of iteration counts
+    (ragged horizons, a diverging rollout, a regularisation failure), also when everything is parked at once (at >= T)."""
+    e = request.getfixturevalue(which)
+    b = pkg.slew_setup.workload_monte_carlo(T=T, N=N, seed=900 + T, random_orbit=True)
+    b.n_knots = np.array([N, 4, N - 3, N, 9, N, N // 2, N, 2, N, N - 1, N, N, 6, N, N, 3, N, N][:T], dtype=np.int32)
+    b.U0[1] = 1e12
+    b.Rd[3] = -1e-4
+    o = oracle_options(ol, max_outer=3, max_inner=5, dj_counter_limit=1, error_state=T % 2, reg_max=1e-2)
+    if which == "emu_packed_f32":
+        o.precision = 32
+    monkeypatch.delenv("TSAT_EMU_SUSPEND_AT", raising=False)
+    plain = e.solve(b, o)
+    monkeypatch.setenv("TSAT_EMU_SUSPEND_AT", str(at))
+    parked = e.solve(b, o)
+    n_parked = e.lib.emu_parked()
+    assert 0 <= n_parked <= min(at, T)          # (none, if the last `at` were all inside their final iteration when the count fell)
+    if at >= T:
+        assert n_parked == int(np.sum(plain["stats"]["status"] != pkg._abi.TSAT_DIVERGED))   # all that survive their rollout
+    _same_bits(plain, parked)
+
+
 def test_fp32_build_against_the_fp64_oracle(pkg, ol, emu_f32):
     """precision = 32 on short solves: same statuses and iteration counts as the fp64 oracle, |dX| < 1e-3, |dU| < 1e-3 of
     the control scale (fp32 bar 1e-3 + status agreement)"""

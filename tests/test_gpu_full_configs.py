@@ -234,7 +234,10 @@ def test_gpu_large_batch_runs_are_repeatable(pkg, ol):
             r = s.download(want_K=False)
             runs.append((r["stats"].copy(), r["X"][::97].copy(), r["U"][::97].copy()))
         for st, X, U in runs[1:]:
-            assert np.array_equal(st, runs[0][0]) and np.array_equal(X, runs[0][1]) and np.array_equal(U, runs[0][2]), (prec, variant)
+            # n_forward counts the sweeps that were executed: with the automatic endgame (tsat_set_endgame) the trajectories
+            # parked for the second kernel — which ones is a matter of wave scheduling — finish in the one-trajectory mapping
+            assert all(np.array_equal(st[f_], runs[0][0][f_]) for f_ in st.dtype.names if f_ != "n_forward"), (prec, variant)
+            assert np.array_equal(X, runs[0][1]) and np.array_equal(U, runs[0][2]), (prec, variant)
         assert not np.any(runs[0][0]["status"] == pkg._abi.TSAT_DIVERGED)
         if prec == 64:      # the tiled batch repeats its 1024 trajectories 16 times: all copies solve alike, whatever wave they sit in
             assert np.array_equal(runs[0][0]["inner_iters"][:1024], runs[0][0]["inner_iters"][1024:2048])

@@ -302,6 +302,55 @@ def test_gpu_packed_builds_ragged_and_tiny_horizons(pkg, ol, solver, variant, es
         assert np.all(got["X"][t, n:] == 0) and np.all(got["U"][t, n - 1:] == 0)
 
 
+@pytest.mark.parametrize("variant,prec", [(3, 64), (4, 64), (3, 32)])
+def test_gpu_packed_endgame_is_the_same_solve(pkg, ol, solver, variant, prec):
+    """tsat_set_endgame: the packed launch parks its last live trajectories and a second kernel finishes each on a wavefront
+    of its own. Which ones are parked depends on the order the hardware ran the waves in; the results must not: bit-identical
+    to the launch without an endgame for a spread of iteration counts (ragged horizons, a diverging rollout, a regularisation
+    failure), at several thresholds including "everything at once", and equal to the oracle."""
+    T, N = 203, 64
+    b = pkg.slew_setup.workload_monte_carlo(T=T, N=N, seed=77, random_orbit=True, degenerate_rd=0.03)
+    rng = np.random.default_rng(5)
+    b.n_knots = rng.integers(2, N + 1, size=T).astype(np.int32)
+    b.n_knots[::3] = N
+    b.U0[7] = 1e12
+    b.Rd[11] = -1e-4
+    o = oracle_options(ol, max_outer=3, max_inner=8, dj_counter_limit=1, error_state=1, reg_max=1e-2)
+    a = helpers.abi_options_like(o, pkg, b.N, b.n_tab)
+    a.precision = prec
+    solver.upload(b, a.max_linesearch)
+
+    def run():
+        solver.run(a)
+        return solver.download()
+
+    solver.set_kernel_variant(variant)
+    try:
+        solver.set_endgame(0)
+        plain = run()
+        for at in (60, 150, 1000):
+            solver.set_endgame(at)
+            got = run()
+            for k in ("X", "U", "K"):
+                # (equal_nan: the diverged trajectory never has a backward sweep; its K is whatever the buffer held before)
+                bad = [t for t in range(T) if not np.array_equal(plain[k][t], got[k][t], equal_nan=True)]
+                assert not bad, (at, k, bad, plain["stats"]["status"][bad].tolist())
+            for f in plain["stats"].dtype.names:
+                assert f == "n_forward" or np.array_equal(plain["stats"][f], got["stats"][f]), (at, f)
+        with pytest.raises(RuntimeError):
+            solver.set_endgame(-2)
+    finally:
+        solver.set_endgame(-1)
+        solver.set_kernel_variant(0)
+    assert len(np.unique(plain["stats"]["inner_iters"])) > 5      # the iteration counts do spread
+    if prec == 64:
+        ref = ol.solve_batch(b, o, nthreads=8)
+        assert np.array_equal(ref["stats"]["status"], plain["stats"]["status"]) and ref["stats"]["status"][7] == pkg._abi.TSAT_DIVERGED
+        ok = np.flatnonzero(ref["stats"]["status"] != pkg._abi.TSAT_DIVERGED)      # (a diverged rollout holds whatever overflowed)
+        pick = lambda r: dict(X=r["X"][ok], U=r["U"][ok], K=r["K"][ok], stats=r["stats"][ok])
+        assert_same_solution(pick(ref), pick(plain))
+
+
 def test_gpu_one_call_abi_entry(pkg, ol, solver):
     """tsat_solve_batch: the single call a Julia `ccall` would make in place of solve!(prob, solver)"""
     lib, abi = pkg._abi.load(), pkg._abi

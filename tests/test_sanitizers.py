@@ -62,6 +62,14 @@ def test_emulated_kernels_are_race_free_under_tsan(exe, oracle_run):
     assert "ThreadSanitizer" not in err, err[-3000:]
     assert rc == 0
     assert out.count("solve es=") == 4        # both state-difference modes x both integrators ran to the end
+    if "packed" in exe:
+        # the endgame of a packed launch (tsat_set_endgame): counters, the parked list and the states go from the first launch's
+        # wavefronts to the second's through HBM — same checksums, no report, and something was parked
+        rc2, out2, err2 = _run(exe, {"TSAN_OPTIONS": "halt_on_error=0:report_signal_unsafe=0", "TSAT_EMU_SUSPEND_AT": "3"})
+        assert "ThreadSanitizer" not in err2, err2[-3000:]
+        assert rc2 == 0 and out2 == out
+        parked = [int(x) for x in re.findall(r"endgame parked (\d+)", err2)]
+        assert len(parked) == 4 and max(parked) > 0, err2[-500:]
     if exe == "emu_tsan":                        # same workload as the oracle run: the checksums agree
         a, b = _numbers(oracle_run[1]), _numbers(out)
         assert a.keys() == b.keys() and len(a) >= 7

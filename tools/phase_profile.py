@@ -28,6 +28,7 @@ opts.opts_uncon.iterations = 10; opts.opts_uncon.dJ_counter_limit = 1
 solver = to.AugmentedLagrangianSolver(None, opts)
 o = opts.to_abi(b.N, b.n_tab, 3, error_state=es)
 solver.set_kernel_variant(variant)
+solver.set_endgame(0)     # one kernel: the stamps of a wavefront cover its trajectories from start to end
 solver.upload(b, o.max_linesearch); solver.trace(1)
 ms = solver.run(o); ms = solver.run(o)
 tr = solver.trace_download()[:, 0, :]
@@ -40,6 +41,9 @@ print(f"kernel {ms:.2f} ms (stamped build); mean inner its {it.mean():.1f}")
 for i, name in enumerate(("forward sweep", "jacobian lanes", "riccati", "parallel passes")):
     print(f"  {name:16s}: {tr[:, i].mean()/1e6:8.2f} Mcycles/wave  ({100*tr[:, i].sum()/tot.sum():5.1f} %)  "
           f"per iteration {np.mean(tr[:, i]/np.maximum(it,1))/1e3:8.1f} kcycles; per knot-iteration {np.mean(tr[:, i]/np.maximum(it,1))/N:7.1f} cycles")
+if variant in (3, 4) or (variant == 0 and T >= 3072):
+    for i, name in ((6, "of the passes: copy of the accepted roll-out + gradient"), (7, "of the passes: end of an inner loop (duals, penalty, next outer)")):
+        print(f"  {name:66s}: per knot-iteration {np.mean(tr[:, i]/np.maximum(it,1))/N:7.1f} cycles")
 print(f"  slowest wave: {tot.max()/1e6:.1f} Mcycles, {int(it[np.argmax(tot)])} iterations (the launch ends with it); mean wave {tot.mean()/1e6:.1f}")
 print(f"  sum of stamped phases {tot.mean()/1e6:.1f} Mcycles/wave = {tot.mean()/ (ms*1e-3)/1e9:.2f} GHz-equivalent of the kernel time")
 solver.close()

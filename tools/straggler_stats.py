@@ -19,6 +19,13 @@ for v in (0, 2, 3, 4):
     s.set_kernel_variant(v)
     ms = s.run(o); ms = s.run(o)
     print(f"variant {v}: {ms:.1f} ms -> {T / ms * 1e3:.0f} solves/s")
+s.set_kernel_variant(3)
+for at in (0, 512, 1024, 1536, 2048, 3072, 4096):     # tsat_set_endgame: park the last `at` live trajectories for a one-per-wavefront launch
+    s.set_endgame(at)
+    ms = s.run(o); ms = s.run(o)
+    print(f"packed, endgame at {at}: {ms:.1f} ms -> {T / ms * 1e3:.0f} solves/s")
+s.set_endgame(-1); s.set_kernel_variant(0)
+s.run(o)
 st = s.download(want_K=False)["stats"]
 it = st["inner_iters"].astype(int) + st["bp_restarts"]
 print("status counts", np.bincount(st["status"], minlength=4), "; inner iterations: min / q10 / median / mean / q90 / max",

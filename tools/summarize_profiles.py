@@ -21,17 +21,26 @@ def one(pattern):
 
 
 def counters(d):
+    """mean per LAUNCH: a packed launch with an endgame is two kernels (solve + resume, tsat_set_endgame), dispatched equally often"""
     acc, n = {}, {}
     kern = None
     with open(one(f"{d}/**/*counter_collection.csv")) as f:
         for r in csv.DictReader(f):
-            if "tsat_solve_kernel" not in r["Kernel_Name"]:
+            name = r["Kernel_Name"]
+            kind = "solve" if "tsat_solve_kernel" in name else ("resume" if "tsat_resume_kernel" in name else None)
+            if kind is None:
                 continue
-            k = r["Counter_Name"]
+            k = (kind, r["Counter_Name"])
             acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
             n[k] = n.get(k, 0) + 1
-            kern = r["Kernel_Name"]
-    return {k: acc[k] / n[k] for k in acc}, kern
+            if kind == "solve":
+                kern = name
+    out = {}
+    for (kind, c), v in acc.items():
+        out[c] = out.get(c, 0.0) + v / n[(kind, c)]
+    if any(kind == "resume" for kind, _ in acc):
+        kern += " + its resume kernel"
+    return out, kern
 
 
 shutil.copy(os.path.join(src, "bench_n1.json"), os.path.join(dst, "bench_n1_final.json"))

@@ -33,6 +33,9 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 #define TSAT_SCHED_FENCE() ((void)0)
 #define TSAT_WAIT_LDS() ((void)0)
 #define TSAT_NO_UNROLL
+// device-wide counters (emulated wavefronts run on several host threads)
+#define TSAT_ATOMIC_ADD(ptr, v) __atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED)
+#define TSAT_ATOMIC_LOAD(ptr) __atomic_load_n((ptr), __ATOMIC_RELAXED)
 #else
 #define TSAT_DEV __device__ __forceinline__
 // Each sweep is its own (non-inlined) function: the register allocator then works on one hot loop at a time
@@ -76,6 +79,8 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 // OLDER data behind more than 15 newer reads can only be expressed as lgkmcnt(0), which would wait for the new batch as well.
 #define TSAT_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)
 #define TSAT_NO_UNROLL _Pragma("unroll 1")
+#define TSAT_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
+#define TSAT_ATOMIC_LOAD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
 // Every build contracts a*b + c ONLY where the source writes it in one expression (the language's own rule, decided by the front end
@@ -194,6 +199,14 @@ struct KArgs {
   double* trace;      // [T][trace_rows][8] or null
   int trace_rows;
   real* JW;           // packed builds: Jacobian records of the backward chunk in flight, [wavefront][4][16][84] (tsat_packed.hpp)
+  // Endgame of a packed launch (tsat_packed.hpp, "suspension"): once at most `suspend_at` trajectories of the batch are still
+  // iterating, every wavefront parks its live ones — id and Resume record appended to the lists below — and leaves; a second
+  // launch gives each parked trajectory a wavefront of its own in the one-trajectory mapping (tsat_resume_kernel_*).
+  int suspend_at = 0;           // 0: never
+  int* live = nullptr;          // [1] trajectories that have not finished (set to T before the launch)
+  int* susp_n = nullptr;        // [1] parked so far
+  int* susp_ids = nullptr;      // [T]
+  void* susp_state = nullptr;   // [T] Resume<real> records
 };
 
 // reals of a.JW per group of four trajectories (4 trajectories x 16 knots x 84-real records): host allocation and kernels agree on it
@@ -1627,7 +1640,7 @@ struct Resume {
 };
 
 template <typename real, int INTEG, int DIAGJ, int ES>
-TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, const Resume<real>* rs = nullptr) {
+TSAT_DEV int solve_trajectory(const KArgs<real>& a, int traj, const Resume<real>* rs = nullptr) {   // returns 1: parked (packed builds' endgame)
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
   const tsat_options& o = a.opt;
@@ -1702,6 +1715,35 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, const Resume<real
       }
       bool regfail = false;
       for (int it = it0; it <= o.max_inner; ++it) {
+#ifdef TSAT_PACKED
+        // A continuation inside a packed launch (hand_over_last) parks for the endgame like the wavefront it came from
+        // (tsat_packed.hpp, suspend_if_endgame): the launch that follows cannot begin before this one has drained.
+        if (rs && a.suspend_at && a.live) {
+          int* seen = reinterpret_cast<int*>(lds + L_RED);
+          TSAT_SYNC_LDS();
+          if (lane == 0) seen[0] = TSAT_ATOMIC_LOAD(a.live);
+          TSAT_SYNC_LDS();
+          const int live_now = seen[0];
+          TSAT_SYNC_LDS();
+          if (live_now <= a.suspend_at) {
+            if (p.cur != 0) {       // the nominal trajectory goes home to its own slab, where any mapping finds it
+              for (int k = lane; k < N; k += WAVE)
+                for (int i = 0; i < XUW; ++i) p.XU0[(size_t)k * XUW + i] = p.XU[(size_t)k * XUW + i];
+            }
+            if (lane == 0) {
+              const int pos = TSAT_ATOMIC_ADD(a.susp_n, 1);
+              a.susp_ids[pos] = traj;
+              Resume<real>& r = reinterpret_cast<Resume<real>*>(a.susp_state)[pos];
+              r.Jprev = Jprev; r.mu = mu; r.rho = rho; r.drho = drho; r.grad = grad;
+              for (int i = 0; i < 7; ++i) r.nu[i] = lds[L_NU + i];
+              r.outer = outer; r.it = it; r.djz = djz; r.inner_iters = inner_iters; r.ls_trials = ls_trials;
+              r.n_backward = n_backward; r.n_forward = n_forward; r.bp_restarts = bp_restarts; r.fp_fails = fp_fails; r.trow = trow;
+            }
+            TSAT_SYNC();
+            return 1;
+          }
+        }
+#endif
         BwdOut<real> bw;
         for (;;) {
           n_backward++;
@@ -1789,6 +1831,9 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, const Resume<real
           double* r = trace + 8 * trow;
           r[0] = outer; r[1] = it; r[2] = (double)Jprev; r[3] = (double)J; r[4] = (jw < WAVE) ? jw : -1;
           r[5] = (double)rho_used; r[6] = (double)dV1; r[7] = (double)dV2;
+#if defined(TSAT_PROFILE) && !defined(TSAT_EMU)
+          r[7] = (double)wall_clock64();     // diagnostic build: when (100 MHz counter) the iteration ended (tools/straggler_timeline.py)
+#endif
         }
         trow++;
         Jprev = J;
@@ -1838,6 +1883,7 @@ TSAT_DEV void solve_trajectory(const KArgs<real>& a, int traj, const Resume<real
     (void)pc_fwd; (void)pc_par;
 #endif
   }
+  return 0;
 }
 
 // ==================================================================================================

@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared tsat_kernels.hip -o libtortoise_hip.so
 // One wavefront (a 64-thread workgroup) owns one trajectory for the whole AL-iLQR solve; see tsat_device.hpp.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <thread>
@@ -120,6 +121,7 @@ struct tsat_handle {
   tsat_stats* stats = nullptr;
   double* trace = nullptr;
   int64_t bytes = 0;
+  int endgame = -1;           // packed builds: park the last trajectories for a one-per-wavefront launch; -1 automatic, 0 never, n: at n live
   int variant = 0;            // solve-kernel build: 0 automatic (dense above 1024 trajectories), 1 wide, 2 dense
   // host copies of the small per-trajectory inputs of the last upload (26 doubles each), for tsat_tvlqr_resident
   std::vector<double> hx0, hxf, htau0, hdtau, hdt, hJ;
@@ -139,7 +141,7 @@ struct tsat_handle {
          WS_HZ_B, WS_HZ_DT, WS_HZ_CUT, WS_HZ_C, WS_HZ_I, WS_BT_COEF, WS_BT_KEP, WS_BT_T0, WS_BT_TF, WS_BT_POS, WS_BT_B,
          WS_JW, WS_MPC_HX, WS_MPC_HU,
          WS_DL_X, WS_DL_U, WS_DL_K, WS_AG_X, WS_AG_U, WS_AG_ST, WS_AG_XA, WS_AG_UA, WS_AG_STA,   // staging: WS_DL_X .. WS_AG_STA (tsat_workspace_trim)
-         WS_AG_CHK, WS_MPC_TALLY, WS_COUNT };
+         WS_AG_CHK, WS_MPC_TALLY, WS_ENDGAME, WS_COUNT };
   void* ws[WS_COUNT] = {};
   size_t ws_bytes[WS_COUNT] = {};
   // RCCL communicator of the sweep (tsat_comm_init): one rank per handle / GPU
@@ -427,6 +429,24 @@ bool uses_packed_build(const tsat_handle* h, int precision) {
   return h->variant == 0 && h->T >= (precision == 32 ? TSAT_PACKED_F32_MIN_T : TSAT_PACKED_MIN_T);
 }
 
+// Endgame of a packed launch (tsat_packed.hpp, suspend_if_endgame). Automatic: once a quarter of the batch, at most the 2048
+// wavefront slots of the machine (256 CUs x 4 SIMDs x 2), is all that still iterates — and only for iteration budgets long
+// enough to spread the trajectories (the 1 x 3 budget of the receding-horizon loop ends all of them together).
+// One block for both precisions: two counters, then T ids, then T Resume records (sized for doubles).
+struct EndgameArgs { int suspend_at = 0; int *live = nullptr, *susp_n = nullptr, *susp_ids = nullptr; void* susp_state = nullptr; };
+EndgameArgs endgame_args(tsat_handle* h, const tsat_options* o) {
+  EndgameArgs a;
+  int at = h->endgame;
+  if (at < 0) at = ((int64_t)o->max_outer * o->max_inner >= 20) ? (int)std::min<int64_t>(2048, h->T / 4) : 0;
+  if (at <= 0) return a;
+  const size_t T = (size_t)h->T, ids_at = 16, st_at = (ids_at + T * sizeof(int) + 15) / 16 * 16;
+  char* w = (char*)ws_get(h, tsat_handle::WS_ENDGAME, st_at + T * sizeof(Resume<double>));
+  if (!w) return a;     // no endgame then: the packed kernel runs every trajectory to its end, as before
+  a.suspend_at = (int)std::min<int64_t>(at, h->T);
+  a.live = (int*)w; a.susp_n = (int*)w + 1; a.susp_ids = (int*)(w + ids_at); a.susp_state = w + st_at;
+  return a;
+}
+
 KArgs<double> solve_args(tsat_handle* h, const tsat_options* o) {
   KArgs<double> a;
   a.T = (int)h->T; a.N = h->N; a.n_tab = h->n_tab; a.max_ls = h->max_ls < NSTORE ? h->max_ls : NSTORE; a.opt = *o;
@@ -434,6 +454,10 @@ KArgs<double> solve_args(tsat_handle* h, const tsat_options* o) {
   a.XU = h->XU; a.KD = h->KD; a.LAM = h->LAM; a.CAND = h->CAND;
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
   a.JW = uses_packed_build(h, 64) ? (double*)packed_workspace(h) : nullptr;
+  if (a.JW) {
+    const EndgameArgs e = endgame_args(h, o);
+    a.suspend_at = e.suspend_at; a.live = e.live; a.susp_n = e.susp_n; a.susp_ids = e.susp_ids; a.susp_state = e.susp_state;
+  }
   return a;
 }
 
@@ -460,6 +484,10 @@ int launch_solve_f32(tsat_handle* h, const tsat_options* o) {
   a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
   a.JW = uses_packed_build(h, 32) ? (float*)packed_workspace(h) : nullptr;
   if (uses_packed_build(h, 32) && !a.JW) return -10;
+  if (a.JW) {
+    const EndgameArgs e = endgame_args(h, o);
+    a.suspend_at = e.suspend_at; a.live = e.live; a.susp_n = e.susp_n; a.susp_ids = e.susp_ids; a.susp_state = e.susp_state;
+  }
   // build by batch size: the layout for two wavefronts per SIMD while the batch fits the GPU that way (256 CUs x 4 SIMDs x 2),
   // else the one for four; tsat_set_kernel_variant(h, 12 | 13 | 14) forces one (tuning, tests)
   // batches several times larger than the machine: the packed build (tsat_kernels_packed_f32.hip), as in fp64
@@ -506,6 +534,13 @@ int tsat_set_kernel_variant(tsat_handle* h, int32_t variant) {
   if (!((variant >= 0 && variant <= 4) || (variant >= 12 && variant <= 14)))
     return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), 3 (packed, 4 trajectories per wavefront), 4 (packed, 8), or 12 / 13 / 14 (fp32 layouts for 2 / 3 / 4 waves per SIMD)");
   h->variant = variant;
+  return 0;
+}
+
+int tsat_set_endgame(tsat_handle* h, int32_t suspend_at) {
+  if (!h) return -1;
+  if (suspend_at < -1) return fail(h, -1, "suspend_at must be -1 (automatic), 0 (never) or the live count at which the packed builds park their trajectories");
+  h->endgame = suspend_at;
   return 0;
 }
 

@@ -12,6 +12,7 @@
 #define TSAT_PK_NAME(base) base
 #endif
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "tsat_packed.hpp"
 
 using namespace tsat;
@@ -22,6 +23,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   if (wave * PK_G >= a.T) return;
   solve_group<real, INTEG, DIAGJ, ES>(a, wave);
 }
+
+// Endgame (tsat_packed.hpp, suspend_if_endgame): the trajectories the solve kernel parked, one per wavefront from here on.
+// Launched with a.suspend_at blocks; the parked count is known on the device only.
+template <typename real, int INTEG, int DIAGJ, int ES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void TSAT_PK_NAME(tsat_resume_kernel_packed)(KArgs<real> a) {
+  const int w = blockIdx.x;
+  if (w >= *a.susp_n) return;
+  (void)continue_trajectory<real, INTEG, DIAGJ, ES>(a, a.susp_ids[w], reinterpret_cast<const Resume<real>*>(a.susp_state)[w]);
+}
+__global__ void TSAT_PK_NAME(tsat_endgame_init_kernel)(int* live, int* susp_n, int T) { *live = T; *susp_n = 0; }
 
 // called by tsat_kernels.hip; same variant axes as the other builds: integrator x inertia class x error-state mode
 hipError_t TSAT_PK_NAME(tsat_launch_solve_packed)(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream) {
@@ -39,7 +50,23 @@ hipError_t TSAT_PK_NAME(tsat_launch_solve_packed)(const KArgs<double>& a, int rk
   // while every stored candidate costs 80 B per knot and sweep of HBM writes whether it wins or not.
   KArgs<double> b = a;
   b.max_ls = a.max_ls < PK_STORE ? a.max_ls : PK_STORE;
+  if (const char* e = getenv("TSAT_PK_STORE")) { const int v = atoi(e); if (v >= 1 && v < b.max_ls) b.max_ls = v; }   // tuning (tools/store_probe.py)
+  static const kern_t resume[2][3][2] = {
+      {{TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 3, 0, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 3, 0, 1>},
+       {TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 3, 1, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 3, 1, 1>},
+       {TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 3, 2, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 3, 2, 1>}},
+      {{TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 4, 0, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 4, 0, 1>},
+       {TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 4, 1, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 4, 1, 1>},
+       {TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 4, 2, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 4, 2, 1>}}};
+  const bool endgame = b.suspend_at > 0 && b.live && b.susp_n && b.susp_ids && b.susp_state;
+  if (!endgame) b.suspend_at = 0;
+  else hipLaunchKernelGGL(TSAT_PK_NAME(tsat_endgame_init_kernel), dim3(1), dim3(1), 0, stream, b.live, b.susp_n, b.T);
   hipLaunchKernelGGL(variants[rk4 ? 1 : 0][inertia_class][error_state ? 1 : 0], dim3(waves), dim3(64), 0, stream, b);
+  if (endgame) {
+    KArgs<double> c = b;
+    c.live = nullptr;          // nothing parks in the second launch
+    hipLaunchKernelGGL(resume[rk4 ? 1 : 0][inertia_class][error_state ? 1 : 0], dim3((unsigned)b.suspend_at), dim3(64), 0, stream, c);
+  }
   return hipGetLastError();
 }
 int TSAT_PK_NAME(tsat_packed_group)(void) { return PK_G; }

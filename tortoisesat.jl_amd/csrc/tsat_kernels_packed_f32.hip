@@ -26,6 +26,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TSAT_PKF_WAV
   solve_group<float, INTEG, DIAGJ, ES>(a, wave);
 }
 
+// endgame of the launch: the parked trajectories, one per wavefront (see tsat_kernels_packed.hip)
+template <int INTEG, int DIAGJ, int ES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TSAT_PKF_WAVES, TSAT_PKF_WAVES))) void TSAT_PK_NAME(tsat_resume_kernel_packed_f32)(KArgs<float> a) {
+  const int w = blockIdx.x;
+  if (w >= *a.susp_n) return;
+  (void)continue_trajectory<float, INTEG, DIAGJ, ES>(a, a.susp_ids[w], reinterpret_cast<const Resume<float>*>(a.susp_state)[w]);
+}
+__global__ void TSAT_PK_NAME(tsat_endgame_init_kernel_f32)(int* live, int* susp_n, int T) { *live = T; *susp_n = 0; }
+
 hipError_t TSAT_PK_NAME(tsat_launch_solve_packed_f32)(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream) {
   using kern_t = void (*)(KArgs<float>);
   static const kern_t variants[2][3][2] = {
@@ -38,6 +47,21 @@ hipError_t TSAT_PK_NAME(tsat_launch_solve_packed_f32)(const KArgs<float>& a, int
   const unsigned waves = (unsigned)((a.T + PK_G - 1) / PK_G);
   KArgs<float> b = a;
   b.max_ls = a.max_ls < PK_STORE ? a.max_ls : PK_STORE;      // stored candidates per sweep, as in tsat_kernels_packed.hip
+  static const kern_t resume[2][3][2] = {
+      {{TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<3, 0, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<3, 0, 1>},
+       {TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<3, 1, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<3, 1, 1>},
+       {TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<3, 2, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<3, 2, 1>}},
+      {{TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<4, 0, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<4, 0, 1>},
+       {TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<4, 1, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<4, 1, 1>},
+       {TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<4, 2, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<4, 2, 1>}}};
+  const bool endgame = b.suspend_at > 0 && b.live && b.susp_n && b.susp_ids && b.susp_state;
+  if (!endgame) b.suspend_at = 0;
+  else hipLaunchKernelGGL(TSAT_PK_NAME(tsat_endgame_init_kernel_f32), dim3(1), dim3(1), 0, stream, b.live, b.susp_n, b.T);
   hipLaunchKernelGGL(variants[rk4 ? 1 : 0][inertia_class][error_state ? 1 : 0], dim3(waves), dim3(64), 0, stream, b);
+  if (endgame) {
+    KArgs<float> c = b;
+    c.live = nullptr;          // nothing parks in the second launch
+    hipLaunchKernelGGL(resume[rk4 ? 1 : 0][inertia_class][error_state ? 1 : 0], dim3((unsigned)b.suspend_at), dim3(64), 0, stream, c);
+  }
   return hipGetLastError();
 }

@@ -652,8 +652,8 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
 // iteration budget that spreads the trajectories' iteration counts (3 x 50: 21 ... 150), most wavefronts are down to one live
 // trajectory for the last third of the launch. Same bits either way (every build is the same solve).
 template <typename real, int INTEG, int DIAGJ, int ES>
-TSAT_PHASE void continue_trajectory(const KArgs<real>& a, int traj, Resume<real> r) {
-  solve_trajectory<real, INTEG, DIAGJ, ES>(a, traj, &r);
+TSAT_PHASE int continue_trajectory(const KArgs<real>& a, int traj, Resume<real> r) {      // 1: parked for the endgame, not finished
+  return solve_trajectory<real, INTEG, DIAGJ, ES>(a, traj, &r);
 }
 
 // the whole AL-iLQR solve of trajectories traj0 .. traj0 + PK_G - 1 (traj0 = wave * PK_G) by one wavefront
@@ -715,6 +715,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       st.status = u.status; st.outer_iters = u.outer; st.inner_iters = u.inner_iters; st.ls_trials = u.ls_trials;
       st.n_backward = u.n_backward; st.n_forward = u.n_forward; st.bp_restarts = u.bp_restarts; st.fp_fails = u.fp_fails;
       st.cost = (double)cost; st.cost_al = (double)cost_al; st.c_max = (double)cmax; st.grad = (double)u.grad;
+      if (a.live) (void)TSAT_ATOMIC_ADD(a.live, -1);
     }
     u.active = 0; u.need_bwd = 0;
   };
@@ -747,6 +748,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
   };
   // Advance trajectory g from "a forward sweep has just been evaluated" (after_forward) or from the very start to the point
   // where it needs its next backward sweep (u.need_bwd) or is finished.
+  unsigned long long pc_adopt = 0, pc_end = 0;   // diagnostic build: the copy of the accepted roll-out + gradient; outer-loop bookkeeping
   auto advance = [&](int g, GState<real>& u, bool after_forward) {
     const int traj = traj0 + g;
     const TPtrs<real> p = group_ptrs<real>(a, traj);
@@ -759,6 +761,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       return;
     }
     acc_t J;
+    const unsigned long long t_ad0 = tick_();
     if (u.found) {
       J = u.Jw;
       u.ls_trials += u.jw + 1;
@@ -773,12 +776,16 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       u.grad = adopt_and_gradient<real>(p, u.N, -1);
     }
     TSAT_SYNC();
+    pc_adopt += tick_() - t_ad0;
     acc_t dJ = J - u.Jprev;
     dJ = dJ < 0 ? -dJ : dJ;
     if (trace && lane == 0 && u.trow < a.trace_rows) {
       double* r = trace + 8 * u.trow;
       r[0] = u.outer; r[1] = u.it; r[2] = (double)u.Jprev; r[3] = (double)J; r[4] = u.found ? u.jw : -1;
       r[5] = (double)u.rho_used; r[6] = (double)u.dV1; r[7] = (double)u.dV2;
+#if defined(TSAT_PROFILE) && !defined(TSAT_EMU)
+      r[7] = (double)wall_clock64();     // diagnostic build: when (100 MHz counter) the iteration ended (tools/straggler_timeline.py)
+#endif
     }
     u.trow++;
     u.Jprev = J;
@@ -791,7 +798,9 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       u.need_bwd = 1;
       return;
     }
+    const unsigned long long t_e0 = tick_();
     end_inner(g, p, u);
+    pc_end += tick_() - t_e0;
   };
   unsigned long long pc_jac = 0, pc_ric = 0;   // diagnostic build: shader clocks in the Jacobian lanes / the Riccati lanes
   // Backward sweeps of all trajectories that need one (mine.need_bwd), together, with their regularisation restarts:
@@ -906,9 +915,41 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
     r.outer = u.outer; r.it = u.it; r.djz = u.djz; r.inner_iters = u.inner_iters; r.ls_trials = u.ls_trials;
     r.n_backward = u.n_backward; r.n_forward = u.n_forward; r.bp_restarts = u.bp_restarts; r.fp_fails = u.fp_fails; r.trow = u.trow;
     TSAT_SYNC();
-    continue_trajectory<real, INTEG, DIAGJ, ES>(a, traj0 + gl, r);
+    const int parked = continue_trajectory<real, INTEG, DIAGJ, ES>(a, traj0 + gl, r);
     TSAT_SYNC();
+    if (a.live && !parked && lane == 0) (void)TSAT_ATOMIC_ADD(a.live, -1);
     if (myg == gl) { mine.active = 0; mine.need_bwd = 0; }
+  };
+  // Suspension: the batch is down to a.suspend_at live trajectories — fewer than the machine has wavefront slots for, so each can
+  // have a wavefront (and the faster one-trajectory mapping) of its own. The wave parks its live trajectories, each at the top of
+  // an inner iteration, and leaves; tsat_resume_kernel_packed (the launch that follows on the stream) carries them on with
+  // continue_trajectory. No wave ever waits for another: the counter is only read. Which trajectories end up parked depends on
+  // the order the hardware ran the waves in; their results do not (every mapping is the same solve, bit for bit) — only the
+  // diagnostic count n_forward, which already differs between the builds, does.
+  auto suspend_if_endgame = [&]() {
+    if (!a.suspend_at || !a.live) return;
+    int* seen = reinterpret_cast<int*>(lds + L_RED);     // one read for the whole wave: the decision is wave-uniform
+    TSAT_SYNC_LDS();
+    if (lane == 0) seen[0] = TSAT_ATOMIC_LOAD(a.live);
+    TSAT_SYNC_LDS();
+    const int live_now = seen[0];
+    TSAT_SYNC_LDS();
+    if (live_now > a.suspend_at) return;
+    for (int g = 0; g < ntr; ++g) {
+      const GState<real> u = gstate_bcast(mine, g * PK_C);
+      if (!(u.active && u.need_bwd && !u.regfail)) continue;       // (a trajectory in any other state finishes in the joint loop)
+      if (lane == 0) {
+        const int pos = TSAT_ATOMIC_ADD(a.susp_n, 1);
+        a.susp_ids[pos] = traj0 + g;
+        Resume<real>& r = reinterpret_cast<Resume<real>*>(a.susp_state)[pos];
+        r.Jprev = u.Jprev; r.mu = u.mu; r.rho = u.rho; r.drho = u.drho; r.grad = u.grad;
+        for (int i = 0; i < 7; ++i) r.nu[i] = u.nu[i];
+        r.outer = u.outer; r.it = u.it; r.djz = u.djz; r.inner_iters = u.inner_iters; r.ls_trials = u.ls_trials;
+        r.n_backward = u.n_backward; r.n_forward = u.n_forward; r.bp_restarts = u.bp_restarts; r.fp_fails = u.fp_fails; r.trow = u.trow;
+      }
+      if (myg == g) { mine.active = 0; mine.need_bwd = 0; }
+    }
+    TSAT_SYNC();
   };
 
   unsigned long long pc_fwd = 0, pc_adv = 0;   // diagnostic build (-DTSAT_PROFILE): shader clocks in forward sweeps / everything else
@@ -937,6 +978,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       if (myg == g) mine = u;
     }
     hand_over_last();
+    suspend_if_endgame();
     joint_backward();
   }
   // ---- main loop: one forward sweep for all trajectories that are still iterating, then each of them moves on ------------
@@ -1002,6 +1044,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       if (myg == g) mine = u;
     }
     hand_over_last();
+    suspend_if_endgame();
     joint_backward();
     pc_adv += tick_() - t_a0;
   }
@@ -1016,11 +1059,11 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       double* trace = a.trace + (size_t)traj0 * a.trace_rows * 8;
       const double jac = (double)pc_jac, ric = (double)pc_ric;
       trace[0] = (double)pc_fwd; trace[1] = jac; trace[2] = ric; trace[3] = (double)pc_adv - jac - ric;
-      trace[4] = (double)its; trace[5] = (double)nb;
+      trace[4] = (double)its; trace[5] = (double)nb; trace[6] = (double)pc_adopt; trace[7] = (double)pc_end;
     }
   }
 #else
-  (void)pc_fwd; (void)pc_adv; (void)pc_jac; (void)pc_ric;
+  (void)pc_fwd; (void)pc_adv; (void)pc_jac; (void)pc_ric; (void)pc_adopt; (void)pc_end;
 #endif
 }
 

@@ -267,6 +267,11 @@ class AugmentedLagrangianSolver:
         tsat_set_kernel_variant. Results do not depend on it."""
         self._check(self._lib.tsat_set_kernel_variant(self._h, int(variant)), "tsat_set_kernel_variant")
 
+    def set_endgame(self, suspend_at):
+        """packed builds: live count at which the wavefronts park their trajectories for a one-per-wavefront launch
+        (-1 automatic, 0 never): see tsat_set_endgame. Results do not depend on it."""
+        self._check(self._lib.tsat_set_endgame(self._h, int(suspend_at)), "tsat_set_endgame")
+
     # ---- resident-batch API -------------------------------------------------------------------
     def upload(self, batch: SlewBatch, max_linesearch):
         # batch.Btab is None: one table per trajectory, left on the device by the last tsat_btable_batch (magnetic.py, host=False)
