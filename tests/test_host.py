@@ -114,6 +114,21 @@ def test_shard_range_partitions_exactly(pkg):
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_inclination_sweep_dealt_out_to_ranks_covers_the_sweep(pkg):
+    """configs[3] shards: contiguous blocks (stride 1) or the sweep dealt out to the ranks (j0 = rank, stride = world) — either
+    way the ranks together hold every inclination i = 90 (j + 1/2) / T_total of src/paper_images/heatmap.jl:120 exactly once"""
+    ss = pkg.slew_setup
+    W, T_total = 4, 64
+    want = 90.0 * (np.arange(T_total) + 0.5) / T_total
+    for shards in ([ss.workload_inclination_sweep(T=16, N=20, j0=16 * r, T_total=T_total, tables=False) for r in range(W)],
+                   [ss.workload_inclination_sweep(T=16, N=20, j0=r, stride=W, T_total=T_total, tables=False) for r in range(W)]):
+        inc = np.sort(np.concatenate([b.meta["kep"][:, 2] for b in shards]))
+        np.testing.assert_allclose(inc, want, rtol=0, atol=1e-12)
+    dealt = ss.workload_inclination_sweep(T=16, N=20, j0=1, stride=W, T_total=T_total, tables=False)
+    assert dealt.meta["kep"][0, 2] == want[1] and dealt.meta["kep"][1, 2] == want[1 + W]
+    assert dealt.meta["error_state"] == 1 and dealt.meta["max_outer"] == 3 and dealt.meta["max_inner"] == 50
+
+
 def test_model_hooks_select_error_state_mode(pkg):
     """Model(f!, n, m, quaternion_error, quaternion_expansion) as at src/monte_carlo.jl:158"""
     to = pkg.trajopt

@@ -63,8 +63,13 @@ echo "configs[3] passes done" >> "$OUT/progress.txt"
 cd "$ROOT"
 python3 tools/straggler_stats.py 8192 > "$OUT/straggler_stats.txt" 2> "$OUT/straggler_stats.err"
 python3 tools/fp32_paths.py 512 > "$OUT/fp32_paths.txt" 2> "$OUT/fp32_paths.err"
+python3 tools/store_probe.py 8192 > "$OUT/store_probe.txt" 2> "$OUT/store_probe.err"
+python3 tools/straggler_timeline.py 8192 0 2048 > "$OUT/straggler_timeline.txt" 2> "$OUT/straggler_timeline.err"
 TSAT_PK_G=4 python3 tools/phase_profile.py 16384 1000 3 1 > "$OUT/phase_clocks_packed.txt" 2> "$OUT/phase_clocks_packed.err"
 TSAT_PK_G=8 python3 tools/phase_profile.py 16384 1000 4 1 > "$OUT/phase_clocks_packed8.txt" 2> "$OUT/phase_clocks_packed8.err"
 python3 tools/phase_profile.py 16384 1000 2 1 > "$OUT/phase_clocks_dense.txt" 2> "$OUT/phase_clocks_dense.err"
 fi
+# gpurun copies back at most 64 MiB: report and drop anything large (the summaries need the small CSVs and text files only)
+find "$OUT" -type f -size +2M -exec ls -la {} \; -delete
+du -sh "$OUT"
 echo done

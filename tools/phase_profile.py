@@ -32,6 +32,7 @@ solver.set_endgame(0)     # one kernel: the stamps of a wavefront cover its traj
 solver.upload(b, o.max_linesearch); solver.trace(1)
 ms = solver.run(o); ms = solver.run(o)
 tr = solver.trace_download()[:, 0, :]
+nfw = solver.download(want_K=False)["stats"]["n_forward"].astype(float)
 if variant in (3, 4) or (variant == 0 and T >= 3072):   # the packed builds stamp one row per wavefront (its first trajectory): sums over
     tr = tr[::int(os.environ.get("TSAT_PK_G", "4"))]   # its PK_G trajectories
 print(f"T = {T}, variant {variant}, error_state {es}: {len(tr)} stamped wavefronts")
@@ -44,6 +45,10 @@ for i, name in enumerate(("forward sweep", "jacobian lanes", "riccati", "paralle
 if variant in (3, 4) or (variant == 0 and T >= 3072):
     for i, name in ((6, "of the passes: copy of the accepted roll-out + gradient"), (7, "of the passes: end of an inner loop (duals, penalty, next outer)")):
         print(f"  {name:66s}: per knot-iteration {np.mean(tr[:, i]/np.maximum(it,1))/N:7.1f} cycles")
+if variant in (3, 4) or (variant == 0 and T >= 3072):   # a sweep serves the whole wavefront: cycles per sweep and knot of the WAVE
+    G = int(os.environ.get("TSAT_PK_G", "4"))
+    sw = nfw.reshape(-1, G).max(1)
+    print(f"  forward sweep, per executed sweep of a wavefront and knot: {np.mean(tr[:, 0] / np.maximum(sw, 1)) / N:7.1f} cycles ({sw.mean():.1f} sweeps per wavefront)")
 print(f"  slowest wave: {tot.max()/1e6:.1f} Mcycles, {int(it[np.argmax(tot)])} iterations (the launch ends with it); mean wave {tot.mean()/1e6:.1f}")
 print(f"  sum of stamped phases {tot.mean()/1e6:.1f} Mcycles/wave = {tot.mean()/ (ms*1e-3)/1e9:.2f} GHz-equivalent of the kernel time")
 solver.close()

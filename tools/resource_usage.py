@@ -103,7 +103,7 @@ def main():
             dm = demangle(list(fi) + list(rem))
             lines.append(f"== {unit}")
             lines.append(f"  {'kernel':<62} {'VGPR':>5} {'AGPR':>5} {'spillV':>6} {'spillS':>6} {'scratch B/lane':>14} {'LDS B':>6} {'waves/SIMD':>10}")
-            solve = [(k, v) for k, v in rem.items() if "solve_kernel" in dm.get(k, k)]
+            solve = [(k, v) for k, v in rem.items() if "solve_kernel" in dm.get(k, k) or "resume_kernel" in dm.get(k, k)]
             solve.sort(key=lambda kv: (not any(b in dm[kv[0]] for b in BENCH), dm[kv[0]]))
             for k, v in solve:
                 name = re.sub(r"\(tsat::KArgs<\w+>\)|void ", "", dm[k])

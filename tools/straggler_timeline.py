@@ -29,10 +29,12 @@ for at in ats:
     st = s.download(want_K=False)["stats"]
     tr = s.trace_download()                       # (T, rows, 8)
     n = st["inner_iters"].astype(int)
-    clk = tr[:, :, 7] / 100.0 / 1e3               # ms
-    t0 = min(clk[t, 0] for t in range(T) if n[t] > 0)     # about one iteration after the launch began
-    end = np.array([clk[t, n[t] - 1] - t0 if n[t] > 0 else 0.0 for t in range(T)])
+    clk = tr[:, :, 7] / 100.0 / 1e3               # ms; row 0 of a wavefront's first trajectory holds the phase clocks instead (diagnostic build)
+    t0 = min(clk[t, 1] for t in range(T) if n[t] > 1)     # about two iterations after the launch began
+    end = np.array([clk[t, n[t] - 1] - t0 if n[t] > 1 else 0.0 for t in range(T)])
+    clk[:, 0] = t0
     print(f"== endgame at {at}: launch {ms:.1f} ms (stamped build); last iteration ends {end.max():.1f} ms after the first one")
+    assert 0 < end.max() < 1e5, "no wall-clock stamps in the trace: is this the diagnostic build?"
     grid = np.arange(0, end.max() + 50, 50.0)
     print("   live trajectories at t [ms]:", {int(g): int((end > g).sum()) for g in grid})
     # the trajectories that end the launch: their iteration index against time

@@ -109,7 +109,8 @@ def other(tag, bench_file, cfg, stats_csv):
 other("c2", "bench_c2_fp64.json", 2, "kernel_stats_c2_fp64.csv")
 other("c2f32", "bench_c2_fp32.json", 2, "kernel_stats_c2_fp32.csv")
 other("c3", "bench_c3.json", 3, "kernel_stats_c3.csv")
-for a, b in (("bench_c3.json", "bench_c3.json"), ("straggler_stats.txt", "straggler_stats.txt"), ("fp32_paths.txt", "fp32_paths.txt")):
+for a, b in (("bench_c3.json", "bench_c3.json"), ("straggler_stats.txt", "straggler_stats.txt"), ("fp32_paths.txt", "fp32_paths.txt"),
+             ("store_probe.txt", "store_probe.txt"), ("straggler_timeline.txt", "straggler_timeline.txt")):
     if os.path.exists(os.path.join(src, a)):
         with open(os.path.join(src, a)) as f:
             keep = [ln for ln in f if not ln.startswith(("W20", "E20", "I20")) and "amdgpu.ids" not in ln]

@@ -309,18 +309,21 @@ def workload_monte_carlo(T=1024, N=1000, seed=20190530, random_orbit=False, dege
     return b
 
 
-def workload_inclination_sweep(T=8192, N=1000, seed=20190601, j0=0, T_total=65536, tables=True):
+def workload_inclination_sweep(T=8192, N=1000, seed=20190601, j0=0, T_total=65536, tables=True, stride=1):
     """configs[3] shard: deterministic inclination sweep i = 90 (j + 1/2)/T_total deg (the reference draws
     rand*90, src/paper_images/heatmap.jl:120), random RAAN / true anomaly, q0 = [0,0,1,0] (heatmap.jl:106),
     Bryson weights with that script's R scaled by 0.1 (:172) — its ``omega_max = maximum(X[1:3,:])`` without ``abs.`` (:164) is
     NOT followed: for this fixed q0 / qf pair the eigen-axis guess has no positive rate component (axis (0, -c, -c)), so the
     line as written gives omega_max = 0 and an infinite Q; the ``abs.`` of src/monte_carlo.jl:167 is used instead —
     budget 3 x 50 (heatmap.jl:197-198), the quaternion hooks of ``Model(DerivFunction,n,m,quaternion_error,
-    quaternion_expansion)`` (:154; ``meta["error_state"] = 1``). ``j0`` is the first global index of this shard."""
+    quaternion_expansion)`` (:154; ``meta["error_state"] = 1``). ``j0`` is the first global index of this shard, ``stride``
+    the step between its indices: 1 for a contiguous block of the sweep; ``world`` (with ``j0 = rank``) deals the sweep out
+    to the ranks like cards, so that every rank sees every inclination band — the iteration count of a slew depends on the
+    inclination, and contiguous blocks give the ranks unequal work (tools/shard_balance.py)."""
     dt = 0.2
     a_km = R_EARTH_KM + 400.0
     rng = np.random.Generator(np.random.PCG64([seed, j0]))
-    inc = 90.0 * (np.arange(j0, j0 + T) + 0.5) / float(T_total)
+    inc = 90.0 * (j0 + stride * np.arange(T) + 0.5) / float(T_total)
     raan = rng.random(T) * 360.0
     nu = rng.random(T) * 360.0
     B = np.stack([dipole_btable(N, dt, a_km, inc[i], raan[i], nu[i]) for i in range(T)]) if tables else np.zeros((T, 1, 3))
