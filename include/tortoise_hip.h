@@ -42,7 +42,8 @@ enum {
   TSAT_CONVERGED = 0,   /* c_max < constraint_tol after an inner solve                       */
   TSAT_MAX_OUTER = 1,   /* outer budget exhausted (src/TortoiseSat.jl:196 `iterations`)      */
   TSAT_REG_FAIL  = 2,   /* backward-pass regularisation exceeded reg_max                     */
-  TSAT_DIVERGED  = 3    /* non-finite cost in the initial rollout                            */
+  TSAT_DIVERGED  = 3    /* non-finite cost in the initial rollout (no backward sweep ran: K of
+                           such a trajectory is undefined, X / U hold the overflowed rollout) */
 };
 
 /*
@@ -189,7 +190,11 @@ typedef struct tsat_tvlqr_options {
   double  w_tol;            /* 0.05 rad/s   (src/monte_carlo.jl:70)                                           */
   double  angle_tol;        /* 0.08727 rad  (src/monte_carlo.jl:71)                                           */
   int32_t noise_mode;       /* 0: the `noise` array (NULL = noise-free plant); 1: drawn inside the kernel, below */
-  int32_t reserved;
+  int32_t rate_as_written;  /* statistic: 0 (default) |w| of sample j; 1 the line as the reference has it,
+                               `omega_norm_vec[j] = norm(sim_states[i][1:3,i])` (src/monte_carlo.jl:247): for every j the
+                               rate of sample i, the 1-based number of the trial (`noise_id` + 1, or the position in the
+                               batch + 1) — past the end of a shorter trajectory Julia raises a BoundsError, here the
+                               last sample is taken                                                           */
   uint64_t noise_seed;      /* key of the counter-based generator                                             */
   double  sigma_gyro;       /* (0.38 deg)^2: `randn(3,1)*(.38*pi/180)^2`, src/simulator.jl:5                  */
   double  sigma_att;        /* (1 deg)^2:    `randn(3,1)*(1*pi/180)^2`,   src/simulator.jl:10                 */
@@ -206,7 +211,8 @@ typedef struct tsat_tvlqr_options {
  * from Julia's global generator inside `simulator`; any generator is as faithful, this one is reproducible. */
 
 typedef struct tsat_tvlqr_stats {
-  int32_t slew_index;       /* first 1-based sample j > min_steps with |w| < w_tol and error angle < angle_tol; 0 = none */
+  int32_t slew_index;       /* first 1-based sample j > min_steps with |w| < w_tol (rate_as_written: see the options) and
+                               error angle < angle_tol; 0 = none                                              */
   int32_t failed;           /* 1 when no such sample exists (`fails[i]`, src/monte_carlo.jl:258-261)           */
   double  slew_time;        /* dt * slew_index, or dt * N when failed (`slew_time[i]`, :237,252)               */
   double  final_w_norm;     /* |w| of the last simulated sample                                                */

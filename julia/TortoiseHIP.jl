@@ -244,7 +244,7 @@ Base.@kwdef mutable struct TvlqrOptions
     w_tol::Float64 = 0.05            # slew_limits, src/monte_carlo.jl:70-71
     angle_tol::Float64 = 0.08727
     noise_mode::Int32 = 0            # 1: the kernel draws the plant noise itself (Philox4x32-10 keyed by noise_seed)
-    reserved::Int32 = 0
+    rate_as_written::Int32 = 0       # 1: `norm(sim_states[i][1:3,i])` as src/monte_carlo.jl:247 has it (rate of sample i = trial number)
     noise_seed::UInt64 = 0
     sigma_gyro::Float64 = (0.38 * pi / 180)^2    # src/simulator.jl:5
     sigma_att::Float64 = (pi / 180)^2            # src/simulator.jl:10

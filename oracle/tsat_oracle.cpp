@@ -1025,18 +1025,26 @@ int orc_tvlqr_batch(const tsat_tvlqr_options* o, int64_t T, int64_t n_btab, cons
         for (int a = 0; a < 3; ++a)
           for (int j = 0; j < 6; ++j) K_lqr[((size_t)t * (NS - 1) + k) * 18 + j * 3 + a] = Kt[(size_t)18 * k + a * 6 + j];
     // slew-time statistic (src/monte_carlo.jl:242-262; the norm is taken at sample j — the reference indexes the
-    // run number there, an evident slip)
+    // run number there, `norm(sim_states[i][1:3,i])` (:247), an evident slip that rate_as_written = 1 reproduces: the
+    // rate of sample i = trial number, for every j; clamped to the trajectory where Julia would raise a BoundsError)
     tsat_tvlqr_stats& st = stats[t];
     st.slew_index = 0; st.failed = 1; st.slew_time = h * N;
     const double* qf = xf + 7 * t + 3;
     double qfi[4] = {qf[0], -qf[1], -qf[2], -qf[3]};
+    double w_trial = 0;
+    if (o->rate_as_written) {
+      const int64_t id = noise_id ? noise_id[t] : t;
+      const double* xi = Xs + 7 * (size_t)std::min<int64_t>(std::max<int64_t>(id, 0), N - 1);
+      w_trial = std::sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
+    }
     for (int j = 1; j <= N; ++j) {
       const double* xs = Xs + 7 * (j - 1);
-      double wn = std::sqrt(xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2]), qe[4];
+      const double wj = std::sqrt(xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2]);
+      double wn = o->rate_as_written ? w_trial : wj, qe[4];
       qmult<double>(qfi, xs + 3, qe);
       double ang = 2.0 * std::acos(std::min(qe[0], 1.0));
       if (j > o->min_steps && wn < o->w_tol && ang < o->angle_tol && st.slew_index == 0) { st.slew_index = j; st.failed = 0; st.slew_time = h * j; }
-      if (j == N) { st.final_w_norm = wn; st.final_angle = ang; }
+      if (j == N) { st.final_w_norm = wj; st.final_angle = ang; }
     }
   }
   return 0;

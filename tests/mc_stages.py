@@ -23,4 +23,5 @@ class OracleStages:
         o = self.ol.tvlqr_default_options()
         o.w_tol, o.angle_tol = s.w_tol, s.angle_tol
         o.noise_mode, o.noise_seed = 1, noise_seed
+        o.rate_as_written = int(bool(getattr(s, "rate_as_written", False)))
         return self.ol.tvlqr_batch(batch, X, U, Qd, Qfd, Rd, x0_sim, opts=o, nthreads=self.nthreads, noise_ids=noise_ids)

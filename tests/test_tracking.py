@@ -83,6 +83,43 @@ def test_oracle_tracking_statistic(pkg, ol):
     assert np.max(np.abs(tv["X_sim"] - r["X"])) < 0.05          # the loop tracks the plan
 
 
+def test_statistic_as_the_reference_line_reads(pkg, ol, emu):
+    """rate_as_written = 1: `omega_norm_vec[j] = norm(sim_states[i][1:3,i])` (src/monte_carlo.jl:247) — for every sample j the
+    rate of sample i, the trial's 1-based number; recomputed from X_sim as the Julia loop does it, for trial numbers from the
+    position in the batch and from explicit ids (one past the end of the trajectory: clamped where Julia raises). Limits chosen
+    so that the slews of this short batch do arrive under the default reading."""
+    b, r = _solved(pkg, ol, T=3, N=400, budget=(5, 10))
+    Qd, Qfd, Rd, x0s, nz = _setup(pkg, b)
+    base = ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz)
+    rates = np.linalg.norm(base["X_sim"][:, :, :3], axis=2)
+    w_tol, ang_tol = 1.5 * float(rates[:, 200:].min(axis=1).max()), 3.2
+    o0 = ol.tvlqr_default_options(); o0.w_tol, o0.angle_tol = w_tol, ang_tol
+    plain = ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz, opts=o0)
+    assert np.all(plain["stats"]["slew_index"] > 10)
+    o = ol.tvlqr_default_options(); o.w_tol, o.angle_tol, o.rate_as_written = w_tol, ang_tol, 1
+    differs = 0
+    for ids in (None, np.array([350, 5, 4000], dtype=np.int64)):
+        tv = ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz, opts=o, noise_ids=ids)
+        assert np.array_equal(tv["X_sim"], plain["X_sim"])
+        for t in range(b.T):
+            i = (t if ids is None else int(ids[t])) + 1                       # Julia's i
+            w_i = np.linalg.norm(tv["X_sim"][t, min(i, b.N) - 1, :3])         # sim_states[i][1:3,i]
+            idx = 0
+            for j in range(1, b.N + 1):
+                xs = tv["X_sim"][t, j - 1]
+                ang = 2 * np.arccos(min(rm.qmult(rm.q_inv(b.xf[t, 3:]), xs[3:7])[0], 1.0))
+                if j > 10 and w_i < w_tol and ang < ang_tol:
+                    idx = j
+                    break
+            st = tv["stats"][t]
+            assert st["slew_index"] == idx and st["failed"] == (idx == 0), (t, ids)
+            assert st["final_w_norm"] == plain["stats"]["final_w_norm"][t]    # (the last sample's own rate either way)
+            differs += int(idx != plain["stats"]["slew_index"][t])
+        got = emu.tvlqr(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz, opts=o, noise_ids=ids)
+        _same_tracking(tv, got)
+    assert differs > 0          # the two readings are not the same statistic
+
+
 @pytest.mark.parametrize("noisy", [False, True])
 def test_emulated_tracking_kernel_matches_oracle(pkg, ol, emu, noisy):
     b, r = _solved(pkg, ol, T=2, N=60)
@@ -212,6 +249,11 @@ def test_gpu_tracking_matches_oracle(pkg, ol):
     assert np.max(np.abs(gen["X_sim"] - arr["X_sim"])) < 1e-12 and np.array_equal(gen["stats"]["slew_index"], arr["stats"]["slew_index"])
     o = ol.tvlqr_default_options(); o.noise_mode, o.noise_seed = 1, 424242
     _same_tracking(ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, opts=o, noise_ids=ids, nthreads=5), gen)
+    # the statistic as the reference's line reads (rate of sample i = trial number, src/monte_carlo.jl:247)
+    o = ol.tvlqr_default_options(); o.rate_as_written = 1
+    for tid in (None, np.array([250, 1, 2, 9000, 0], dtype=np.int64)):
+        got = tr.attitude_simulation(s, b, r["X"], r["U"], x0s, Qd, Qfd, Rd, noise=nz, rate_as_written=True, trial_ids=tid)
+        _same_tracking(ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz, opts=o, noise_ids=tid, nthreads=5), got)
     with pytest.raises(RuntimeError):
         tr.attitude_simulation(s, b, r["X"], r["U"], x0s, Qd, Qfd, Rd, noise=nz, noise_seed=None if False else None, min_steps=-1)
     s.close()

@@ -59,7 +59,7 @@ class TvlqrOptions(C.Structure):
 
     _fields_ = [("n_knots", C.c_int32), ("n_tab", C.c_int32), ("linearize_dt_sq", C.c_int32), ("min_steps", C.c_int32),
                 ("u_scale", C.c_double), ("w_tol", C.c_double), ("angle_tol", C.c_double),
-                ("noise_mode", C.c_int32), ("reserved", C.c_int32), ("noise_seed", C.c_uint64),
+                ("noise_mode", C.c_int32), ("rate_as_written", C.c_int32), ("noise_seed", C.c_uint64),
                 ("sigma_gyro", C.c_double), ("sigma_att", C.c_double), ("field_amp", C.c_double)]
 
 

@@ -1910,6 +1910,7 @@ struct TvArgs {
   int noise_mode;     // 1: draw the noise in the kernel (Philox4x32-10, see include/tortoise_hip.h)
   unsigned k0, k1;    // generator key
   const long long* nid;   // [T] generator ids or null (id = trajectory index)
+  int rate_as_written;    // statistic: the rate of sample `id` for every j (src/monte_carlo.jl:247 as written)
   real sg, sa, fa;    // sigma_gyro, sigma_att, field_amp
   real* KD;           // [T][N-1][24] gains (solver sign) + unused d
   real* XS;           // [T][N][10]   simulated (x,u) records
@@ -2150,13 +2151,23 @@ TSAT_DEV void tvlqr_trajectory(const TvArgs<real>& a, int traj) {
   // ---- statistic (src/monte_carlo.jl:242-262): lanes = samples ------------------------------------------
   real first = (real)(N + 1), wN = 0, angN = 0;
   const real qf0 = tr.xf[3], qf1 = -tr.xf[4], qf2 = -tr.xf[5], qf3 = -tr.xf[6];
+  // `omega_norm_vec[j] = norm(sim_states[i][1:3,i])` (src/monte_carlo.jl:247) indexes the TRIAL where the sample is meant:
+  // rate_as_written reproduces it (sample i = id + 1, clamped to the trajectory), the default takes sample j
+  real w_trial = 0;
+  if (a.rate_as_written) {
+    const long long id = a.nid ? a.nid[traj] : (long long)traj;
+    const int ji = (id < 0) ? 0 : (id > (long long)(N - 1) ? N - 1 : (int)id);
+    const TSAT_GLOBAL real* xi = XSg + (size_t)ji * XUW;
+    w_trial = sqrt_(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
+  }
   for (int j = 1 + lane; j <= N; j += WAVE) {
     const TSAT_GLOBAL real* xs = XSg + (size_t)(j - 1) * XUW;
-    const real wn = sqrt_(xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2]);
+    const real wj = sqrt_(xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2]);
+    const real wn = a.rate_as_written ? w_trial : wj;
     const real e0 = qf0 * xs[3] - (qf1 * xs[4] + qf2 * xs[5] + qf3 * xs[6]);
     const real ang = 2 * acos_(e0 < 1 ? e0 : (real)1);
     if (j > a.min_steps && wn < a.w_tol && ang < a.ang_tol && (real)j < first) first = (real)j;
-    if (j == N) { wN = wn; angN = ang; }
+    if (j == N) { wN = wj; angN = ang; }
   }
   first = wave_min(first, lds + L_RED);
   const int srcN = (N - 1) % WAVE;

@@ -225,7 +225,7 @@ inline std::string check_tv_options(const tsat_tvlqr_options& o) {
 // scales of the three draws of `simulator` (src/simulator.jl:5,10,22)
 inline void tv_noise_defaults(tsat_tvlqr_options& o) {
   const double deg = 3.14159265358979323846 / 180.0;
-  o.noise_mode = 0; o.reserved = 0; o.noise_seed = 0;
+  o.noise_mode = 0; o.rate_as_written = 0; o.noise_seed = 0;
   o.sigma_gyro = (0.38 * deg) * (0.38 * deg);
   o.sigma_att = deg * deg;
   o.field_amp = 1e-5 * 1e-5;
@@ -236,6 +236,7 @@ inline void fill_tv_noise(const tsat_tvlqr_options& o, const long long* ids, TvA
   a.noise_mode = o.noise_mode;
   a.k0 = (unsigned)(o.noise_seed & 0xFFFFFFFFull); a.k1 = (unsigned)(o.noise_seed >> 32);
   a.nid = ids;
+  a.rate_as_written = o.rate_as_written;
   a.sg = (real)o.sigma_gyro; a.sa = (real)o.sigma_att; a.fa = (real)o.field_amp;
 }
 

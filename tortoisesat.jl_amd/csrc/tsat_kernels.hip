@@ -704,7 +704,7 @@ int run_tvlqr(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, int N, int
   if (noise) { A((void**)&dNZ, tsat_handle::WS_TV_NZ, nNZ * 8); C(dNZ, noise, nNZ * 8); }
   A((void**)&dKD, tsat_handle::WS_TV_KD, nKD * 8); A((void**)&dXS, tsat_handle::WS_TV_XS, nXS * 8);
   A((void**)&dst, tsat_handle::WS_TV_ST, Tn * sizeof(tsat_tvlqr_stats));
-  if (o->noise_mode == 1 && noise_id) { A((void**)&dnid, tsat_handle::WS_TV_NID, Tn * sizeof(long long)); C(dnid, noise_id, Tn * sizeof(long long)); }
+  if ((o->noise_mode == 1 || o->rate_as_written) && noise_id) { A((void**)&dnid, tsat_handle::WS_TV_NID, Tn * sizeof(long long)); C(dnid, noise_id, Tn * sizeof(long long)); }
   // ragged batch: the slabs beyond a trajectory's own horizon stay zero
   if (dnk && !rc && (hipMemsetAsync(dKD, 0, nKD * 8, h->stream) != hipSuccess || hipMemsetAsync(dXS, 0, nXS * 8, h->stream) != hipSuccess)) rc = -10;
   if (!rc) {

@@ -52,6 +52,7 @@ class MonteCarloSetup:
     lqr_r: float = 0.5e3          # (:228)
     w_tol: float = 0.05           # slew_limits (:70-71)
     angle_tol: float = 0.08727
+    rate_as_written: bool = False  # statistic: True takes `norm(sim_states[i][1:3,i])` literally (:247: the rate of sample i = trial number)
     field_rate: str = "physical"
     inertia: str = "1U"           # (:31-33)
 
@@ -96,7 +97,8 @@ class GpuStages:
     def attitude_simulation(self, batch, X, U, x0_sim, Qd, Qfd, Rd, noise_seed, noise_ids, s, want_trajectories=True):
         # the batch just solved is still resident: its trajectories and tables do not travel again
         return tr.attitude_simulation(self.solver, batch, None, None, x0_sim, Qd, Qfd, Rd, noise_seed=noise_seed, noise_ids=noise_ids,
-                                      w_tol=s.w_tol, angle_tol=s.angle_tol, want_K=False, want_trajectories=want_trajectories)
+                                      w_tol=s.w_tol, angle_tol=s.angle_tol, want_K=False, want_trajectories=want_trajectories,
+                                      rate_as_written=bool(getattr(s, "rate_as_written", False)))
 
 
 def trial_rng(seed, i):

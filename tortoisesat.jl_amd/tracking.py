@@ -83,13 +83,16 @@ def generated_noise(seed, ids, N, sigma_gyro=(0.38 * np.pi / 180.0) ** 2, sigma_
 
 def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noise=None, linearize_dt_sq=True,
                         u_scale=1e-2, min_steps=10, w_tol=0.05, angle_tol=0.08727, noise_seed=None, noise_ids=None,
-                        want_K=True, want_trajectories=True):
+                        want_K=True, want_trajectories=True, rate_as_written=False, trial_ids=None):
     """Batched ``attitude_simulation`` + slew-time statistic. ``solver`` is an AugmentedLagrangianSolver (owns the GPU
     handle); X (T,N,7), U (T,N-1,3) are the solved trajectories — or both ``None`` to track the batch that is resident on
     the device right after ``solve_`` (no re-upload of trajectories and tables; ``batch`` must be the one just solved).
     Plant noise: ``noise`` array (T,N-1,4,9), or ``noise_seed`` (+ optional per-trajectory ``noise_ids``) to have the
     kernel draw it, or neither for the noise-free plant. Returns dict(X_sim, U_sim, K (T,N-1,6,3), stats);
-    ``want_trajectories=False`` brings only the slew-time statistic back (X_sim = U_sim = None)."""
+    ``want_trajectories=False`` brings only the slew-time statistic back (X_sim = U_sim = None).
+    ``rate_as_written=True`` evaluates the statistic as the reference's line reads, ``norm(sim_states[i][1:3,i])``
+    (src/monte_carlo.jl:247): for every sample j the rate of sample i, the 1-based number of the trial — ``trial_ids`` (0-based,
+    default: ``noise_ids``, else the position in the batch); the default takes the rate of sample j, which the line means."""
     lib = _abi.load()
     T, N = batch.T, batch.N
     o = _abi.TvlqrOptions()
@@ -100,6 +103,12 @@ def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noi
             raise ValueError("give either a noise array or a noise seed")
         o.noise_mode, o.noise_seed = 1, int(noise_seed)
         ids = None if noise_ids is None else np.ascontiguousarray(noise_ids, dtype=np.int64)
+    if rate_as_written:
+        o.rate_as_written = 1
+        if trial_ids is not None:
+            if ids is not None and not np.array_equal(ids, np.asarray(trial_ids, dtype=np.int64)):
+                raise ValueError("trial_ids and noise_ids are the same index of the reference's loop: give one, or equal arrays")
+            ids = np.ascontiguousarray(trial_ids, dtype=np.int64)
     o.n_knots, o.n_tab, o.linearize_dt_sq, o.min_steps = N, batch.n_tab, int(bool(linearize_dt_sq)), int(min_steps)
     o.u_scale, o.w_tol, o.angle_tol = float(u_scale), float(w_tol), float(angle_tol)
     c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
