@@ -29,6 +29,18 @@ for variant in (3, 4):
         same = ref is None or all(np.array_equal(st[f], ref[f]) for f in st.dtype.names if f != "n_forward")
         ref = st if ref is None else ref
         print(f"variant {variant}, {slots:2d} stored slots: {ms:.1f} ms; sweeps per iteration {st['n_forward'].sum() / st['inner_iters'].sum():.3f}; same results {same}", flush=True)
+os.environ.pop("TSAT_PK_STORE", None)
+# the rule that is built in: keep `few` roll-outs while the trajectory's line searches end early, all six after a deep one
+for variant in (3, 4):
+    for few in (6, 4, 3, 2):
+        os.environ["TSAT_PK_FEW"] = str(few)
+        s.upload(b, o.max_linesearch)
+        s.set_kernel_variant(variant)
+        ms = s.run(o); ms = s.run(o)
+        st = s.download(want_K=False)["stats"]
+        same = all(np.array_equal(st[f], ref[f]) for f in st.dtype.names if f != "n_forward")
+        print(f"variant {variant}, {few} roll-outs kept while searches end early (6 after a deep one): {ms:.1f} ms; sweeps per iteration {st['n_forward'].sum() / st['inner_iters'].sum():.3f}; same results {same}", flush=True)
+os.environ.pop("TSAT_PK_FEW", None)
 w = st["ls_trials"].sum() / st["inner_iters"].sum()
 print("mean accepted index + 1:", w)
 s.close()

@@ -202,6 +202,7 @@ struct KArgs {
   // Endgame of a packed launch (tsat_packed.hpp, "suspension"): once at most `suspend_at` trajectories of the batch are still
   // iterating, every wavefront parks its live ones — id and Resume record appended to the lists below — and leaves; a second
   // launch gives each parked trajectory a wavefront of its own in the one-trajectory mapping (tsat_resume_kernel_*).
+  int pk_few = 0;               // packed builds: roll-outs kept per sweep while line searches end early (0: PK_FEW; tuning)
   int suspend_at = 0;           // 0: never
   int* live = nullptr;          // [1] trajectories that have not finished (set to T before the launch)
   int* susp_n = nullptr;        // [1] parked so far
@@ -1637,6 +1638,7 @@ struct Resume {
   acc_t Jprev;
   real mu, rho, drho, grad, nu[7];
   int outer, it, djz, inner_iters, ls_trials, n_backward, n_forward, bp_restarts, fp_fails, trow;
+  int cur, pad;     // slab that holds the nominal trajectory (cand_slab numbering; both mappings use the launch's a.max_ls slots)
 };
 
 template <typename real, int INTEG, int DIAGJ, int ES>
@@ -1675,6 +1677,7 @@ TSAT_DEV int solve_trajectory(const KArgs<real>& a, int traj, const Resume<real>
   if (rs) {
     // carry on: the nominal trajectory, gains' inputs and multipliers are in HBM; counters and terminal multipliers come along
     trow = rs->trow; mu = rs->mu; grad = rs->grad;
+    p.cur = rs->cur; p.XU = slab_ptr<real>(p, N, p.cur);
     inner_iters = rs->inner_iters; ls_trials = rs->ls_trials; n_backward = rs->n_backward; n_forward = rs->n_forward;
     bp_restarts = rs->bp_restarts; fp_fails = rs->fp_fails;
     if (lane < 7) lds[L_NU + lane] = rs->nu[lane];
@@ -1726,10 +1729,6 @@ TSAT_DEV int solve_trajectory(const KArgs<real>& a, int traj, const Resume<real>
           const int live_now = seen[0];
           TSAT_SYNC_LDS();
           if (live_now <= a.suspend_at) {
-            if (p.cur != 0) {       // the nominal trajectory goes home to its own slab, where any mapping finds it
-              for (int k = lane; k < N; k += WAVE)
-                for (int i = 0; i < XUW; ++i) p.XU0[(size_t)k * XUW + i] = p.XU[(size_t)k * XUW + i];
-            }
             if (lane == 0) {
               const int pos = TSAT_ATOMIC_ADD(a.susp_n, 1);
               a.susp_ids[pos] = traj;
@@ -1738,6 +1737,7 @@ TSAT_DEV int solve_trajectory(const KArgs<real>& a, int traj, const Resume<real>
               for (int i = 0; i < 7; ++i) r.nu[i] = lds[L_NU + i];
               r.outer = outer; r.it = it; r.djz = djz; r.inner_iters = inner_iters; r.ls_trials = ls_trials;
               r.n_backward = n_backward; r.n_forward = n_forward; r.bp_restarts = bp_restarts; r.fp_fails = fp_fails; r.trow = trow;
+              r.cur = p.cur; r.pad = 0;
             }
             TSAT_SYNC();
             return 1;

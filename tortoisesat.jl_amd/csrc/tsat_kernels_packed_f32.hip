@@ -15,6 +15,7 @@
 #define TSAT_PK_NAME(base) base
 #endif
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "tsat_packed.hpp"
 
 using namespace tsat;
@@ -47,6 +48,7 @@ hipError_t TSAT_PK_NAME(tsat_launch_solve_packed_f32)(const KArgs<float>& a, int
   const unsigned waves = (unsigned)((a.T + PK_G - 1) / PK_G);
   KArgs<float> b = a;
   b.max_ls = a.max_ls < PK_STORE ? a.max_ls : PK_STORE;      // stored candidates per sweep, as in tsat_kernels_packed.hip
+  if (const char* e = getenv("TSAT_PK_FEW")) { const int v = atoi(e); if (v >= 1) b.pk_few = v; }   // tuning (tools/store_probe.py)
   static const kern_t resume[2][3][2] = {
       {{TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<3, 0, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<3, 0, 1>},
        {TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<3, 1, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed_f32)<3, 1, 1>},

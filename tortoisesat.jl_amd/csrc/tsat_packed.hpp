@@ -32,7 +32,8 @@ namespace tsat {
 #ifndef TSAT_PK_STORE
 #define TSAT_PK_STORE 6
 #endif
-constexpr int PK_STORE = TSAT_PK_STORE;     // line-search candidates per trajectory whose rollouts a sweep keeps in HBM
+constexpr int PK_STORE = TSAT_PK_STORE;     // line-search candidates per trajectory whose rollouts a sweep keeps in HBM at most
+constexpr int PK_FEW = 3;                   // ... and while the trajectory's line searches end early (see solve_group)
 constexpr int PK_G = TSAT_PK_G;             // trajectories per wavefront
 constexpr int PK_C = WAVE / PK_G;           // lanes (line-search candidates) per trajectory
 constexpr int PK_CK = TSAT_PK_CK;           // knots per forward chunk and trajectory
@@ -99,7 +100,7 @@ static_assert(PK_JW_WAVE == TSAT_JW_REALS_PER_4, "host allocation of a.JW");
 constexpr int sym_ut(int i, int j, int n) { return i * n - (i * (i - 1)) / 2 + (j - i); }
 // hand-over between the trajectories' state lanes (PK_C per trajectory) and the lanes of a backward pass (PK_BC per trajectory),
 // in the part of the one-trajectory Riccati scratch the packed build does not use
-template <typename real> struct BwdIn { int N, need; real mu, rho; };
+template <typename real> struct BwdIn { int N, need; real mu, rho; int cur, pad; };
 template <typename real> struct BwdRes { acc_t dV1, dV2; int ok, pad; };
 constexpr int L_BWT = L_HXX;
 static_assert(L_BWT % 2 == 0, "hand-over tables are 8-byte aligned");
@@ -111,7 +112,7 @@ struct GState {
   acc_t Jprev, dV1, dV2, Jw;
   real mu, rho, drho, grad, rho_used, nu[7];
   int N, active, status, outer, it, inner_iters, ls_trials, n_backward, n_forward, bp_restarts, fp_fails, djz, trow, regfail,
-      found, jw, slot, need_bwd;
+      found, jw, slot, need_bwd, last_jw, cur;      // last_jw: accepted line-search index of the previous iteration; cur: the slab that holds the nominal trajectory (0 = XU, 1 .. = candidate slabs; cand_slab)
 };
 
 template <typename real>
@@ -126,7 +127,7 @@ TSAT_DEV GState<real> gstate_bcast(const GState<real>& s, int src) {
 }
 
 template <typename real>
-TSAT_DEV TPtrs<real> group_ptrs(const KArgs<real>& a, int traj) {
+TSAT_DEV TPtrs<real> group_ptrs(const KArgs<real>& a, int traj, int cur = 0, int N = 0) {      // cur != 0: N = the trajectory's own knot count
   const int NS = a.N;
   TPtrs<real> p;
   p.XU = (TSAT_GLOBAL real*)(a.XU + (size_t)traj * xu_stride<real>(NS));
@@ -134,7 +135,8 @@ TSAT_DEV TPtrs<real> group_ptrs(const KArgs<real>& a, int traj) {
   p.LAM = (TSAT_GLOBAL real*)(a.LAM + (size_t)traj * lam_stride<real>(NS));
   p.CAND = (TSAT_GLOBAL real*)(a.CAND + (size_t)traj * a.max_ls * xu_stride<real>(NS));
   p.bt = (const TSAT_GLOBAL real*)(a.BT + (size_t)a.bidx[traj] * a.n_tab * 4);
-  p.XU0 = p.XU; p.cur = 0;
+  p.XU0 = p.XU; p.cur = cur;
+  if (cur) p.XU = slab_ptr<real>(p, N, cur);      // the accepted roll-out is adopted by pointer, as in solve_trajectory
   return p;
 }
 
@@ -151,7 +153,7 @@ TSAT_DEV TPtrs<real> group_ptrs(const KArgs<real>& a, int traj) {
 #endif
 template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, int closed, int shift, int n_store, bool live, int N,
-                                           real mu, const real nu[7], int term_mask, real max_state) {
+                                           real mu, const real nu[7], int term_mask, real max_state, int nom) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE(), myg = lane / PK_C, myc = lane % PK_C;
   const int n_tab = a.n_tab;
@@ -175,15 +177,17 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
   double* pk_tau0 = reinterpret_cast<double*>(lds + L_ST);
   double* pk_dtau = pk_tau0 + PK_G;
   int* pk_n = reinterpret_cast<int*>(pk_dtau + PK_G);
+  int* pk_cur = pk_n + PK_G;                 // slab of each trajectory's nominal records (`nom`: this lane's trajectory)
+  static_assert((2 * PK_G * sizeof(double) + 2 * PK_G * sizeof(int)) <= (L_UNION - L_ST) * sizeof(real), "copy-lane tables fit the Riccati scratch");
   TSAT_SYNC_LDS();
-  if (myc == 0) { pk_tau0[myg] = tr.tau0; pk_dtau[myg] = tr.dtau; pk_n[myg] = live ? N : 0; }
+  if (myc == 0) { pk_tau0[myg] = tr.tau0; pk_dtau[myg] = tr.dtau; pk_n[myg] = live ? N : 0; pk_cur[myg] = nom; }
   TSAT_SYNC_LDS();
   int nmax = 0;
   for (int g = 0; g < PK_G; ++g) nmax = (pk_n[g] > nmax) ? pk_n[g] : nmax;
   real alpha = 1;
   for (int j = 0; j < myc + shift && j < TSAT_MAX_LINESEARCH; ++j) alpha *= (real)0.5;
   const TPtrs<real> pm = group_ptrs<real>(a, traj);
-  TSAT_GLOBAL real* Cg = pm.CAND + (size_t)(myc < n_store ? myc : 0) * (size_t)N * XUW;
+  TSAT_GLOBAL real* Cg = slab_ptr<real>(pm, N, cand_slab(nom, myc < n_store ? myc : 0));     // the slabs other than the nominal one, in order
   const bool store = live && myc < n_store;
   HalfWeights<real> hw;
   for (int i = 0; i < 7; ++i) hw.hQd[i] = (real)0.5 * tr.Qd[i];
@@ -221,7 +225,14 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
 #ifndef TSAT_EMU
 #pragma unroll
 #endif
-  for (int j = 0; j < PK_NI_XU; ++j) role(lane + WAVE * j, PK_UXU, XUW, a.XU, xu_stride<real>(a.N), xu_src[j], xu_lim[j]);
+  for (int j = 0; j < PK_NI_XU; ++j) {
+    role(lane + WAVE * j, PK_UXU, XUW, a.XU, xu_stride<real>(a.N), xu_src[j], xu_lim[j]);
+    const int i = lane + WAVE * j, g = i / (PK_UXU + 1), e = i - g * (PK_UXU + 1);
+    if (g < PK_G && pk_cur[g] != 0) {        // this trajectory's nominal records live in a candidate slab
+      const int tg = (traj0 + g <= tmax) ? traj0 + g : tmax;
+      xu_src[j] = (const TSAT_GLOBAL real*)(a.CAND + (size_t)tg * a.max_ls * xu_stride<real>(a.N) + (size_t)(pk_cur[g] - 1) * (size_t)pk_n[g] * XUW + (size_t)e * RPU);
+    }
+  }
 #ifndef TSAT_EMU
 #pragma unroll
 #endif
@@ -360,14 +371,14 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
 // ([4][16][PK_RECS]). Same per-knot arithmetic as jacobian_chunk (tsat_device.hpp).
 // --------------------------------------------------------------------------------------------------
 template <typename real, int INTEG, int DIAGJ, int ES>
-TSAT_PHASE void jacobian16(const KArgs<real>& a, int traj0, TSAT_GLOBAL real* jw, int kb0, bool need, int N, real mu) {
+TSAT_PHASE void jacobian16(const KArgs<real>& a, int traj0, TSAT_GLOBAL real* jw, int kb0, bool need, int N, real mu, int cur) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE(), g = lane / PK_BC, kk = lane % PK_BC;
   const int k = kb0 + kk;
   if (!(need && k < N - 1)) return;
   const int tmax = a.T - 1;
   const int traj = (traj0 + g <= tmax) ? traj0 + g : tmax;
-  const TPtrs<real> p = group_ptrs<real>(a, traj);
+  const TPtrs<real> p = group_ptrs<real>(a, traj, cur, N);
   const Traj<real> tr = load_traj_at<real>(lds + L_GTR + g * PK_GTRW, N, a.n_tab, p.bt);
   const TSAT_GLOBAL real* xu = p.XU + (size_t)k * XUW;
   real x[7], u[3], lam[6], b0[3], b1[3], b2[3];
@@ -679,7 +690,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
   mine.N = mine.active ? (a.nk ? a.nk[traj0 + myg] : NS) : 2;
   mine.status = TSAT_MAX_OUTER; mine.outer = 0; mine.it = 0; mine.inner_iters = 0; mine.ls_trials = 0; mine.n_backward = 0;
   mine.n_forward = 0; mine.bp_restarts = 0; mine.fp_fails = 0; mine.djz = 0; mine.trow = 0; mine.regfail = 0;
-  mine.found = 0; mine.jw = 0; mine.slot = 0; mine.need_bwd = 0;
+  mine.found = 0; mine.jw = 0; mine.slot = 0; mine.need_bwd = 0; mine.cur = 0; mine.last_jw = 0;
 
   // initial_controls!(prob, U0) (src/TortoiseSat.jl:191) + zero multipliers, trajectory by trajectory (lanes = knots)
   for (int g = 0; g < ntr; ++g) {
@@ -705,8 +716,16 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
     if (lane < 7) lds[L_NU + lane] = u.nu[lane];
     TSAT_SYNC();
   };
-  auto finish = [&](int g, const TPtrs<real>& p, GState<real>& u) {   // final statistics of trajectory g
+  auto finish = [&](int g, const TPtrs<real>& p_in, GState<real>& u) {   // final statistics of trajectory g
     TSAT_SYNC();
+    TPtrs<real> p = p_in;
+    if (u.cur != 0) {     // the nominal trajectory lives in one of the candidate slabs: bring it home, once per solve
+      const TSAT_GLOBAL real* src = slab_ptr<real>(p, u.N, u.cur);
+      for (int k = lane; k < u.N; k += WAVE)
+        for (int i = 0; i < XUW; ++i) p.XU0[(size_t)k * XUW + i] = src[(size_t)k * XUW + i];
+      p.XU = p.XU0; p.cur = 0; u.cur = 0;
+      TSAT_SYNC();
+    }
     const real cmax = violation_and_duals<real>(p, u.N, u.mu, tmask, 0, (real)o.dual_max);
     const acc_t cost = nominal_cost<real>(p, u.N, u.mu, tmask, 0);
     const acc_t cost_al = nominal_cost<real>(p, u.N, u.mu, tmask, 1);
@@ -751,21 +770,21 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
   unsigned long long pc_adopt = 0, pc_end = 0;   // diagnostic build: the copy of the accepted roll-out + gradient; outer-loop bookkeeping
   auto advance = [&](int g, GState<real>& u, bool after_forward) {
     const int traj = traj0 + g;
-    const TPtrs<real> p = group_ptrs<real>(a, traj);
     double* trace = a.trace ? a.trace + (size_t)traj * a.trace_rows * 8 : nullptr;
     stage_for(g, u);
     if (!after_forward) {
-      (void)adopt_and_gradient<real>(p, u.N, 0);        // the open-loop rollout becomes the nominal trajectory
+      u.cur = cand_slab(u.cur, 0);                      // the open-loop rollout (slot 0) becomes the nominal trajectory: a pointer swap
       TSAT_SYNC();
-      start_outer(p, u, 1);
+      start_outer(group_ptrs<real>(a, traj, u.cur, u.N), u, 1);
       return;
     }
     acc_t J;
     const unsigned long long t_ad0 = tick_();
+    u.last_jw = u.found ? u.jw : max_ls;
     if (u.found) {
       J = u.Jw;
       u.ls_trials += u.jw + 1;
-      u.grad = adopt_and_gradient<real>(p, u.N, u.slot);
+      u.cur = cand_slab(u.cur, u.slot);                 // adoption of the accepted roll-out by pointer
     } else {
       J = u.Jprev;
       u.ls_trials += max_ls;
@@ -773,8 +792,9 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       u.drho = (u.drho * (real)o.reg_scale > (real)o.reg_scale) ? u.drho * (real)o.reg_scale : (real)o.reg_scale;
       u.rho = (u.rho * u.drho > (real)o.reg_min) ? u.rho * u.drho : (real)o.reg_min;
       u.rho += (real)o.reg_fp;
-      u.grad = adopt_and_gradient<real>(p, u.N, -1);
     }
+    const TPtrs<real> p = group_ptrs<real>(a, traj, u.cur, u.N);
+    u.grad = todorov_gradient<real>(p.XU, p.KD, u.N);
     TSAT_SYNC();
     pc_adopt += tick_() - t_ad0;
     acc_t dJ = J - u.Jprev;
@@ -814,7 +834,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
     for (;;) {
       const bool need = mine.need_bwd != 0;
       TSAT_SYNC_LDS();
-      if (myc == 0) { tin[myg].N = mine.N; tin[myg].need = need ? 1 : 0; tin[myg].mu = mine.mu; tin[myg].rho = mine.rho; }
+      if (myc == 0) { tin[myg].N = mine.N; tin[myg].need = need ? 1 : 0; tin[myg].mu = mine.mu; tin[myg].rho = mine.rho; tin[myg].cur = mine.cur; }
       TSAT_SYNC_LDS();
       int any = 0;
       for (int g = 0; g < PK_G; ++g) any |= tin[g].need;
@@ -834,7 +854,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
             stage_for(t0 + g, u);
             real* gt = lds + L_GTR + g * PK_GTRW;
             for (int e = lane; e < PK_GT_NU + 8; e += WAVE) gt[e] = lds[L_TR + e];     // L_NU follows L_TR
-            const TSAT_GLOBAL real* XUg = (const TSAT_GLOBAL real*)(a.XU + (size_t)(traj0 + t0 + g) * xu_stride<real>(NS));
+            const TSAT_GLOBAL real* XUg = group_ptrs<real>(a, traj0 + t0 + g, u.cur, u.N).XU;
             terminal_cost_to_go<real, ES>(XUg, u.N, u.mu, tmask);
             TSAT_SYNC_LDS();
             real* gx = lds + L_GX + g * PK_GXW;
@@ -851,7 +871,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
           for (int ch = nch - 1; ch >= 0; --ch) {
             const int kb0 = ch * PK_JCH;
             const unsigned long long c0 = tick_();
-            jacobian16<real, INTEG, DIAGJ, ES>(a, traj0 + t0, jw, kb0, bneed && bw.ok, in.N, in.mu);
+            jacobian16<real, INTEG, DIAGJ, ES>(a, traj0 + t0, jw, kb0, bneed && bw.ok, in.N, in.mu, in.cur);
             TSAT_SYNC();         // the records are in the workspace (vmcnt(0)) before the ring copies read them
             const unsigned long long c1 = tick_();
             bw = riccati_group<real, NH>(a, traj0 + t0, jw, kb0, bneed, in.N, in.rho, bw.dV1, bw.dV2, bw.ok);
@@ -887,7 +907,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       GState<real> u = gstate_bcast(mine, g * PK_C);
       if (u.active && u.regfail) {
         stage_for(g, u);
-        end_inner(g, group_ptrs<real>(a, traj0 + g), u);
+        end_inner(g, group_ptrs<real>(a, traj0 + g, u.cur, u.N), u);
       }
       if (myg == g) mine = u;
     }
@@ -914,6 +934,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
     for (int i = 0; i < 7; ++i) r.nu[i] = u.nu[i];
     r.outer = u.outer; r.it = u.it; r.djz = u.djz; r.inner_iters = u.inner_iters; r.ls_trials = u.ls_trials;
     r.n_backward = u.n_backward; r.n_forward = u.n_forward; r.bp_restarts = u.bp_restarts; r.fp_fails = u.fp_fails; r.trow = u.trow;
+        r.cur = u.cur;
     TSAT_SYNC();
     const int parked = continue_trajectory<real, INTEG, DIAGJ, ES>(a, traj0 + gl, r);
     TSAT_SYNC();
@@ -946,6 +967,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
         for (int i = 0; i < 7; ++i) r.nu[i] = u.nu[i];
         r.outer = u.outer; r.it = u.it; r.djz = u.djz; r.inner_iters = u.inner_iters; r.ls_trials = u.ls_trials;
         r.n_backward = u.n_backward; r.n_forward = u.n_forward; r.bp_restarts = u.bp_restarts; r.fp_fails = u.fp_fails; r.trow = u.trow;
+        r.cur = u.cur;
       }
       if (myg == g) { mine.active = 0; mine.need_bwd = 0; }
     }
@@ -956,7 +978,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
   // ---- open-loop rollout of U0 for every trajectory of the wave, then the first backward sweeps ------------------------
   {
     const FwdOut<real> f0 = forward_sweep_packed<real, INTEG, DIAGJ, ES>(a, traj0, 0, 0, 1, mine.active != 0, mine.N, mine.mu, mine.nu,
-                                                                         tmask, max_state);
+                                                                         tmask, max_state, mine.cur);
     if (mine.active) mine.n_forward++;
     mine.Jw = f0.J;            // lane (g, 0) holds the rollout's cost (all PK_C lanes of a group computed the same rollout)
     mine.found = f0.ok;
@@ -970,7 +992,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
         stage_traj<real>((const TSAT_GLOBAL real*)(a.P + (size_t)(traj0 + g) * PSTRIDE), (real)o.u_scale);
         if (lane < 7) lds[L_NU + lane] = 0;
         TSAT_SYNC();
-        (void)adopt_and_gradient<real>(p, u.N, 0);
+        u.cur = cand_slab(u.cur, 0);               // (the overflowed rollout is what the caller gets back)
         finish(g, p, u);
       } else {
         advance(g, u, false);
@@ -990,13 +1012,20 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
     // left (max_linesearch > shift + PK_C), the next sweep takes the next PK_C.
     mine.found = 0;
     int g_shift = 0, g_mode = 0;              // per trajectory: 0 searching, 1 re-roll of the winner pending, 2 search over
+    // How many roll-outs a trajectory keeps is a fifth of the launch's HBM writes: while its line searches end early it keeps
+    // PK_FEW of them (a deeper winner is rolled out once more, below), after a deep search all n_store — the rule of
+    // solve_trajectory. The accepted candidate, and with it every result, is the same either way. Measured on one MI355X
+    // (tools/store_probe.py, TSAT_PK_FEW): 16384 x 1000 fp64 573 / 547 / 538 / 539 ms with 6 / 4 / 3 / 2 kept — the eight-per-wave
+    // launch is short of HBM write bandwidth —, nothing either way on the configs[3] shard, whose searches are deep.
+    const int few = a.pk_few > 0 ? a.pk_few : PK_FEW;
+    const int my_store = (mine.last_jw >= few - 1 || n_store < few) ? n_store : few;
     for (;;) {
       const bool live = mine.active && !mine.found && g_mode != 2;
       if (!any_lane(live)) break;
       TSAT_SYNC();
       const unsigned long long t_f0 = tick_();
-      const FwdOut<real> fw = forward_sweep_packed<real, INTEG, DIAGJ, ES>(a, traj0, 1, g_shift, (g_mode == 1) ? 1 : n_store, live, mine.N,
-                                                                           mine.mu, mine.nu, tmask, max_state);
+      const FwdOut<real> fw = forward_sweep_packed<real, INTEG, DIAGJ, ES>(a, traj0, 1, g_shift, (g_mode == 1) ? 1 : my_store, live, mine.N,
+                                                                           mine.mu, mine.nu, tmask, max_state, mine.cur);
       pc_fwd += tick_() - t_f0;
       if (live) mine.n_forward++;
       // first accepted candidate of each searching trajectory
@@ -1028,7 +1057,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
           mine.found = 1; mine.slot = 0;
         } else if (jl < PK_C) {
           mine.jw = g_shift + jl; mine.Jw = Jwin;
-          if (jl < n_store) { mine.found = 1; mine.slot = jl; }
+          if (jl < my_store) { mine.found = 1; mine.slot = jl; }
           else { g_mode = 1; g_shift = mine.jw; }
         } else {
           g_shift += PK_C;
