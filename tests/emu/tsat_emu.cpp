@@ -25,9 +25,11 @@ namespace tsat_emu {
 thread_local int g_lane = 0;
 std::barrier<>* g_bar = nullptr;
 void* g_lds = nullptr;     // one emulated wavefront at a time
+double g_xch[64 * 16];     // scratch of the emulated cross-lane (DPP) reads: 16 doubles per lane
 int lane() { return g_lane; }
 void sync() { g_bar->arrive_and_wait(); }
 void* lds() { return g_lds; }
+double* xch() { return g_xch; }
 template <typename F>
 void run_wave(size_t lds_bytes, F&& body) {
   std::vector<double> lds((lds_bytes + 7) / 8, 0.0);
@@ -74,12 +76,14 @@ struct Wave {
   int cur = 0, arrived = 0, n_done = 0;
   unsigned gen = 0;
   void* lds = nullptr;
+  double xch[64 * 16] = {};             // scratch of the emulated cross-lane (DPP) reads: 16 doubles per lane
   std::function<void()> body;
   std::unique_ptr<char[]> stacks;
 };
 thread_local Wave* g_w = nullptr;
 int lane() { return g_w->cur; }
 void* lds() { return g_w->lds; }
+double* xch() { return g_w->xch; }
 static void yield_from(int from) {      // to the next lane that has not finished (round-robin); back here when it is our turn
   Wave* w = g_w;
   int to = from;

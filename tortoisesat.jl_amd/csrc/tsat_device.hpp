@@ -21,7 +21,7 @@
 
 #ifdef TSAT_EMU
 #include <cmath>
-namespace tsat_emu { int lane(); void sync(); void* lds(); }
+namespace tsat_emu { int lane(); void sync(); void* lds(); double* xch(); }
 #define TSAT_DEV inline
 #define TSAT_PHASE inline
 #define TSAT_FWD inline
@@ -36,6 +36,7 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 // device-wide counters (emulated wavefronts run on several host threads)
 #define TSAT_ATOMIC_ADD(ptr, v) __atomic_fetch_add((ptr), (v), __ATOMIC_RELAXED)
 #define TSAT_ATOMIC_LOAD(ptr) __atomic_load_n((ptr), __ATOMIC_RELAXED)
+#define TSAT_UNIFORM_INT(x) (x)
 #else
 #define TSAT_DEV __device__ __forceinline__
 // Each sweep is its own (non-inlined) function: the register allocator then works on one hot loop at a time
@@ -81,6 +82,8 @@ namespace tsat_emu { int lane(); void sync(); void* lds(); }
 #define TSAT_NO_UNROLL _Pragma("unroll 1")
 #define TSAT_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
 #define TSAT_ATOMIC_LOAD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// an int that is the same in every lane, said so to the compiler (lane 0's copy in an SGPR): a loop or branch on it is scalar
+#define TSAT_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane((int)(x))
 #endif
 
 // Every build contracts a*b + c ONLY where the source writes it in one expression (the language's own rule, decided by the front end
@@ -316,6 +319,18 @@ TSAT_DEV acc_t* red64() {
   unsigned char* b = tsat_smem;
 #endif
   return reinterpret_cast<acc_t*>(b + (RED64_BYTES ? LDS_REALS * (int)sizeof(cfg_real) : L_RED * (int)sizeof(cfg_real)));
+}
+
+// S~ = [S; s'] of the row-oriented Riccati recursion between two chunks, in double whatever the storage type: row stride 9 from
+// L_ST on — in the double builds exactly where terminal_cost_to_go leaves it; the float builds widen it in place over the scratch
+// of the element-oriented recursion that follows L_ST (unused by the row-oriented one)
+TSAT_DEV double* st64() {
+#ifdef TSAT_EMU
+  unsigned char* b = reinterpret_cast<unsigned char*>(tsat_emu::lds());
+#else
+  unsigned char* b = tsat_smem;
+#endif
+  return reinterpret_cast<double*>(b + L_ST * (int)sizeof(cfg_real));
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1440,6 +1455,216 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
   return out;
 }
 
+// --------------------------------------------------------------------------------------------------
+// Row-oriented Riccati recursion (every build of the SOLVE kernel; the tracking kernel keeps riccati_chunk).
+// One trajectory per 16-lane ROW of the wavefront: lane j of the row owns COLUMN j of F = [A|B] (state columns j < NH, control
+// columns NH .. NH + 2) and column j of the cost-to-go S~ = [S; s'] (S~[r][j], r <= NH, in registers). Nothing goes through LDS
+// between the steps of a knot: a value another lane holds is read as the DPP operand `row_newbcast:n` of the FMA that consumes
+// it (v_fmac_f64_dpp: src0 = lane n of the reader's row; issue cost and latency of a plain v_fma_f64,
+// profiles/r04/valu_f64_ubench.txt), against ~90 cycles for an LDS write -> read exchange, of which riccati_chunk pays four per
+// knot and the packed builds' former column recursion three. The one-trajectory builds run the same instructions with the
+// four rows holding the same trajectory; the packed builds run four trajectories at once (tsat_packed.hpp).
+//   step 1  W[r]  = sum_m S~[r][m] F[m][j]                r <= NH; row NH starts from l_j = [lx; lu]_j: W[NH] = Qx_j | Qu_b
+//   step 2  Q[i]  = lxx(i,j) | luu + sum_m F[m][i] W[m]   i < NH + 3: Qxx(:, j), Qux(:, j) on a state lane, Quu(:, b) on a control lane
+//   step 3  Quu, Qu to every lane (v_mov_b64_dpp); regularise, Sylvester test, adjugate inverse, K(:, j), d (every lane)
+//   step 4  S(i,j) = Qxx(i,j) + sum_c T[c][i] K[c][j],  s(j) = Qx_j + sum_c T[c][j] d[c],  T = Qux - rho K
+//           (= Qxx + Qux'K - rho K'K: Quu K = -Qux - rho K by the definition of K)
+// S is formed column by column and is symmetric up to rounding only (both triangles are carried); the arithmetic is double
+// whatever the storage type of the records.
+// --------------------------------------------------------------------------------------------------
+#ifndef TSAT_EMU
+#include "tsat_riccati_dpp.inc"
+#endif
+template <int NH> struct RowState { double Sc[NH + 1]; };
+#ifdef TSAT_EMU
+// emulator: the DPP reads of a block become one exchange through a scratch block — every lane publishes the registers the block
+// reads across lanes, one barrier, the block's arithmetic in the GPU's operation order, one barrier
+constexpr int XCH_W = 16;
+TSAT_DEV double* xch_mine() { return tsat_emu::xch() + TSAT_LANE() * XCH_W; }
+TSAT_DEV const double* xch_of(int row_lane) { return tsat_emu::xch() + ((TSAT_LANE() & ~15) + row_lane) * XCH_W; }
+#endif
+
+// per-lane constants of riccati_row_step for lane j of a row; Qd: the trajectory's stage weights.
+//   cj: the column of F this lane reads (j clamped to the record's columns: lanes beyond them repeat column 0 and are never read);
+//   qc[i]: lxx(i, j) for the rows whose stage Hessian is a constant of the trajectory (error coordinates: the three rate rows);
+//   mq, mu_[a]: 1 on the lanes that own an entry of G'QG / luu(a), else 0; qq_off[a]: where G'QG(a, j - 3) sits in the record
+template <int NH, typename R>
+struct RowRoles {
+  int cj, qq_off[3];
+  double qc[NH], mq, mu_[3];
+  template <typename real>
+  TSAT_DEV void set(int j, const real* Qd) {
+    constexpr int ES = (NH == 6) ? 1 : 0, NC = NH + 3;
+    cj = (j < NC) ? j : 0;
+    for (int i = 0; i < NH; ++i) qc[i] = (j == i && (!ES || i < 3)) ? (double)Qd[i] : 0.0;
+    const bool att = ES && j >= 3 && j < NH;
+    mq = att ? 1.0 : 0.0;
+    for (int a = 0; a < 3; ++a) {
+      // G'QG upper triangle (0,0)(0,1)(0,2)(1,1)(1,2)(2,2): entry (min, max) of (a, j - 3)
+      const int b = att ? j - 3 : 0, lo = (a < b) ? a : b, hi = (a < b) ? b : a;
+      qq_off[a] = R::QQ + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5));
+      mu_[a] = (j == NH + a) ? 1.0 : 0.0;
+    }
+  }
+};
+// what a lane reads from its row's knot record (LDS; layout R, storage type real): its column of F, l_j = [lx; lu]_j (contiguous in
+// the record), the entries of the stage Hessian its column starts from (before the masks)
+template <int NH> struct RowIn { double f[NH], l, qq[3], luu[3]; };
+template <typename real, int NH, typename R>
+TSAT_DEV RowIn<NH> row_load(const real* rc, const RowRoles<NH, R>& ro) {
+  constexpr int ES = (NH == 6) ? 1 : 0;
+  RowIn<NH> in;
+  if constexpr (ES && sizeof(real) == 8) {          // 48-byte columns: three 16-byte reads
+    typedef real v2 __attribute__((vector_size(16)));
+    const v2* q = reinterpret_cast<const v2*>(rc + ro.cj * R::FSR);
+    for (int t = 0; t < NH / 2; ++t) { const v2 v = q[t]; in.f[2 * t] = (double)v[0]; in.f[2 * t + 1] = (double)v[1]; }
+  } else {
+    for (int m = 0; m < NH; ++m) in.f[m] = (double)rc[ro.cj * R::FSR + m];
+  }
+  in.l = (double)rc[R::LX + ro.cj];
+  for (int a = 0; a < 3; ++a) { in.qq[a] = ES ? (double)rc[ro.qq_off[a]] : 0.0; in.luu[a] = (double)rc[R::LUU + a]; }
+  return in;
+}
+
+// One knot of one row. Returns the Sylvester test (row-uniform); Kc: column j of K (state lanes), d: the feed-forward (every lane).
+template <int NH, typename R>
+TSAT_DEV bool riccati_row_step(RowState<NH>& st, const RowIn<NH>& in, const RowRoles<NH, R>& ro, double rho, double Kc[3], double d[3],
+                               acc_t& dV1, acc_t& dV2) {
+  constexpr int ES = (NH == 6) ? 1 : 0, NC = NH + 3;
+  double f[NH], W[NH + 1], Q[NC], qu[3], h00, h01, h02, h11, h12, h22;
+  for (int m = 0; m < NH; ++m) f[m] = in.f[m];
+  W[NH] = in.l;
+  // stage Hessian entries this lane's column starts from
+  for (int i = 0; i < NH; ++i) {
+    if (ES && i >= 3) Q[i] = in.qq[i - 3] * ro.mq;   // G'QG(i - 3, j - 3) on the attitude lanes
+    else Q[i] = ro.qc[i];
+  }
+  for (int a = 0; a < 3; ++a) Q[NH + a] = in.luu[a] * ro.mu_[a];
+#ifdef TSAT_EMU
+  {
+    double* x = xch_mine();
+    for (int r = 0; r <= NH; ++r) x[r] = st.Sc[r];
+    tsat_emu::sync();
+    for (int r = 0; r < NH; ++r) W[r] = 0;
+    for (int m = 0; m < NH; ++m)
+      for (int r = 0; r <= NH; ++r) W[r] = fma_(xch_of(m)[r], f[m], W[r]);
+    tsat_emu::sync();
+    for (int m = 0; m < NH; ++m) x[m] = f[m];
+    tsat_emu::sync();
+    for (int m = 0; m < NH; ++m)
+      for (int i = 0; i < NC; ++i) Q[i] = fma_(xch_of(i)[m], W[m], Q[i]);
+    tsat_emu::sync();
+    for (int a = 0; a < 3; ++a) x[a] = Q[NH + a];
+    x[3] = W[NH];
+    tsat_emu::sync();
+    h00 = xch_of(NH)[0]; h01 = xch_of(NH + 1)[0]; h02 = xch_of(NH + 2)[0];
+    h11 = xch_of(NH + 1)[1]; h12 = xch_of(NH + 2)[1]; h22 = xch_of(NH + 2)[2];
+    for (int a = 0; a < 3; ++a) qu[a] = xch_of(NH + a)[3];
+    tsat_emu::sync();
+  }
+#else
+  if constexpr (NH == 6) { TSAT_RB1_6(); TSAT_RB2_6(); TSAT_RB3_6(); }
+  else { TSAT_RB1_7(); TSAT_RB2_7(); TSAT_RB3_7(); }
+#endif
+  // step 3 (every lane; the operations of riccati_chunk's step 3)
+  const double q00 = h00 + rho, q11 = h11 + rho, q22 = h22 + rho;
+  const double q10 = h01, q20 = h02, q21 = h12;
+  const double c00 = dmm_(q11, q22, q21, q21);
+  const double c01 = dmm_(q20, q21, q10, q22);
+  const double c02 = dmm_(q10, q21, q20, q11);
+  const double c11 = dmm_(q00, q22, q20, q20);
+  const double c12 = dmm_(q10, q20, q00, q21);
+  const double c22 = dmm_(q00, q11, q10, q10);
+  const double det = dot3_(q00, c00, q10, c01, q20, c02);
+  const bool pd = (q00 > 0 && c22 > 0 && det > 0);
+  const double nid = -rcp_(det);
+  const double i00 = c00 * nid, i01 = c01 * nid, i02 = c02 * nid, i11 = c11 * nid, i12 = c12 * nid, i22 = c22 * nid;
+  Kc[0] = dot3_(i00, Q[NH], i01, Q[NH + 1], i02, Q[NH + 2]);
+  Kc[1] = dot3_(i01, Q[NH], i11, Q[NH + 1], i12, Q[NH + 2]);
+  Kc[2] = dot3_(i02, Q[NH], i12, Q[NH + 1], i22, Q[NH + 2]);
+  d[0] = dot3_(i00, qu[0], i01, qu[1], i02, qu[2]);
+  d[1] = dot3_(i01, qu[0], i11, qu[1], i12, qu[2]);
+  d[2] = dot3_(i02, qu[0], i12, qu[1], i22, qu[2]);
+  // step 4. With K = -Quu_reg^-1 Qux: Quu K = -Qux - rho K, so the new cost-to-go is Qxx + Qux'K - rho K'K = Qxx + T'K and
+  // Qx + T'd with T = Qux - rho K (column j of T from the lane's own Qux and K columns)
+  double Tc[3];
+  for (int c = 0; c < 3; ++c) Tc[c] = fma_(-rho, Kc[c], Q[NH + c]);
+#ifdef TSAT_EMU
+  {
+    double* x = xch_mine();
+    for (int c = 0; c < 3; ++c) x[c] = Tc[c];
+    tsat_emu::sync();
+    for (int c = 0; c < 3; ++c)
+      for (int i = 0; i < NH; ++i) Q[i] = fma_(xch_of(i)[c], Kc[c], Q[i]);
+    tsat_emu::sync();
+  }
+#else
+  if constexpr (NH == 6) { TSAT_RB4_6(); } else { TSAT_RB4_7(); }
+#endif
+  double sn = W[NH];
+  for (int c = 0; c < 3; ++c) sn = fma_(Tc[c], d[c], sn);
+  // dV1 += d'Qu ; dV2 += 0.5 d'Quu d = -0.5 (d'Qu + rho d'd)   (riccati_chunk, step 4)
+  const double dqu = dot3_(d[0], qu[0], d[1], qu[1], d[2], qu[2]);
+  dV1 += (acc_t)dqu;
+  dV2 -= (acc_t)(0.5 * fma_(rho, dot3_(d[0], d[0], d[1], d[1], d[2], d[2]), dqu));
+  for (int r = 0; r < NH; ++r) st.Sc[r] = Q[r];
+  st.Sc[NH] = sn;
+  return pd;
+}
+
+// The recursion over one chunk whose records are in LDS at L_REC (one-trajectory builds; last knot first). S~ comes from and
+// goes back to L_ST (row stride 9) between chunks: jacobian_chunk, a function of its own, runs in between.
+template <typename real, int NH, typename R>
+TSAT_PHASE BwdOut<real> riccati_rows(TSAT_GLOBAL real* KDg, int k0_, int nk_, real rho_, acc_t dV1, acc_t dV2) {
+  // (arguments of a non-inlined function arrive in VGPRs: the chunk bounds are said to be wave-uniform, the loop below is scalar)
+  const int k0 = TSAT_UNIFORM_INT(k0_), nk = TSAT_UNIFORM_INT(nk_);
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE(), j = lane & 15;
+  RowRoles<NH, R> ro;
+  ro.template set<real>(j, lds + L_TR + P_QD);
+  const double rho = (double)rho_;
+  double* S64 = st64();
+  RowState<NH> st;
+  const int js = (j < NH) ? j : 0;
+  for (int r = 0; r <= NH; ++r) st.Sc[r] = S64[r * 9 + js];
+  // K,d record of a knot: lanes 0 .. 6 store their gain column (zero beyond NH), lane 7 the feed-forward — as Kc km + d dm with
+  // per-lane 0 / 1 factors instead of selects; the stores stay in flight (no vmcnt wait in this loop)
+  const double km = (lane < NH) ? 1.0 : 0.0, dm = (lane == 7) ? 1.0 : 0.0;
+  int slot[3];
+  for (int c = 0; c < 3; ++c) slot[c] = (lane < 7) ? (c * 7 + lane) : (21 + c);
+  bool pd_ok = true;
+  // One knot: the recursion step on the record read a knot ago, then its K,d record to HBM. Returns the Sylvester test.
+  auto knot = [&](const RowIn<NH>& in, int l) {
+    double Kc[3], d[3];
+    const bool pd = riccati_row_step<NH, R>(st, in, ro, rho, Kc, d, dV1, dV2);
+    if (lane < 8) {
+      TSAT_GLOBAL real* kd = KDg + (size_t)(k0 + l) * KDW;
+      for (int c = 0; c < 3; ++c) kd[slot[c]] = (real)fma_(Kc[c], km, d[c] * dm);
+    }
+    return TSAT_UNIFORM_INT(pd) != 0;      // wave-uniform: the four rows hold the same trajectory
+  };
+  // The record of knot l - 1 is read while knot l is worked on (one wavefront per SIMD has nobody to hide an LDS latency behind);
+  // two knots per turn, two register sets A / B taking turns (a single set would have to be copied every knot).
+  auto rec = [&](int l) { return lds + L_REC + ((l > 0) ? l : 0) * R::RECS; };
+  RowIn<NH> A = row_load<real, NH, R>(rec(nk - 1), ro);
+  for (int l = nk - 1; l >= 0; l -= 2) {
+    const RowIn<NH> B = row_load<real, NH, R>(rec(l - 1), ro);
+    TSAT_SCHED_FENCE();
+    if (!knot(A, l)) { pd_ok = false; break; }
+    if (l - 1 >= 0) {
+      A = row_load<real, NH, R>(rec(l - 2), ro);
+      TSAT_SCHED_FENCE();
+      if (!knot(B, l - 1)) { pd_ok = false; break; }
+    }
+  }
+  TSAT_SYNC_LDS();
+  if (lane < NH)
+    for (int r = 0; r <= NH; ++r) S64[r * 9 + lane] = st.Sc[r];
+  BwdOut<real> out;
+  out.dV1 = dV1; out.dV2 = dV2; out.pd_ok = pd_ok ? 1 : 0;
+  return out;
+}
+
 // terminal cost-to-go into the Riccati scratch S~ (L_ST, row stride 9; row NH = s'): reads the staged trajectory constants
 // (L_TR) and terminal multipliers (L_NU)
 template <typename real, int ES>
@@ -1514,7 +1739,8 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
     jacobian_chunk<real, INTEG, DIAGJ, ES>(p, N, n_tab, k0, nk, mu);
     TSAT_SYNC();
     const unsigned long long t_j1 = tick_();
-    acc = riccati_chunk<real, BwdCfg<ES>::NH, PkRec<ES>>(p.KD, k0, nk, rho, acc.dV1, acc.dV2);
+    if constexpr (sizeof(real) == 8) acc = riccati_rows<real, BwdCfg<ES>::NH, PkRec<ES>>(p.KD, k0, nk, rho, acc.dV1, acc.dV2);
+    else acc = riccati_chunk<real, BwdCfg<ES>::NH, PkRec<ES>>(p.KD, k0, nk, rho, acc.dV1, acc.dV2);
     TSAT_SYNC();
 #ifdef TSAT_PROFILE
     if (lane == 0) {

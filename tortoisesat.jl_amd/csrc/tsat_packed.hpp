@@ -655,6 +655,81 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
   return out;
 }
 
+// The same recursion ROW-oriented (riccati_row_step, tsat_device.hpp): the trajectory's 16 lanes are a DPP row, lane j owns column j
+// of F and of S~, and every value another lane holds is read as the `row_newbcast` operand of the FMA that consumes it — no exchange
+// block, no barrier and no re-read of S~ between the steps of a knot; the four trajectories of the pass run the same instructions
+// side by side (a row whose trajectory does not take part in a knot is switched off as a whole). The one-trajectory builds run
+// the very same step function: bit-identical results. S~ lives in the registers of the row across the 16 knots of a pass and in
+// the trajectory's exchange block (as doubles, [r][8]) between passes. The record ring is that of riccati_group.
+template <typename real, int NH>
+TSAT_PHASE GBwd<real> riccati_group_rows(const KArgs<real>& a, int traj0, const TSAT_GLOBAL real* jw, int kb0, bool need, int N, real rho_,
+                                         acc_t dV1, acc_t dV2, int ok_in) {
+  constexpr int ES = (NH == 6) ? 1 : 0;
+  real* lds = lds_base<real>();
+  const int lane = TSAT_LANE(), g = lane / PK_BC, j = lane % PK_BC;
+  using R = PkRec<ES>;
+  static_assert(sizeof(real) == 8, "the exchange block holds S~ as doubles");
+  double* gs = reinterpret_cast<double*>(lds + L_GX + g * PK_GXW);
+  static_assert((NH + 1) * 8 <= PK_GXW, "S~ fits the exchange block");
+  RowRoles<NH, R> ro;
+  ro.template set<real>(j, lds + L_GTR + g * PK_GTRW + P_QD);
+  const real* recs = lds + L_GREC + g * R::RECS;                   // this trajectory's record inside a ring slot
+  constexpr int UPR = R::RECS / RPU, UPS = R::SLOT / RPU, NCI = (UPS + WAVE - 1) / WAVE;
+  const TSAT_GLOBAL real* cp_src[NCI];
+  bool cp_on[NCI];
+  for (int i = 0; i < NCI; ++i) {
+    const int v = lane + WAVE * i;
+    cp_on[i] = v < UPS;
+    const int vg = cp_on[i] ? v / UPR : 0, ve = cp_on[i] ? v - vg * UPR : 0;
+    cp_src[i] = jw + (size_t)vg * PK_JCH * R::RECS + (size_t)ve * RPU;
+  }
+  auto ring_copy = [&](int q) {
+    real* slot = lds + L_GREC + (q & (PK_RING - 1)) * R::SLOT;
+    for (int i = 0; i < NCI; ++i)
+      if (cp_on[i]) glds_put_at<real>(slot + GLDS * i, cp_src[i] + (size_t)q * R::RECS);
+  };
+  const int tmax = a.T - 1;
+  const int traj = (traj0 + g <= tmax) ? traj0 + g : tmax;
+  TSAT_GLOBAL real* KDg = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * kd_stride<real>(a.N));
+  const double rho = (double)rho_;
+  const double km = (j < NH) ? 1.0 : 0.0, dm = (j == 7) ? 1.0 : 0.0;
+  int slot_[3];
+  for (int c = 0; c < 3; ++c) slot_[c] = (j < 7) ? (c * 7 + j) : (21 + c);
+  bool ok = ok_in != 0;
+  RowState<NH> st;
+  const int js = (j < NH) ? j : 0;
+  for (int r = 0; r <= NH; ++r) st.Sc[r] = gs[r * 8 + js];
+  for (int l = PK_JCH - 1; l >= 0; --l) {
+    const int k = kb0 + l;
+    const bool act = need && ok && k < N - 1;
+    if (l >= PK_RING - 1 && l < PK_JCH - 1) ring_copy(l - (PK_RING - 1));
+    ring_wait<NCI>(l);
+    const real* rc = recs + (l & (PK_RING - 1)) * R::SLOT;
+    double Kc[3], d[3];
+#ifdef TSAT_EMU
+    // every emulated lane takes part in the exchanges of the step; a row that does not take part keeps its state
+    RowState<NH> st2 = st;
+    acc_t v1 = dV1, v2 = dV2;
+    const bool pd = riccati_row_step<NH, R>(st2, row_load<real, NH, R>(rc, ro), ro, rho, Kc, d, v1, v2);
+    if (act) { st = st2; dV1 = v1; dV2 = v2; }
+#else
+    bool pd = true;
+    if (act) pd = riccati_row_step<NH, R>(st, row_load<real, NH, R>(rc, ro), ro, rho, Kc, d, dV1, dV2);
+#endif
+    if (act && j < 8) {      // K,d record of the knot: lanes 0..6 their gain column (zero beyond NH), lane 7 the feed-forward; stays in flight
+      TSAT_GLOBAL real* kd = KDg + (size_t)k * KDW;
+      for (int c = 0; c < 3; ++c) kd[slot_[c]] = (real)fma_(Kc[c], km, d[c] * dm);
+    }
+    ok = ok && (!act || pd);
+  }
+  TSAT_SYNC_LDS();
+  if (j < NH)
+    for (int r = 0; r <= NH; ++r) gs[r * 8 + j] = st.Sc[r];
+  GBwd<real> out;
+  out.dV1 = dV1; out.dV2 = dV2; out.ok = ok ? 1 : 0;
+  return out;
+}
+
 // The rest of ONE trajectory's solve in the one-trajectory mapping (solve_trajectory, tsat_device.hpp, in the layout of the dense
 // build: this translation unit's LDS block holds it), from the top of an inner iteration on. A wavefront whose other trajectories
 // have finished runs its last one this way: a joint iteration costs the same whether four trajectories of the wave are live or
@@ -858,10 +933,16 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
             terminal_cost_to_go<real, ES>(XUg, u.N, u.mu, tmask);
             TSAT_SYNC_LDS();
             real* gx = lds + L_GX + g * PK_GXW;
-            for (int e = lane; e < NP + NH; e += WAVE) {
-              int i = NH, j = e - NP;
-              if (e < NP) pair_ut(e, NH, i, j);
-              gx[GX_S + e] = lds[L_ST + i * 9 + j];
+            if constexpr (sizeof(real) == 8) {          // row-oriented recursion: S~ as doubles, [r][8]
+              double* gs = reinterpret_cast<double*>(gx);
+              for (int e = lane; e < (NH + 1) * 8; e += WAVE)
+                if ((e & 7) < NH) gs[e] = (double)lds[L_ST + (e >> 3) * 9 + (e & 7)];
+            } else {
+              for (int e = lane; e < NP + NH; e += WAVE) {
+                int i = NH, j = e - NP;
+                if (e < NP) pair_ut(e, NH, i, j);
+                gx[GX_S + e] = lds[L_ST + i * 9 + j];
+              }
             }
             TSAT_SYNC_LDS();
           }
@@ -874,7 +955,8 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
             jacobian16<real, INTEG, DIAGJ, ES>(a, traj0 + t0, jw, kb0, bneed && bw.ok, in.N, in.mu, in.cur);
             TSAT_SYNC();         // the records are in the workspace (vmcnt(0)) before the ring copies read them
             const unsigned long long c1 = tick_();
-            bw = riccati_group<real, NH>(a, traj0 + t0, jw, kb0, bneed, in.N, in.rho, bw.dV1, bw.dV2, bw.ok);
+            if constexpr (sizeof(real) == 8) bw = riccati_group_rows<real, NH>(a, traj0 + t0, jw, kb0, bneed, in.N, in.rho, bw.dV1, bw.dV2, bw.ok);
+            else bw = riccati_group<real, NH>(a, traj0 + t0, jw, kb0, bneed, in.N, in.rho, bw.dV1, bw.dV2, bw.ok);
             TSAT_SYNC();         // every copy has landed and every record has been consumed before the next pass overwrites them
             pc_jac += c1 - c0; pc_ric += tick_() - c1;
           }
