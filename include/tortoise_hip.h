@@ -55,8 +55,10 @@ typedef struct tsat_options {
   int32_t n_knots;          /* N, knot points incl. terminal (src/TortoiseSat.jl:85)                */
   int32_t n_tab;            /* rows in each B table                                                 */
   int32_t integrator;       /* 3 = rk3 (src/TortoiseSat.jl:146), 4 = rk4 (src/attitude_controller.jl:122) */
-  int32_t precision;        /* 64 (fp64) or 32: float storage and arithmetic of the solve, costs / line search in  */
-                            /* double (BASELINE.json configs[2]); tsat_mpc_run takes 64 only               */
+  int32_t precision;        /* 64 (fp64) or 32 (mixed precision, BASELINE.json configs[2]): float LINEARISATION — the   */
+                            /* Jacobian lanes and the knot records they leave for the Riccati recursion — while the      */
+                            /* roll-out, the costs, the recursion, the gains and every array in HBM stay double, so the   */
+                            /* line-search decisions follow the fp64 path; tsat_mpc_run takes 64 only                     */
   int32_t max_outer;        /* opts_al.iterations            (src/TortoiseSat.jl:196; 20)           */
   int32_t max_inner;        /* opts_al.opts_uncon.iterations (src/TortoiseSat.jl:195; 50)           */
   int32_t max_linesearch;   /* backtracking trials alpha = 2^-j, j < max_linesearch (<= 32)         */
@@ -250,12 +252,11 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
  *   2 dense   one trajectory per wavefront, two wavefronts per SIMD (20 KB, 256 registers): 1025 .. 3071;
  *   3 packed  four trajectories per wavefront share every forward sweep (16 line-search candidates each) and run their
  *             backward sweeps together (Jacobian lanes = trajectory x knot x column quarter, Riccati recursion on 16 lanes per
- *             trajectory), two wavefronts per SIMD: from 3072 trajectories; with precision = 32 the float build of the same
- *             (from 3072);
- *   4 packed8 the same with eight trajectories per wavefront (eight candidates each, two backward passes): from 16384;
- *   12 | 13 | 14  precision = 32 only: the one-trajectory float build laid out for 2 | 3 | 4 wavefronts per SIMD.
- * The fp64 builds give bit-identical results (X, U, K, iteration counts; `n_forward` counts the sweeps a build executed and
- * differs). The switch exists for tuning and for the tests. */
+ *             trajectory), two wavefronts per SIMD: from 3072 trajectories;
+ *   4 packed8 the same with eight trajectories per wavefront (eight candidates each, two backward passes): from 16384.
+ * precision = 32 has the dense, packed and packed8 layouts (below 3072 trajectories the dense one, whatever `variant` says).
+ * The builds of one precision give bit-identical results (X, U, K, iteration counts; `n_forward` counts the sweeps a build
+ * executed and differs). The switch exists for tuning and for the tests. */
 int  tsat_set_kernel_variant(tsat_handle* h, int32_t variant);
 
 /* Endgame of the packed builds (variants 3 and 4). The trajectories of one launch need different numbers of iterations (21 .. 150

@@ -76,7 +76,7 @@ function default_options()
     return o
 end
 
-"set_kernel_variant!(s, v) — 0 automatic by batch size; 1 wide, 2 dense, 3 packed, 4 packed8 (fp64 results do not depend on it); 12-14 fp32 layouts"
+"set_kernel_variant!(s, v) — 0 automatic by batch size; 1 wide, 2 dense, 3 packed, 4 packed8 (results do not depend on it)"
 set_kernel_variant!(s::HIPSolver, v::Integer) =
     check(s, ccall((:tsat_set_kernel_variant, LIB), Cint, (Ptr{Cvoid}, Int32), s.handle, v), "tsat_set_kernel_variant")
 

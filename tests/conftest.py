@@ -141,9 +141,9 @@ def emu_packed(pkg):
 
 
 @pytest.fixture(scope="session")
-def emu_f32(pkg):
-    """the fp32 build of the solve kernel (options.precision = 32): float storage and arithmetic, double costs, -DTSAT_F32"""
-    return Emu(pkg._abi, "libtsat_emu_f32.so")
+def emu_mixed(pkg):
+    """the mixed-precision build of the solve kernel (options.precision = 32): float linearisation, everything else double, -DTSAT_JAC32"""
+    return Emu(pkg._abi, "libtsat_emu_mixed.so")
 
 
 @pytest.fixture(scope="session")
@@ -153,9 +153,9 @@ def emu_packed8(pkg):
 
 
 @pytest.fixture(scope="session")
-def emu_packed_f32(pkg):
-    """the fp32 packed build (tsat_kernels_packed_f32.hip)"""
-    return Emu(pkg._abi, "libtsat_emu_packed_f32.so")
+def emu_packed_mixed(pkg):
+    """the mixed-precision packed build (tsat_kernels_packed_mixed.hip)"""
+    return Emu(pkg._abi, "libtsat_emu_packed_mixed.so")
 
 
 def oracle_options(ol, **kw):

@@ -156,7 +156,7 @@ void for_each_wave(int n, F&& fn) {
 
 using namespace tsat;
 
-using R = tsat::cfg_real;   // storage type of this build of the solve kernel: double, or float with -DTSAT_F32
+using R = tsat::cfg_real;   // storage type of the solve kernel's arrays (double in every build)
 
 template <int INTEG, int DIAGJ, int ES>
 static void run_block(const KArgs<R>& a, int traj) {
@@ -241,7 +241,7 @@ extern "C" int emu_solve_batch(const tsat_options* o, int64_t T, int64_t n_btab,
   return 0;
 }
 
-#if !defined(TSAT_DENSE) && !defined(TSAT_F32)   // the dense build exists for the solve kernel only (tortoisesat.jl_amd/csrc/tsat_kernels_dense.hip)
+#if !defined(TSAT_DENSE)   // the dense build exists for the solve kernel only (tortoisesat.jl_amd/csrc/tsat_kernels_dense.hip)
 template <int DIAGJ>
 static void run_mpc_block(const MpcArgs<double>& a, int traj) {
   tsat_emu::run_wave((size_t)LDS_REALS * 8, [&]() { mpc_advance_trajectory<double, DIAGJ>(a, traj); });

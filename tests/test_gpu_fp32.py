@@ -1,23 +1,21 @@
-"""GPU tier: the fp32 build of the solve kernel (options.precision = 32; BASELINE.json configs[2] is quoted as "fp32").
+"""GPU tier: the mixed-precision builds of the solve kernel (options.precision = 32; BASELINE.json configs[2] is quoted as "fp32").
 
-The solve is budget-limited (5 x 10 iterations, src/monte_carlo.jl:189-191): it stops on the way to the optimum, and where it
-stops depends on every accept / reject decision of the line search on the way. Costs are carried in double in the fp32 build,
-but the rolled-out states are float, so roughly nine in ten trajectories take at least one decision differently from the fp64
-oracle and end at a different point of the SAME descent. The bar is therefore stated in two parts, both asserted here:
+What is float: the LINEARISATION — the Jacobian lanes (nine tangent passes per knot: the bulk of the flops) and the knot records
+they leave for the Riccati recursion (72 | 84 values per knot and iteration: the bulk of the on-chip and workspace bytes). What
+stays double: the roll-out state and the feedback u = u_nom + K dx + alpha d, every cost, the cost-to-go recursion and the gains,
+the multipliers, the field tables, every array in HBM (fp64 accumulation). A float error in [A|B] perturbs
+the search direction by ~1e-7 relative; the decisions a budget-limited solve takes on its way — accept / reject in the line
+search, the convergence tests — are taken on double quantities and follow the fp64 path. (Round 3's all-float build took another
+decision than the oracle somewhere on 86 % of the trajectories and ended up to 0.57 away from it.)
 
-  * on the trajectories that follow the oracle's iteration PATH — the same accepted line-search index in every iteration, read
-    from the per-iteration traces of both (about one in eight) — |dX| < 1e-3 on >= 95 % of them (fp32 bar 1e-3;
-    q90 ~ 1e-4) and |dX| < 1e-2, |dU| < 2e-2 of the control scale on EVERY one (worst seen 3e-3 / 6e-3: the same decisions, float
-    rounding amplified over 50 iterations). Equal iteration and line-search COUNTS are not the same thing: two solves can take index 1 at
-    iteration 3 and 0 at iteration 7 or the other way round; round 2 used the counts and reported such a trajectory (0.22 away
-    from the oracle) as a same-path outlier — tools/fp32_paths.py shows where its path leaves the oracle's;
-  * every float build gives the same bits: they contract a*b + c only where the source writes it in one expression
-    (`#pragma clang fp contract(on)` in the float translation units), so the packed builds are the one-trajectory float solve;
-  * on all trajectories: status agreement >= 99 % (§8(d)), |dX| < 1e-3 on >= 85 %, median |dU| / scale < 1e-3, the
-    achieved cost within 1e-4 relative on >= 90 %, and no loss of solution quality in the mean (cost and constraint
-    violation within 1 % / 5 % of the oracle's batch means).
-
-Short solves, where no decision is close, agree outright (first test, and tests/test_emu_packed_f32.py on the CPU).
+Asserted here against the fp64 oracle ("fp32: 1e-3 + status agreement >= 99 %"):
+  * short solves: the oracle's statuses and iteration / line-search counts, |dX| < 1e-5, |dU| < 1e-3 of the control scale;
+  * configs[2] inputs, 1000 knots, the reference's 5 x 10 budget (a budget-limited solve: where it stops depends on every decision
+    on the way): status agreement >= 99 %; the oracle's iteration PATH (same accepted line-search index in every iteration) on
+    >= 90 % of the trajectories (measured 97 %), and on those |dX| < 1e-3 and |dU| / scale < 1e-3 (>= 99.5 %); overall >= 97 %
+    inside both (the few that leave the path end at another point of the same descent);
+  * the same inputs with a budget that is not the limiter (20 x 50): the mixed solve converges to the fp64 optimum — same bars;
+  * dense, packed and packed8 mixed builds give the same bits.
 """
 import numpy as np
 import pytest
@@ -65,58 +63,81 @@ def _errors(ref, got):
     return dX, dU
 
 
-@pytest.mark.parametrize("variant", [12, 13, 14, 3, 4])
-def test_gpu_fp32_short_solves_agree_outright(pkg, ol, solver, variant):
-    """the three LDS layouts of the fp32 build (2 / 3 / 4 wavefronts per SIMD) and the fp32 packed builds (variants 3 / 4: four / eight
-    trajectories per wavefront, taken automatically from 3072 / 16384 trajectories on) on short solves: oracle's statuses and counts"""
+def _same_bits(a, b, what):
+    assert np.array_equal(a["X"], b["X"]) and np.array_equal(a["U"], b["U"]), what
+    for f in ("status", "outer_iters", "inner_iters", "ls_trials", "n_backward", "bp_restarts", "fp_fails", "cost", "c_max"):
+        assert np.array_equal(a["stats"][f], b["stats"][f]), (what, f)
+
+
+@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("es", [0, 1])
+def test_gpu_mixed_short_solves_agree_outright(pkg, ol, solver, variant, es):
+    """the dense, packed and packed8 mixed builds (taken automatically below 3072 / from 3072 / from 16384 trajectories) on short
+    solves: the oracle's statuses and counts, |dX| < 1e-5, |dU| < 1e-3 of the control scale"""
     b = pkg.slew_setup.workload_monte_carlo(T=16, N=120, seed=31)
-    o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1, error_state=1)
+    o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1, error_state=es)
     ref, got = ol.solve_batch(b, o, nthreads=8), _run32(pkg, solver, b, o, variant)
-    assert np.array_equal(ref["stats"]["status"], got["stats"]["status"])
-    assert np.array_equal(ref["stats"]["inner_iters"], got["stats"]["inner_iters"])
+    for f in ("status", "inner_iters", "ls_trials"):
+        assert np.array_equal(ref["stats"][f], got["stats"][f]), f
     dX, dU = _errors(ref, got)
-    assert dX.max() < 1e-3 and dU.max() < 1e-3, (dX.max(), dU.max())
-    np.testing.assert_allclose(got["stats"]["cost"], ref["stats"]["cost"], rtol=1e-4)
+    assert dX.max() < 1e-5 and dU.max() < 1e-3, (dX.max(), dU.max())
+    np.testing.assert_allclose(got["stats"]["cost"], ref["stats"]["cost"], rtol=1e-6)
 
 
-def test_gpu_fp32_configs2_inputs_1000_knots(pkg, ol, solver):
-    """configs[2] inputs (random q0 and orbit per trajectory, IGRF-12 tables, quaternion hooks), 1000 knots, 5 x 10 budget"""
+def _report(tag, ref, got):
+    rs, gs = ref["stats"], got["stats"]
+    dX, dU = _errors(ref, got)
+    same = np.all(_paths(ref["trace"]) == _paths(got["trace"]), axis=1) if "trace" in got and "trace" in ref else None
+    rel_cost = np.abs(gs["cost"] / rs["cost"] - 1)
+    out = dict(status=float(np.mean(rs["status"] == gs["status"])), dx_ok=float(np.mean(dX < 1e-3)), du_ok=float(np.mean(dU < 1e-3)),
+               same=float(same.mean()) if same is not None else float("nan"),
+               same_ok=float(np.mean((dX[same] < 1e-3) & (dU[same] < 1e-3))) if same is not None and same.any() else float("nan"),
+               counts=float(np.mean((rs["inner_iters"] == gs["inner_iters"]) & (rs["ls_trials"] == gs["ls_trials"]))))
+    print(f"[mixed {tag}] status agreement {out['status']:.4f}; |dX|<1e-3 on {out['dx_ok']:.4f} (max {dX.max():.2e}, q99 {np.quantile(dX, 0.99):.2e}); "
+          f"|dU|/scale<1e-3 on {out['du_ok']:.4f} (max {dU.max():.2e}, q99 {np.quantile(dU, 0.99):.2e}); same path {out['same']:.4f} (of those inside both bars: {out['same_ok']:.4f}); "
+          f"equal iteration and line-search counts {out['counts']:.4f}; cost within 1e-6 relative on {np.mean(rel_cost < 1e-6):.4f}, worst {rel_cost.max():.2e}")
+    return out
+
+
+def test_gpu_mixed_configs2_inputs_1000_knots(pkg, ol, solver):
+    """configs[2] inputs (random q0 and orbit per trajectory, IGRF-12 tables, quaternion hooks), 1000 knots, the reference's
+    5 x 10 budget (src/monte_carlo.jl:189-191): a budget-limited solve, where the result depends on every decision on the way"""
     T = 512
     b = pkg.magnetic.attach_igrf_tables(solver, pkg.slew_setup.workload_monte_carlo(T=T, N=1000, seed=20190531, random_orbit=True, tables=False))
     o = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, error_state=1)
     ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False, trace_rows=TRACE_ROWS)
-    layouts = {}
-    for variant in (12, 14, 3, 4):
-        got = layouts[variant] = _run32(pkg, solver, b, o, variant, trace=True)
-        rs, gs = ref["stats"], got["stats"]
-        dX, dU = _errors(ref, got)
-        same = np.all(_paths(ref["trace"]) == _paths(got["trace"]), axis=1)          # the oracle's iteration path, step for step
-        rel_cost = np.abs(gs["cost"] / rs["cost"] - 1)
-        print(f"[fp32 layout {variant}] same path {same.mean():.3f}; status agreement {np.mean(rs['status'] == gs['status']):.3f}; "
-              f"|dX|<1e-3 {np.mean(dX < 1e-3):.3f}; median |dU|/scale {np.median(dU):.2e}; same-path q90/max |dX| "
-              f"{np.quantile(dX[same], 0.9) if same.any() else 0:.2e}/{dX[same].max() if same.any() else 0:.2e}, median |dU|/scale {np.median(dU[same]) if same.any() else 0:.2e}; cost within 1e-4 "
-              f"{np.mean(rel_cost < 1e-4):.3f}; mean cost {gs['cost'].mean():.6g} vs {rs['cost'].mean():.6g}; mean c_max "
-              f"{gs['c_max'].mean():.4g} vs {rs['c_max'].mean():.4g}")
+    builds = {}
+    for variant in (2, 3, 4):
+        got = builds[variant] = _run32(pkg, solver, b, o, variant, trace=True)
         assert np.all(np.isfinite(got["X"])) and np.all(np.isfinite(got["U"]))
-        assert np.mean(rs["status"] == gs["status"]) >= 0.99
-        # same-path trajectories: the fp32 bar 1e-3 on >= 95 % of them (q90 ~ 1e-4), and no outlier: every one within 1e-2 on the
-        # states and 2e-2 of the control scale (float rounding amplified over 50 iterations: the worst seen 3e-3 / 6e-3)
-        assert same.sum() >= 8 and np.mean(dX[same] < 1e-3) >= 0.95 and dX[same].max() < 1e-2 and dU[same].max() < 2e-2
-        assert np.mean(dX < 1e-3) >= 0.85 and np.median(dU) < 1e-3
-        assert np.mean(rel_cost < 1e-4) >= 0.90
-        assert abs(gs["cost"].mean() / rs["cost"].mean() - 1) < 0.01
-        assert gs["c_max"].mean() < 1.05 * rs["c_max"].mean() + 1e-6
-        qn = np.linalg.norm(got["X"][:, :, 3:7], axis=2)                 # the states are still attitudes
-        assert np.max(np.abs(qn - 1)) < 1e-2
-    # one fp32 solve, whatever the build: LDS layouts, four or eight trajectories per wavefront — same arithmetic, same bits
-    for variant in (14, 3, 4):
-        assert np.array_equal(layouts[12]["X"], layouts[variant]["X"]) and np.array_equal(layouts[12]["U"], layouts[variant]["U"]), variant
-        for f in ("status", "outer_iters", "inner_iters", "ls_trials", "n_backward", "bp_restarts", "fp_fails", "cost", "c_max"):
-            assert np.array_equal(layouts[12]["stats"][f], layouts[variant]["stats"][f]), (variant, f)
+    r = _report("configs[2] inputs, 5 x 10", ref, builds[2])
+    # measured: statuses 100 %, the oracle's path on 97 % (all-float build of round 3: 14 %), 98.6 % / 98.0 % inside 1e-3 on X / U.
+    # A budget-limited solve that takes ONE decision differently ends at another point of the descent (up to 0.4 away): the bar of
+    # SURVEY.md §8(d) is asserted on the statuses and on the trajectories that follow the oracle's path; overall >= 97 %
+    assert r["status"] >= 0.99
+    assert r["same"] >= 0.90 and r["same_ok"] >= 0.995
+    assert r["dx_ok"] >= 0.97 and r["du_ok"] >= 0.97
+    for variant in (3, 4):      # one mixed solve, whatever the build
+        _same_bits(builds[2], builds[variant], variant)
+
+
+def test_gpu_fp32_converges_to_the_fp64_optimum(pkg, ol, solver):
+    """the same inputs with an iteration budget that is not the limiter (20 x 50, the single slew's of src/TortoiseSat.jl:195-196;
+    options of src/monte_carlo.jl:186-196 otherwise): both solves run until a convergence test stops them, and the mixed one ends
+    at the fp64 optimum — statuses >= 99 %, |dX| < 1e-3 and |dU| / scale < 1e-3 on >= 99 % of the trajectories"""
+    T = 256
+    b = pkg.magnetic.attach_igrf_tables(solver, pkg.slew_setup.workload_monte_carlo(T=T, N=1000, seed=20190532, random_orbit=True, tables=False))
+    o = oracle_options(ol, max_outer=20, max_inner=50, dj_counter_limit=1, error_state=1)
+    ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False)
+    got = _run32(pkg, solver, b, o, 0)
+    r = _report("configs[2] inputs, 20 x 50", ref, got)
+    print(f"[mixed 20 x 50] converged: oracle {np.mean(ref['stats']['status'] == 0):.3f}, mixed {np.mean(got['stats']['status'] == 0):.3f}; "
+          f"mean inner iterations {ref['stats']['inner_iters'].mean():.1f} vs {got['stats']['inner_iters'].mean():.1f}")
+    assert r["status"] >= 0.99 and r["dx_ok"] >= 0.99 and r["du_ok"] >= 0.99
 
 
 def test_gpu_fp32_then_fp64_on_the_same_upload(pkg, ol, solver):
-    """the two precisions share the resident batch: an fp64 run after an fp32 run is the plain fp64 result"""
+    """the two precisions share the resident batch: an fp64 run after a precision = 32 run is the plain fp64 result"""
     from conftest import assert_same_solution
     import helpers
     b = pkg.slew_setup.workload_monte_carlo(T=8, N=90, seed=5)

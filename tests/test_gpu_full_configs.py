@@ -208,20 +208,33 @@ def test_gpu_configs4_shard(pkg, ol):
         assert np.array_equal(ref["stats"][k], got["stats"][k][idx]), k
 
 
+def take(b, idx):
+    """the trajectories `idx` of a batch as a batch of their own (tables taken along and re-indexed)"""
+    import copy
+    idx = np.asarray(idx)
+    sb = b.slice(0, 1)
+    for f_ in ("x0", "xf", "tau0", "dtau", "dt", "Jmat", "Qd", "Qfd", "Rd", "ulo", "uhi", "U0"):
+        setattr(sb, f_, np.ascontiguousarray(getattr(b, f_)[idx]))
+    sb.Btab = np.ascontiguousarray(b.Btab[b.btab_idx[idx]])
+    sb.btab_idx = np.arange(len(idx), dtype=np.int32)
+    if b.n_knots is not None:
+        sb.n_knots = np.ascontiguousarray(b.n_knots[idx])
+    return sb
+
+
 def test_gpu_large_batch_runs_are_repeatable(pkg, ol):
-    """16384 x 1000 knots (configs[2] shape) three times per build: identical results run to run. The machine is under full
-    memory load here, which is where an unsafe s_waitcnt count shows (the forward chunk wait of the packed builds once did:
-    loads and stores do not retire in order relative to each other) — small batches never saw it. Both precisions are also held
-    to the oracle at this size: fp64 directly on a sub-sample spread over the launch, fp32 through the one-trajectory float build
-    (whose bits the 16384-trajectory launch must reproduce, copy by copy of the tiled batch) and the status statistic on it."""
-    ss, to = pkg.slew_setup, pkg.trajopt
-    base = ss.workload_monte_carlo(T=1024, N=1000, seed=20190531, random_orbit=True)
-    rep = lambda a: np.ascontiguousarray(np.concatenate([a] * 16))
-    b = ss.SlewBatch(base.N, base.n_tab, rep(base.x0), rep(base.xf), base.Btab, rep(base.btab_idx), rep(base.tau0), rep(base.dtau),
-                     rep(base.dt), rep(base.Jmat), rep(base.Qd), rep(base.Qfd), rep(base.Rd), rep(base.ulo), rep(base.uhi), rep(base.U0))
+    """16384 DISTINCT trajectories x 1000 knots — BASELINE.json configs[2] as `bench.py --config 2` times it: random q0, random
+    orbit and IGRF-12 table per trajectory — three times per build and precision: identical results run to run. The machine is
+    under full memory load here, which is where an unsafe s_waitcnt count shows (the forward chunk wait of the packed builds once
+    did: loads and stores do not retire in order relative to each other) — small batches never saw it; and with 16384 different
+    slews the wavefronts diverge in their iteration counts as they do in the bench run. Both precisions are also held to the
+    oracle at this size: fp64 on a sub-sample of 48 spread over the launch; precision = 32 (mixed) through the one-trajectory
+    mixed build on a 1024-trajectory sub-range (same bits) and, on the sub-sample, SURVEY.md §8(d)'s bar against the oracle."""
+    ss, to, mg = pkg.slew_setup, pkg.trajopt, pkg.magnetic
     opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = 5
     opts.opts_uncon.iterations = 10; opts.opts_uncon.dJ_counter_limit = 1
     s = to.AugmentedLagrangianSolver(None, opts)
+    b = mg.attach_igrf_tables(s, ss.workload_monte_carlo(T=16384, N=1000, seed=20190531, random_orbit=True, tables=False))
     o = opts.to_abi(b.N, b.n_tab, 3, error_state=1)
     s.upload(b, o.max_linesearch)
     last = {}
@@ -239,35 +252,35 @@ def test_gpu_large_batch_runs_are_repeatable(pkg, ol):
             assert all(np.array_equal(st[f_], runs[0][0][f_]) for f_ in st.dtype.names if f_ != "n_forward"), (prec, variant)
             assert np.array_equal(X, runs[0][1]) and np.array_equal(U, runs[0][2]), (prec, variant)
         assert not np.any(runs[0][0]["status"] == pkg._abi.TSAT_DIVERGED)
-        if prec == 64:      # the tiled batch repeats its 1024 trajectories 16 times: all copies solve alike, whatever wave they sit in
-            assert np.array_equal(runs[0][0]["inner_iters"][:1024], runs[0][0]["inner_iters"][1024:2048])
+        if prec in last:      # packed and packed8 are the same solve
+            assert np.array_equal(last[prec]["X"], r["X"]) and np.array_equal(last[prec]["stats"]["inner_iters"], r["stats"]["inner_iters"]), (prec, variant)
         last[prec] = r
-    s.set_kernel_variant(0)
-    # oracle sub-sample: 48 base trajectories, each taken from another copy of the tiled batch
-    sel = np.arange(5, 1024, 1024 // 48)[:48]
-    pos = sel + 1024 * (np.arange(len(sel)) % 16)
-    sb = base.slice(0, 1)
-    for f_ in ("x0", "xf", "btab_idx", "tau0", "dtau", "dt", "Jmat", "Qd", "Qfd", "Rd", "ulo", "uhi", "U0"):
-        setattr(sb, f_, np.ascontiguousarray(getattr(base, f_)[sel]))
+    it = last[64]["stats"]["inner_iters"]
+    print(f"[configs[2] 16384 distinct trajectories] inner iterations min / mean / max {it.min()} / {it.mean():.1f} / {it.max()}")
+    # oracle sub-sample: 48 trajectories spread over the launch
+    sel = np.arange(113, 16384, 16384 // 48)[:48]
+    sb = take(b, sel)
     oo = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, error_state=1)
     ref = ol.solve_batch(sb, oo, nthreads=ol.num_procs(), want_K=False)
-    got = dict(X=last[64]["X"][pos], U=last[64]["U"][pos], stats=last[64]["stats"][pos])
-    _report("configs[2] shape 16384 x 1000 fp64 (packed), oracle sub-sample of 48", ref, got)
+    got = dict(X=last[64]["X"][sel], U=last[64]["U"][sel], stats=last[64]["stats"][sel])
+    _report("configs[2] 16384 x 1000 fp64 (packed builds), oracle sub-sample of 48", ref, got)
     assert_same_solution(ref, got)
-    # fp32: the large-batch launch is the one-trajectory float solve of the base batch, bit for bit, in every copy
+    # precision = 32: the 16384-trajectory launch is the one-trajectory mixed solve, bit for bit (sub-range of 1024)
+    lo = 5 * 1024
     o.precision = 32
-    s.set_kernel_variant(12)
-    s.upload(base, o.max_linesearch)
+    s.set_kernel_variant(2)
+    s.upload(b.slice(lo, lo + 1024), o.max_linesearch)
     s.run(o)
     one = s.download(want_K=False)
     s.set_kernel_variant(0)
     s.close()
-    for t in range(16):
-        blk = slice(1024 * t, 1024 * (t + 1))
-        assert np.array_equal(last[32]["X"][blk], one["X"]) and np.array_equal(last[32]["U"][blk], one["U"]), t
-        assert np.array_equal(last[32]["stats"]["inner_iters"][blk], one["stats"]["inner_iters"])
-    agree = np.mean(one["stats"]["status"][sel] == ref["stats"]["status"])
-    dX = np.max(np.abs(one["X"][sel] - ref["X"]), axis=(1, 2))
-    print(f"[configs[2] shape 16384 x 1000 fp32 (packed8 = one-trajectory float build, bit for bit)] oracle sub-sample of 48: status agreement "
-          f"{agree:.3f}, |dX| < 1e-3 on {np.mean(dX < 1e-3):.3f}")
-    assert agree >= 0.95 and np.mean(dX < 1e-3) >= 0.8
+    blk = slice(lo, lo + 1024)
+    assert np.array_equal(last[32]["X"][blk], one["X"]) and np.array_equal(last[32]["U"][blk], one["U"])
+    assert np.array_equal(last[32]["stats"]["inner_iters"][blk], one["stats"]["inner_iters"])
+    g32 = dict(X=last[32]["X"][sel], U=last[32]["U"][sel], stats=last[32]["stats"][sel])
+    agree = np.mean(g32["stats"]["status"] == ref["stats"]["status"])
+    dX = np.max(np.abs(g32["X"] - ref["X"]), axis=(1, 2))
+    dU = np.max(np.abs(g32["U"] - ref["U"]), axis=(1, 2)) / np.maximum(1.0, np.max(np.abs(ref["U"]), axis=(1, 2)))
+    print(f"[configs[2] 16384 x 1000 precision = 32 (mixed packed8 = one-trajectory mixed build, bit for bit)] oracle sub-sample of 48: status "
+          f"agreement {agree:.3f}, |dX| < 1e-3 on {np.mean(dX < 1e-3):.3f} (max {dX.max():.2e}), |dU|/scale < 1e-3 on {np.mean(dU < 1e-3):.3f} (max {dU.max():.2e})")
+    assert agree >= 0.97 and np.mean(dX < 1e-3) >= 0.97 and np.mean(dU < 1e-3) >= 0.97

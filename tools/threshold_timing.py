@@ -18,7 +18,7 @@ for T in (1024, 2048, 3072, 4096, 6144, 8192):
     o = opts.to_abi(b.N, b.n_tab, 3, error_state=1)
     s.upload(b, o.max_linesearch)
     out = []
-    for name, prec, var in (("wide", 64, 1), ("dense", 64, 2), ("packed", 64, 3), ("fp32 2w", 32, 12), ("fp32 4w", 32, 14), ("fp32 packed", 32, 3)):
+    for name, prec, var in (("wide", 64, 1), ("dense", 64, 2), ("packed", 64, 3), ("mixed dense", 32, 2), ("mixed packed", 32, 3)):
         o.precision = prec
         s.set_kernel_variant(var)
         ms = [s.run(o) for _ in range(2)][1:]

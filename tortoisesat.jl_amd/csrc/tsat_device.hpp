@@ -112,6 +112,18 @@ typedef double cfg_real;
 #endif
 typedef double acc_t;
 constexpr int RPU = 16 / (int)sizeof(cfg_real);   // reals per 16-byte copy unit: 2 (double) or 4 (float)
+// Storage / arithmetic type of the LINEARISATION: the Jacobian lanes and the knot records they leave for the Riccati recursion.
+// -DTSAT_JAC32 (options.precision = 32, the mixed-precision builds): float — the discrete Jacobians are the bulk of the flops
+// (nine tangent passes per knot) and of the on-chip / workspace bytes (72 | 84 values per knot and iteration), and an error of 1e-7
+// in [A|B] only perturbs the search direction; everything a line-search decision rests on — the roll-out state, the feedback,
+// the costs, the cost-to-go recursion, the gains, the multipliers, the field tables — stays double (J ~ 1e4 has to resolve
+// dJ ~ 1e-4, and a budget-limited solve follows the fp64 iteration path only if its accept / reject decisions do).
+#ifdef TSAT_JAC32
+typedef float jac_t;
+#else
+typedef cfg_real jac_t;
+#endif
+constexpr int RPUJ = 16 / (int)sizeof(jac_t);     // record values per 16-byte copy unit
 
 // The fp32 build comes in three LDS budgets, TSAT_OCC = wavefronts per SIMD it is laid out for (the compiler derives the
 // register budget from the LDS-limited occupancy): 2 -> <= 20 480 B, 3 -> <= 13 653 B, 4 -> <= 10 240 B per wavefront.
@@ -165,6 +177,11 @@ template <int ES> struct BwdCfg {
 #if defined(TSAT_F32)
   // fp32 build: 4-byte records plus the 512-byte double reduction scratch inside the budget of TSAT_OCC waves per SIMD
   static constexpr int CHB = (TSAT_OCC == 2) ? (ES ? 63 : 54) : (TSAT_OCC == 3) ? (ES ? 39 : 34) : (ES ? 27 : 23);
+#elif defined(TSAT_JAC32) && defined(TSAT_DENSE)
+  // mixed-precision builds at two wavefronts per SIMD: float records, twice the knots of the double build in the same 20 KB
+  static constexpr int CHB = ES ? 59 : 50;
+#elif defined(TSAT_JAC32)
+  static constexpr int CHB = 64;
 #elif defined(TSAT_DENSE)
   // "dense" build of the solve kernel (tsat_kernels_dense.hip) for batches of more than one wave per SIMD: 8 waves x
   // <= 20 KB per CU and <= 256 registers, so that two trajectories share a SIMD (1.45x fp64 issue); the price is
@@ -274,8 +291,9 @@ constexpr int FWD_NBUF = 2;   // the next chunk is copied while this one is roll
 #endif
 constexpr int L_FWD = L_UNION;
 constexpr int L_FWD_END = L_FWD + (FWD_NBUF * FB_SIZE > CG * KBS ? FWD_NBUF * FB_SIZE : CG * KBS);
-constexpr int L_BWD_SOLVE = (BwdCfg<0>::CHB * BwdCfg<0>::RECS > BwdCfg<1>::CHB * BwdCfg<1>::RECS
-                                ? BwdCfg<0>::CHB * BwdCfg<0>::RECS : BwdCfg<1>::CHB * BwdCfg<1>::RECS);
+constexpr int L_BWD_RECV = (BwdCfg<0>::CHB * BwdCfg<0>::RECS > BwdCfg<1>::CHB * BwdCfg<1>::RECS
+                               ? BwdCfg<0>::CHB * BwdCfg<0>::RECS : BwdCfg<1>::CHB * BwdCfg<1>::RECS);     // record values of a chunk
+constexpr int L_BWD_SOLVE = (L_BWD_RECV * (int)sizeof(jac_t) + (int)sizeof(cfg_real) - 1) / (int)sizeof(cfg_real);   // ... in reals
 #if !defined(TSAT_DENSE) && !defined(TSAT_F32)
 constexpr int L_BWD_END = L_REC + (L_BWD_SOLVE > TV_CHB * TvRec::RECS ? L_BWD_SOLVE : TV_CHB * TvRec::RECS);   // + the tracking kernel
 #else
@@ -925,9 +943,9 @@ TSAT_DEV void store_record5(TSAT_GLOBAL real* cr, const real x[7], const real u[
 // the same with the instruction's wave-uniform LDS base given directly: this lane's unit lands at base + RPU * lane
 template <typename real>
 TSAT_DEV void glds_put_at(real* base, const TSAT_GLOBAL real* src) {
-  static_assert(sizeof(real) == sizeof(cfg_real), "16-byte copy units are RPU reals");
+  constexpr int U = 16 / (int)sizeof(real);      // values per 16-byte copy unit
 #ifdef TSAT_EMU
-  for (int i = 0; i < RPU; ++i) base[RPU * TSAT_LANE() + i] = src[i];
+  for (int i = 0; i < U; ++i) base[U * TSAT_LANE() + i] = src[i];
 #else
   typedef __attribute__((address_space(1))) const void* gp_t;
   typedef __attribute__((address_space(3))) void* lp_t;
@@ -1217,56 +1235,86 @@ TSAT_DEV void al_control_terms(const Traj<real>& tr, const real u[3], const real
 }
 
 // --------------------------------------------------------------------------------------------------
-// Jacobian lanes of one backward chunk: lane l linearises knot k0 + l and leaves [A|B], lx, lu, luu in LDS
+// The knot record of one knot (layout PkRec<ES>, values of type jac_t) through the pointer `rc` (LDS, or generic in the packed
+// builds): [A|B] — in error coordinates A^ = E(q_{k+1})' A E(q_k), B^ = E(q_{k+1})' B column by column (rk_jacobian_es_cols) —
+// from the tangent passes in jac_t arithmetic (float in the mixed-precision builds: the linearisation point and the trajectory
+// constants are rounded once, the passes run at the float rate with half the registers), and the cost terms lx (error
+// coordinates: lx^ = E(q_k)' lx), G'QG = E(q_k)' Q E(q_k) (src/quaternion_toolbox.jl:15-36), lu, luu with the AL terms of the
+// control box in `real` arithmetic, rounded to jac_t when stored. qn: the NOMINAL next quaternion (error coordinates).
+// --------------------------------------------------------------------------------------------------
+template <typename T, typename S>
+TSAT_DEV Traj<T> traj_cast(const Traj<S>& a) {
+  Traj<T> t;
+  for (int i = 0; i < 7; ++i) { t.xf[i] = (T)a.xf[i]; t.Qd[i] = (T)a.Qd[i]; t.Qfd[i] = (T)a.Qfd[i]; }
+  for (int i = 0; i < 3; ++i) { t.Rd[i] = (T)a.Rd[i]; t.ulo[i] = (T)a.ulo[i]; t.uhi[i] = (T)a.uhi[i]; }
+  for (int i = 0; i < 9; ++i) { t.J[i] = (T)a.J[i]; t.hJi[i] = (T)a.hJi[i]; }
+  t.h = (T)a.h; t.hh = (T)a.hh; t.us = (T)a.us; t.usj = (T)a.usj;
+  t.tau0 = a.tau0; t.dtau = a.dtau; t.N = a.N; t.n_tab = a.n_tab; t.bt = nullptr;
+  return t;
+}
+template <typename real, int INTEG, int DIAGJ, int ES, typename JP>
+TSAT_DEV void knot_record(const Traj<real>& tr, const real x[7], const real u[3], const real lam[6], const real b0[3], const real b1[3],
+                          const real b2[3], const real qn[4], real mu, JP rc) {
+  using R = PkRec<ES>;
+  if constexpr (sizeof(jac_t) == sizeof(real)) {
+    if (!ES) rk_jacobian_cols<real, INTEG, DIAGJ, ES, JP, R::FSR>(tr, x, u, b0, b1, b2, rc, 0, 10);
+    else rk_jacobian_es_cols<real, INTEG, DIAGJ, JP, R::FSR>(tr, x, u, b0, b1, b2, qn, rc, 0, 9);
+  } else {
+    const Traj<jac_t> tj = traj_cast<jac_t, real>(tr);
+    jac_t xj[7], uj[3], c0[3], c1[3], c2[3], qj[4];
+    for (int i = 0; i < 7; ++i) xj[i] = (jac_t)x[i];
+    for (int i = 0; i < 3; ++i) { uj[i] = (jac_t)u[i]; c0[i] = (jac_t)b0[i]; c1[i] = (jac_t)b1[i]; c2[i] = (jac_t)b2[i]; }
+    for (int i = 0; i < 4; ++i) qj[i] = (jac_t)qn[i];
+    if (!ES) rk_jacobian_cols<jac_t, INTEG, DIAGJ, ES, JP, R::FSR>(tj, xj, uj, c0, c1, c2, rc, 0, 10);
+    else rk_jacobian_es_cols<jac_t, INTEG, DIAGJ, JP, R::FSR>(tj, xj, uj, c0, c1, c2, qj, rc, 0, 9);
+  }
+  real lx[7];
+  for (int i = 0; i < 7; ++i) lx[i] = tr.Qd[i] * (x[i] - tr.xf[i]);
+  if (ES) {
+    const real qk[4] = {x[3], x[4], x[5], x[6]};
+    real o[3];
+    gt_apply(qk, lx[3], lx[4], lx[5], lx[6], o);
+    lx[3] = o[0]; lx[4] = o[1]; lx[5] = o[2];
+    // G' diag(Qd[3:7]) G, upper triangle (0,0)(0,1)(0,2)(1,1)(1,2)(2,2); G rows: [-v'; s I + hat(v)]
+    const real sq = qk[0], v0 = qk[1], v1 = qk[2], v2 = qk[3];
+    const real G[4][3] = {{-v0, -v1, -v2}, {sq, -v2, v1}, {v2, sq, -v0}, {-v1, v0, sq}};
+    int idx = 0;
+    for (int j = 0; j < 3; ++j)
+      for (int l = j; l < 3; ++l) {
+        real acc = 0;
+        for (int r = 0; r < 4; ++r) acc += G[r][j] * tr.Qd[3 + r] * G[r][l];
+        rc[R::QQ + idx++] = (jac_t)acc;
+      }
+  }
+  for (int i = 0; i < BwdCfg<ES>::NH; ++i) rc[R::LX + i] = (jac_t)lx[i];
+  real lu[3], luu[3];
+  al_control_terms(tr, u, lam, mu, lu, luu);
+  for (int c = 0; c < 3; ++c) { rc[R::LU + c] = (jac_t)lu[c]; rc[R::LUU + c] = (jac_t)luu[c]; }
+}
+
+// the chunk's records in LDS (values of type jac_t, from L_REC on)
+TSAT_DEV jac_t* rec_base() { return reinterpret_cast<jac_t*>(lds_base<cfg_real>() + L_REC); }
+
+// --------------------------------------------------------------------------------------------------
+// Jacobian lanes of one backward chunk: lane l linearises knot k0 + l and leaves its record in LDS
 // --------------------------------------------------------------------------------------------------
 template <typename real, int INTEG, int DIAGJ, int ES>
 TSAT_PHASE void jacobian_chunk(TPtrs<real> p, int N, int n_tab, int k0, int nk, real mu) {
-  real* lds = lds_base<real>();
   const int lane = TSAT_LANE();
   if (lane < nk) {
     const Traj<real> tr = load_traj<real>(N, n_tab, p.bt);
     const int k = k0 + lane;
     const TSAT_GLOBAL real* xu = p.XU + (size_t)k * XUW;
-    real x[7], u[3], lam[6], b0[3], b1[3], b2[3];
+    real x[7], u[3], lam[6], b0[3], b1[3], b2[3], qn[4];
     for (int i = 0; i < 7; ++i) x[i] = xu[i];
     for (int c = 0; c < 3; ++c) u[c] = xu[7 + c];
     for (int c = 0; c < 6; ++c) lam[c] = p.LAM[(size_t)k * LMW + c];
+    for (int i = 0; i < 4; ++i) qn[i] = xu[XUW + 3 + i];
     const TSAT_GLOBAL real* p0 = tr.bt + (size_t)brow_index(tr, k, 0.0) * 4;
     const TSAT_GLOBAL real* p1 = tr.bt + (size_t)brow_index(tr, k, 0.5) * 4;
     const TSAT_GLOBAL real* p2 = tr.bt + (size_t)brow_index(tr, k, 1.0) * 4;
     for (int c = 0; c < 3; ++c) { b0[c] = p0[c]; b1[c] = p1[c]; b2[c] = p2[c]; }
-    using R = PkRec<ES>;
-    real* rc = lds + L_REC + lane * R::RECS;
-    if (!ES) {
-      rk_jacobian<real, INTEG, DIAGJ, ES>(tr, x, u, b0, b1, b2, rc);
-      for (int i = 0; i < 7; ++i) rc[R::LX + i] = tr.Qd[i] * (x[i] - tr.xf[i]);
-    } else {
-      // error coordinates: A^ = E(q_{k+1})' A E(q_k), B^ = E(q_{k+1})' B column by column (rk_jacobian_es_cols),
-      // lx^ = E(q_k)' lx, Qxx^ = E(q_k)' Q E(q_k) (src/quaternion_toolbox.jl:15-36)
-      real qk[4], qn[4];
-      for (int i = 0; i < 4; ++i) { qk[i] = x[3 + i]; qn[i] = xu[XUW + 3 + i]; }
-      rk_jacobian_es_cols<real, INTEG, DIAGJ, real*, R::FSR>(tr, x, u, b0, b1, b2, qn, rc, 0, 9);
-      real lx[7];
-      for (int i = 0; i < 7; ++i) lx[i] = tr.Qd[i] * (x[i] - tr.xf[i]);
-      {
-        real o[3];
-        gt_apply(qk, lx[3], lx[4], lx[5], lx[6], o);
-        lx[3] = o[0]; lx[4] = o[1]; lx[5] = o[2];
-      }
-      for (int i = 0; i < 6; ++i) rc[R::LX + i] = lx[i];
-      {  // G' diag(Qd[3:7]) G, upper triangle (0,0)(0,1)(0,2)(1,1)(1,2)(2,2); G rows: [-v'; s I + hat(v)]
-        const real sq = qk[0], v0 = qk[1], v1 = qk[2], v2 = qk[3];
-        const real G[4][3] = {{-v0, -v1, -v2}, {sq, -v2, v1}, {v2, sq, -v0}, {-v1, v0, sq}};
-        int idx = 0;
-        for (int j = 0; j < 3; ++j)
-          for (int l = j; l < 3; ++l) {
-            real acc = 0;
-            for (int r = 0; r < 4; ++r) acc += G[r][j] * tr.Qd[3 + r] * G[r][l];
-            rc[R::QQ + idx++] = acc;
-          }
-      }
-    }
-    al_control_terms(tr, u, lam, mu, rc + R::LU, rc + R::LUU);
+    knot_record<real, INTEG, DIAGJ, ES, jac_t*>(tr, x, u, lam, b0, b1, b2, qn, mu, rec_base() + lane * PkRec<ES>::RECS);
   }
 }
 
@@ -1518,6 +1566,10 @@ TSAT_DEV RowIn<NH> row_load(const real* rc, const RowRoles<NH, R>& ro) {
     typedef real v2 __attribute__((vector_size(16)));
     const v2* q = reinterpret_cast<const v2*>(rc + ro.cj * R::FSR);
     for (int t = 0; t < NH / 2; ++t) { const v2 v = q[t]; in.f[2 * t] = (double)v[0]; in.f[2 * t + 1] = (double)v[1]; }
+  } else if constexpr (ES && sizeof(real) == 4) {   // 24-byte columns: three 8-byte reads
+    typedef real v2 __attribute__((vector_size(8)));
+    const v2* q = reinterpret_cast<const v2*>(rc + ro.cj * R::FSR);
+    for (int t = 0; t < NH / 2; ++t) { const v2 v = q[t]; in.f[2 * t] = (double)v[0]; in.f[2 * t + 1] = (double)v[1]; }
   } else {
     for (int m = 0; m < NH; ++m) in.f[m] = (double)rc[ro.cj * R::FSR + m];
   }
@@ -1645,14 +1697,14 @@ TSAT_PHASE BwdOut<real> riccati_rows(TSAT_GLOBAL real* KDg, int k0_, int nk_, re
   };
   // The record of knot l - 1 is read while knot l is worked on (one wavefront per SIMD has nobody to hide an LDS latency behind);
   // two knots per turn, two register sets A / B taking turns (a single set would have to be copied every knot).
-  auto rec = [&](int l) { return lds + L_REC + ((l > 0) ? l : 0) * R::RECS; };
-  RowIn<NH> A = row_load<real, NH, R>(rec(nk - 1), ro);
+  auto rec = [&](int l) { return rec_base() + ((l > 0) ? l : 0) * R::RECS; };
+  RowIn<NH> A = row_load<jac_t, NH, R>(rec(nk - 1), ro);
   for (int l = nk - 1; l >= 0; l -= 2) {
-    const RowIn<NH> B = row_load<real, NH, R>(rec(l - 1), ro);
+    const RowIn<NH> B = row_load<jac_t, NH, R>(rec(l - 1), ro);
     TSAT_SCHED_FENCE();
     if (!knot(A, l)) { pd_ok = false; break; }
     if (l - 1 >= 0) {
-      A = row_load<real, NH, R>(rec(l - 2), ro);
+      A = row_load<jac_t, NH, R>(rec(l - 2), ro);
       TSAT_SCHED_FENCE();
       if (!knot(B, l - 1)) { pd_ok = false; break; }
     }
@@ -1739,8 +1791,7 @@ TSAT_PHASE BwdOut<real> backward_sweep(TPtrs<real> p, int N, int n_tab, real mu,
     jacobian_chunk<real, INTEG, DIAGJ, ES>(p, N, n_tab, k0, nk, mu);
     TSAT_SYNC();
     const unsigned long long t_j1 = tick_();
-    if constexpr (sizeof(real) == 8) acc = riccati_rows<real, BwdCfg<ES>::NH, PkRec<ES>>(p.KD, k0, nk, rho, acc.dV1, acc.dV2);
-    else acc = riccati_chunk<real, BwdCfg<ES>::NH, PkRec<ES>>(p.KD, k0, nk, rho, acc.dV1, acc.dV2);
+    acc = riccati_rows<real, BwdCfg<ES>::NH, PkRec<ES>>(p.KD, k0, nk, rho, acc.dV1, acc.dV2);
     TSAT_SYNC();
 #ifdef TSAT_PROFILE
     if (lane == 0) {

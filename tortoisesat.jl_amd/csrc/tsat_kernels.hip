@@ -22,13 +22,12 @@ using namespace tsat;
 hipError_t tsat_launch_solve_dense(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 // the packed build — 8 trajectories per wavefront share the forward sweeps (tsat_kernels_packed.hip, tsat_packed.hpp)
 hipError_t tsat_launch_solve_packed(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
-// the fp32 build (options.precision = 32) likewise (tsat_kernels_f32.hip)
-hipError_t tsat_launch_solve_packed_f32(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_packed8(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
-hipError_t tsat_launch_solve_packed_f328(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
-hipError_t tsat_launch_solve_f32_o2(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
-hipError_t tsat_launch_solve_f32_o3(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
-hipError_t tsat_launch_solve_f32_o4(const KArgs<float>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+// the mixed-precision builds (options.precision = 32: float linearisation, everything else double; -DTSAT_JAC32 in tsat_device.hpp)
+// of the dense, packed and packed8 layouts, on the very arrays of the fp64 builds (tsat_kernels_*_mixed.hip)
+hipError_t tsat_launch_solve_dense_mixed(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+hipError_t tsat_launch_solve_packed_mixed(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+hipError_t tsat_launch_solve_packed_mixed8(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -68,12 +67,6 @@ __global__ __launch_bounds__(64) void tsat_horizon_kernel(HzArgs<real> a) {
   horizon_trajectory<real>(a, traj);
 }
 
-// double -> float copies of the uploaded tables and initial controls for the fp32 build, and float -> double widening of the
-// fp32 build's (x,u) records for the (fp64) tracking kernel
-__global__ __launch_bounds__(256) void tsat_narrow_kernel(int64_t n, const double* src, float* dst) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) dst[e] = (float)src[e];
-}
 // resident field tables [T][rows][3] (tsat_btable_batch) -> the solver's padded tables [T][n_tab][4], first n_tab rows
 __global__ __launch_bounds__(256) void tsat_pack_tables_kernel(int64_t n, int rows, int n_tab, const double* B, double* BT) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,16 +77,6 @@ __global__ __launch_bounds__(256) void tsat_pack_tables_kernel(int64_t n, int ro
   double* dst = BT + (size_t)e * 4;
   dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = 0.0;
 }
-__global__ __launch_bounds__(256) void tsat_widen_records_kernel(int64_t n_rec, int N, const float* XU32, double* XU64) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_rec) return;
-  const int64_t t = e / N;
-  const int k = (int)(e - t * N);
-  const float* r = XU32 + (size_t)t * xu_stride<float>(N) + (size_t)k * XUW;
-  double* w = XU64 + (size_t)e * XUW;
-  for (int i = 0; i < XUW; ++i) w[i] = (double)r[i];
-}
-
 template <typename real>
 __global__ __launch_bounds__(256) void tsat_export_kernel(int64_t n_rec, int N, const int* nk, const real* XU,
                                                           const real* KD, double* X, double* U, double* K) {
@@ -125,13 +108,6 @@ struct tsat_handle {
   int variant = 0;            // solve-kernel build: 0 automatic (dense above 1024 trajectories), 1 wide, 2 dense
   // host copies of the small per-trajectory inputs of the last upload (26 doubles each), for tsat_tvlqr_resident
   std::vector<double> hx0, hxf, htau0, hdtau, hdt, hJ;
-  // fp32 build: float parameter records packed at upload (host), float mirrors of the tables / initial controls made on the
-  // device at the first precision = 32 run after an upload; the solver's own arrays (XU, KD, LAM, CAND) are shared with
-  // the fp64 builds (allocated for doubles, used as floats)
-  std::vector<float> hP32;
-  float *P32 = nullptr, *BT32 = nullptr, *U032 = nullptr;
-  bool f32_ready = false;
-  int solved_precision = 64;
   int64_t bt_T = 0;      // field tables left on the device by the last tsat_btable_batch: [bt_T][bt_rows][3] in slot WS_BT_B
   int bt_rows = 0;
   int64_t bt_gen = 0;    // bumped by every tsat_btable_batch call that touches the resident tables (tsat_btable_generation)
@@ -165,11 +141,10 @@ int fail(tsat_handle* h, int code, const std::string& msg) {
   } while (0)
 
 void release(tsat_handle* h) {
-  void* ptrs[] = {h->P, h->BT, h->U0, h->XU, h->KD, h->LAM, h->CAND, h->bidx, h->nk, h->stats, h->trace, h->P32, h->BT32, h->U032};
+  void* ptrs[] = {h->P, h->BT, h->U0, h->XU, h->KD, h->LAM, h->CAND, h->bidx, h->nk, h->stats, h->trace};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->P = h->BT = h->U0 = h->XU = h->KD = h->LAM = h->CAND = nullptr;
-  h->P32 = h->BT32 = h->U032 = nullptr; h->f32_ready = false;
   h->bidx = nullptr; h->nk = nullptr; h->ragged = false; h->stats = nullptr; h->trace = nullptr;
   h->T = 0; h->bytes = 0; h->uploaded = h->solved = false;
 }
@@ -362,9 +337,6 @@ int tsat_batch_upload(tsat_handle* h, const double* x0, const double* xf, const 
   TSAT_HIP(h, hipMemcpy(h->U0, U0, (size_t)T * (h->N - 1) * 3 * sizeof(double), hipMemcpyHostToDevice));
   h->hx0.assign(x0, x0 + 7 * T); h->hxf.assign(xf, xf + 7 * T); h->htau0.assign(tau0, tau0 + T);
   h->hdtau.assign(dtau, dtau + T); h->hdt.assign(dt, dt + T); h->hJ.assign(Jmat, Jmat + 9 * T);
-  h->hP32.resize((size_t)T * PSTRIDE);
-  pack_params<float>(T, x0, xf, tau0, dtau, dt, Jmat, Qd, Qfd, Rd, ulo, uhi, h->hP32.data());
-  h->f32_ready = false;
   h->uploaded = true;
   h->solved = false;
   h->ragged = false;   // a fresh upload is a uniform batch until tsat_batch_knots says otherwise
@@ -405,29 +377,37 @@ solve_kern_t solve_variant(const tsat_handle* h, const tsat_options* o) {
 constexpr int64_t TSAT_WIDE_MAX_T = 1024;
 constexpr int64_t TSAT_PACKED_MIN_T = 3072;
 constexpr int64_t TSAT_PACKED8_MIN_T = 16384;
-constexpr int64_t TSAT_PACKED_F32_MIN_T = 3072;     // below it the one-trajectory float build (two waves per SIMD) is faster
+// the build (1 wide, 2 dense, 3 packed, 4 packed8) that (h->variant, batch size, precision) selects. precision = 32 — the
+// mixed-precision builds — has no wide layout: below 3072 trajectories its dense build runs (59-knot Jacobian passes in the
+// 20 KB of two wavefronts per SIMD, which the double records do not allow)
+int selected_build(const tsat_handle* h, int precision) {
+  if (h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED8_MIN_T)) return 4;
+  if (h->variant == 3 || (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T)) return 3;
+  if (precision == 32) return 2;
+  return (h->variant == 2 || (h->variant != 1 && h->T > TSAT_WIDE_MAX_T)) ? 2 : 1;
+}
 hipError_t launch_solve(const tsat_handle* h, const tsat_options* o, const KArgs<double>& a) {
-  const bool packed8 = h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED8_MIN_T);
-  if (packed8) return tsat_launch_solve_packed8(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream);
-  const bool packed = h->variant == 3 || (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T);
-  if (packed) return tsat_launch_solve_packed(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream);
-  const bool dense = h->variant == 2 || (h->variant != 1 && h->T > TSAT_WIDE_MAX_T);
-  if (dense) return tsat_launch_solve_dense(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream);
+  const int build = selected_build(h, o->precision), rk4 = o->integrator == 4;
+  if (o->precision == 32) {
+    if (build == 4) return tsat_launch_solve_packed_mixed8(a, rk4, h->inertia_class, o->error_state, h->stream);
+    if (build == 3) return tsat_launch_solve_packed_mixed(a, rk4, h->inertia_class, o->error_state, h->stream);
+    return tsat_launch_solve_dense_mixed(a, rk4, h->inertia_class, o->error_state, h->stream);
+  }
+  if (build == 4) return tsat_launch_solve_packed8(a, rk4, h->inertia_class, o->error_state, h->stream);
+  if (build == 3) return tsat_launch_solve_packed(a, rk4, h->inertia_class, o->error_state, h->stream);
+  if (build == 2) return tsat_launch_solve_dense(a, rk4, h->inertia_class, o->error_state, h->stream);
   hipLaunchKernelGGL(solve_variant(h, o), dim3((unsigned)h->T), dim3(64), 0, h->stream, a);
   return hipGetLastError();
 }
 
 // Jacobian-record workspace of the packed builds (one block per wavefront, i.e. per four trajectories at most), persistent in
-// the handle; sized for doubles, the float build uses half of it
+// the handle; sized for double records, the mixed-precision builds (float records) use half of it
 void* packed_workspace(tsat_handle* h) {
   return ws_get(h, tsat_handle::WS_JW, (size_t)((h->T + 3) / 4) * TSAT_JW_REALS_PER_4 * sizeof(double));
 }
 
 // does the build that (h->variant, batch size, precision) selects need the packed builds' Jacobian workspace a.JW?
-bool uses_packed_build(const tsat_handle* h, int precision) {
-  if (h->variant == 3 || h->variant == 4) return true;
-  return h->variant == 0 && h->T >= (precision == 32 ? TSAT_PACKED_F32_MIN_T : TSAT_PACKED_MIN_T);
-}
+bool uses_packed_build(const tsat_handle* h, int precision) { return selected_build(h, precision) >= 3; }
 
 // Endgame of a packed launch (tsat_packed.hpp, suspend_if_endgame). Automatic: once a quarter of the batch, at most the 2048
 // wavefront slots of the machine (256 CUs x 4 SIMDs x 2), is all that still iterates — and only for iteration budgets long
@@ -461,45 +441,6 @@ KArgs<double> solve_args(tsat_handle* h, const tsat_options* o) {
   return a;
 }
 
-// float mirrors of the inputs for the fp32 build, made once per upload (outside any timed region)
-int ensure_f32_mirrors(tsat_handle* h) {
-  if (h->f32_ready) return 0;
-  const size_t T = (size_t)h->T, nBT = (size_t)h->n_btab * h->n_tab * 4, nU0 = T * u0_stride<float>(h->N);
-  if (!h->P32 && hipMalloc((void**)&h->P32, T * PSTRIDE * sizeof(float)) != hipSuccess) return -10;
-  if (!h->BT32 && hipMalloc((void**)&h->BT32, nBT * sizeof(float)) != hipSuccess) return -10;
-  if (!h->U032 && hipMalloc((void**)&h->U032, (nU0 ? nU0 : 4) * sizeof(float)) != hipSuccess) return -10;
-  if (hipMemcpyAsync(h->P32, h->hP32.data(), T * PSTRIDE * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess) return -10;
-  hipLaunchKernelGGL(tsat_narrow_kernel, dim3((unsigned)((nBT + 255) / 256)), dim3(256), 0, h->stream, (int64_t)nBT, h->BT, h->BT32);
-  if (nU0) hipLaunchKernelGGL(tsat_narrow_kernel, dim3((unsigned)((nU0 + 255) / 256)), dim3(256), 0, h->stream, (int64_t)nU0, h->U0, h->U032);
-  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -10;
-  h->f32_ready = true;
-  return 0;
-}
-// the fp32 build on the solver's own arrays (allocated for doubles, used as floats)
-int launch_solve_f32(tsat_handle* h, const tsat_options* o) {
-  KArgs<float> a;
-  a.T = (int)h->T; a.N = h->N; a.n_tab = h->n_tab; a.max_ls = h->max_ls < NSTORE ? h->max_ls : NSTORE; a.opt = *o;
-  a.P = h->P32; a.BT = h->BT32; a.bidx = h->bidx; a.nk = h->ragged ? h->nk : nullptr; a.U0 = h->U032;
-  a.XU = (float*)h->XU; a.KD = (float*)h->KD; a.LAM = (float*)h->LAM; a.CAND = (float*)h->CAND;
-  a.stats = h->stats; a.trace = h->trace; a.trace_rows = h->trace ? h->trace_rows : 0;
-  a.JW = uses_packed_build(h, 32) ? (float*)packed_workspace(h) : nullptr;
-  if (uses_packed_build(h, 32) && !a.JW) return -10;
-  if (a.JW) {
-    const EndgameArgs e = endgame_args(h, o);
-    a.suspend_at = e.suspend_at; a.live = e.live; a.susp_n = e.susp_n; a.susp_ids = e.susp_ids; a.susp_state = e.susp_state;
-  }
-  // build by batch size: the layout for two wavefronts per SIMD while the batch fits the GPU that way (256 CUs x 4 SIMDs x 2),
-  // else the one for four; tsat_set_kernel_variant(h, 12 | 13 | 14) forces one (tuning, tests)
-  // batches several times larger than the machine: the packed build (tsat_kernels_packed_f32.hip), as in fp64
-  if (h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED8_MIN_T))
-    return tsat_launch_solve_packed_f328(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream) == hipSuccess ? 0 : -10;
-  if (h->variant == 3 || (h->variant == 0 && h->T >= TSAT_PACKED_F32_MIN_T))
-    return tsat_launch_solve_packed_f32(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream) == hipSuccess ? 0 : -10;
-  // one trajectory per wavefront: the two-waves-per-SIMD layout is the fastest at every batch size measured; 13 / 14 force the others
-  const int occ = (h->variant >= 12 && h->variant <= 14) ? h->variant - 10 : 2;
-  auto fn = occ == 2 ? tsat_launch_solve_f32_o2 : (occ == 3 ? tsat_launch_solve_f32_o3 : tsat_launch_solve_f32_o4);
-  return fn(a, o->integrator == 4, h->inertia_class, o->error_state, h->stream) == hipSuccess ? 0 : -10;
-}
 }  // namespace
 
 int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
@@ -512,27 +453,19 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
   if (!a.JW && uses_packed_build(h, 64))
     return fail(h, -10, "device allocation of the packed builds' Jacobian workspace failed");
   if (h->trace) TSAT_HIP(h, hipMemsetAsync(h->trace, 0, (size_t)h->T * h->trace_rows * 8 * sizeof(double), h->stream));
-  if (o->precision == 32) {
-    // first fp32 run after an upload: the float mirrors are built before the events, so that kernel_ms is the solve alone
-    if (ensure_f32_mirrors(h)) return fail(h, -10, "device allocation or copy failed while preparing the fp32 inputs");
-    TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
-    if (launch_solve_f32(h, o)) return fail(h, -10, "launch of the fp32 solve kernel failed");
-  } else {
-    TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
-    TSAT_HIP(h, launch_solve(h, o, a));
-  }
+  TSAT_HIP(h, hipEventRecord(h->ev0, h->stream));
+  TSAT_HIP(h, launch_solve(h, o, a));
   TSAT_HIP(h, hipEventRecord(h->ev1, h->stream));
   TSAT_HIP(h, hipStreamSynchronize(h->stream));
   if (kernel_ms) TSAT_HIP(h, hipEventElapsedTime(kernel_ms, h->ev0, h->ev1));
   h->solved = true;
-  h->solved_precision = o->precision;
   return 0;
 }
 
 int tsat_set_kernel_variant(tsat_handle* h, int32_t variant) {
   if (!h) return -1;
-  if (!((variant >= 0 && variant <= 4) || (variant >= 12 && variant <= 14)))
-    return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), 3 (packed, 4 trajectories per wavefront), 4 (packed, 8), or 12 / 13 / 14 (fp32 layouts for 2 / 3 / 4 waves per SIMD)");
+  if (!(variant >= 0 && variant <= 4))
+    return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), 3 (packed, 4 trajectories per wavefront) or 4 (packed, 8)");
   h->variant = variant;
   return 0;
 }
@@ -593,16 +526,7 @@ int tsat_mpc_run(tsat_handle* h, const tsat_options* o, int32_t n_steps, int32_t
     for (int i = 0; i < 7; ++i) h->hx0[7 * t + i] = Pb[t * PSTRIDE + P_X0 + i];
     h->htau0[t] = Pb[t * PSTRIDE + P_TAU0];
   }
-  // the float mirrors of the fp32 build describe the UPLOADED x0 / tau0 / U0: refresh them from the advanced state
-  for (size_t t = 0; t < T; ++t) {
-    float* p32 = h->hP32.data() + t * PSTRIDE;
-    for (int i = 0; i < 7; ++i) p32[P_X0 + i] = (float)Pb[t * PSTRIDE + P_X0 + i];
-    p32[P_TAU0] = (float)Pb[t * PSTRIDE + P_TAU0];
-    p32[P_TAU0L] = (float)(Pb[t * PSTRIDE + P_TAU0] - (double)p32[P_TAU0]);
-  }
-  h->f32_ready = false;
   h->solved = true;
-  h->solved_precision = 64;
   return 0;
 }
 
@@ -622,14 +546,9 @@ int tsat_batch_export_device(tsat_handle* h, void* X_dev, void* U_dev, void* K_d
   const int64_t n_rec = h->T * (int64_t)h->N;
   if (X_dev || U_dev || K_dev) {
     const unsigned blocks = (unsigned)((n_rec + 255) / 256);
-    if (h->solved_precision == 32)
-      hipLaunchKernelGGL(tsat_export_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, n_rec, h->N,
-                         h->ragged ? h->nk : nullptr, (const float*)h->XU, (const float*)h->KD,
-                         (double*)X_dev, (double*)U_dev, (double*)K_dev);
-    else
-      hipLaunchKernelGGL(tsat_export_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, n_rec, h->N,
-                         h->ragged ? h->nk : nullptr, h->XU, h->KD,
-                         (double*)X_dev, (double*)U_dev, (double*)K_dev);
+    hipLaunchKernelGGL(tsat_export_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, n_rec, h->N,
+                       h->ragged ? h->nk : nullptr, h->XU, h->KD,
+                       (double*)X_dev, (double*)U_dev, (double*)K_dev);
     TSAT_HIP(h, hipGetLastError());
   }
   if (stats_dev)
@@ -788,17 +707,6 @@ int tsat_tvlqr_resident(tsat_handle* h, const tsat_tvlqr_options* o, const doubl
   if (!dP) return fail(h, -10, "device allocation failed in tsat_tvlqr_resident");
   int rc = hipMemcpy(dP, P.data(), P.size() * 8, hipMemcpyHostToDevice) == hipSuccess ? 0 : -10;
   const double* dXUR = h->XU;
-  if (!rc && h->solved_precision == 32) {   // the tracking kernel is fp64: widen the fp32 build's records into a workspace
-    const int64_t n_rec = T * (int64_t)h->N;
-    double* w = (double*)ws_get(h, tsat_handle::WS_TVB_XUR, (size_t)n_rec * XUW * 8);
-    if (!w) rc = -10;
-    if (!rc) {
-      hipLaunchKernelGGL(tsat_widen_records_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, h->stream, n_rec, h->N,
-                         (const float*)h->XU, w);
-      if (hipGetLastError() != hipSuccess) rc = -10;
-      dXUR = w;
-    }
-  }
   if (!rc) rc = run_tvlqr(h, &oo, T, h->N, h->n_tab, h->inertia_class, dP, h->BT, h->bidx, h->ragged ? h->nk : nullptr, dXUR,
                           noise, noise_id, X_sim, U_sim, K_lqr, stats);
   if (rc) h->err = "device allocation, copy or launch failed in tsat_tvlqr_resident";
@@ -964,12 +872,8 @@ int tsat_sweep_allgather(tsat_handle* h, void* X_all, void* U_all, void* stats_a
   }
   const int64_t n_rec = h->T * (int64_t)h->N;
   if (dX || dU) {
-    if (h->solved_precision == 32)
-      hipLaunchKernelGGL(tsat_export_kernel<float>, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, h->stream, n_rec, h->N,
-                         h->ragged ? h->nk : nullptr, (const float*)h->XU, (const float*)h->KD, dX, dU, (double*)nullptr);
-    else
-      hipLaunchKernelGGL(tsat_export_kernel<double>, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, h->stream, n_rec, h->N,
-                         h->ragged ? h->nk : nullptr, h->XU, h->KD, dX, dU, (double*)nullptr);
+    hipLaunchKernelGGL(tsat_export_kernel<double>, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, h->stream, n_rec, h->N,
+                       h->ragged ? h->nk : nullptr, h->XU, h->KD, dX, dU, (double*)nullptr);
     TSAT_HIP(h, hipGetLastError());
   }
   if (dS) TSAT_HIP(h, hipMemcpyAsync(dS, h->stats, nS, hipMemcpyDeviceToDevice, h->stream));

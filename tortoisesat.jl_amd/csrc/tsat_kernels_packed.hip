@@ -50,8 +50,10 @@ hipError_t TSAT_PK_NAME(tsat_launch_solve_packed)(const KArgs<double>& a, int rk
   // while every stored candidate costs 80 B per knot and sweep of HBM writes whether it wins or not.
   KArgs<double> b = a;
   b.max_ls = a.max_ls < PK_STORE ? a.max_ls : PK_STORE;
-  if (const char* e = getenv("TSAT_PK_STORE")) { const int v = atoi(e); if (v >= 1 && v < b.max_ls) b.max_ls = v; }   // tuning (tools/store_probe.py)
+#ifdef TSAT_PROFILE   // tuning knobs of the diagnostic build only (tools/store_probe.py): the product's launches do not read the environment
+  if (const char* e = getenv("TSAT_PK_STORE")) { const int v = atoi(e); if (v >= 1 && v < b.max_ls) b.max_ls = v; }
   if (const char* e = getenv("TSAT_PK_FEW")) { const int v = atoi(e); if (v >= 1) b.pk_few = v; }
+#endif
   static const kern_t resume[2][3][2] = {
       {{TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 3, 0, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 3, 0, 1>},
        {TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 3, 1, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 3, 1, 1>},

@@ -61,21 +61,20 @@ static_assert(L_FWD + PK_NBUF * PK_FB <= LDS_REALS, "packed forward buffers fit 
 // ---- joint backward sweep: carve-up behind L_UNION (the forward chunk buffers overlay all of it between backward sweeps) -----
 // The PK_G trajectories of the wave run their backward sweeps TOGETHER, four at a time, 16 knots of each per chunk:
 //   Jacobian lanes   lane = (trajectory, knot): all 64 lanes linearise a knot each, all columns, and leave the finished record
-//                    (84 reals) in the wavefront's HBM workspace a.JW — the LDS of two wavefronts per SIMD holds only four
-//                    knots per trajectory, and a narrower Jacobian pass repeats the primal stages on every lane of a knot
+//                    (84 values of type jac_t) in the wavefront's HBM workspace a.JW — the LDS of two wavefronts per SIMD holds only
+//                    four knots per trajectory (eight with float records), and a narrower Jacobian pass repeats the primal stages on every lane of a knot
 //                    (measured 2.3x the instructions per knot); the workspace is written and read back by the same wavefront
 //                    within microseconds (42 KB per wavefront: it lives in L2 / MALL);
 //   record ring      the Riccati lanes stream the records back: PK_RING knots of the four trajectories are resident in LDS, the
 //                    record PK_RING - 1 knots ahead is copied by global_load_lds while the recursion works (the wait counts
 //                    younger LOADS only: safe whatever the stores do); the last PK_RING knots of a pass — the first the
 //                    recursion consumes — never leave the chip: their Jacobian lanes write them straight into the ring;
-//   Riccati lanes    PK_C = 16 lanes per trajectory, lane j < NH + 3 owns COLUMN j of [A|B]: it keeps S~ in registers, forms
-//                    column j of W~ = S~ F and of F'W~ (the rows the recursion needs), its gain column and column j of the new
-//                    cost-to-go; three small exchanges per knot go through the trajectory's block in LDS (Quu / Qu, the
-//                    gain columns, the new S~). Element by element the operations — and their order — are those of
-//                    riccati_chunk (tsat_device.hpp): the results are bit-identical to the one-trajectory builds.
+//   Riccati lanes    PK_C = 16 lanes per trajectory = one DPP row: lane j < NH + 3 owns COLUMN j of [A|B] and of the cost-to-go; the
+//                    very step function of the one-trajectory builds (riccati_row_step, tsat_device.hpp: every cross-lane operand
+//                    is the `row_newbcast` source of the FMA that consumes it — no exchange through LDS inside a knot), four
+//                    trajectories side by side: the results are bit-identical to the one-trajectory builds.
 constexpr int PK_JCH = 16;                        // knots per trajectory and Jacobian pass (= lanes per trajectory)
-constexpr int PK_RING = (sizeof(cfg_real) == 8) ? 4 : 8;   // knots of every trajectory resident in LDS during the recursion (20 KB: 4 in double, 8 in float)
+constexpr int PK_RING = (sizeof(jac_t) == 8) ? 4 : 8;      // knots of every trajectory resident in LDS during the recursion (20 KB: 4 double records, 8 float ones)
 constexpr int PK_BC = 16;                         // lanes per trajectory in a backward pass
 constexpr int PK_BG = WAVE / PK_BC;               // trajectories per backward pass (4); a wave of PK_G trajectories takes PK_G / PK_BG passes
 static_assert(PK_G % PK_BG == 0 && PK_JCH == PK_BC, "Jacobian lanes: the 16 lanes of a trajectory linearise 16 knots");
@@ -83,18 +82,16 @@ static_assert(PK_G % PK_BG == 0 && PK_JCH == PK_BC, "Jacobian lanes: the 16 lane
 constexpr int PK_RECS = 84;                       // the larger of the two: LDS ring and workspace are sized for it
 constexpr int PK_GTRW = 88;                       // per-trajectory constants: staged parameter record (76), nu (8), pad
 constexpr int PK_GT_NU = 76;
-constexpr int PK_GXW = 88;                        // per-trajectory exchange block of the Riccati lanes:
-constexpr int GX_S = 0;                           //   S~ as packed upper triangle (<= 28) + s (<= 7)
-constexpr int GX_QU = 36;                         //   Quu (0,0)(0,1)(0,2)(1,1)(1,2)(2,2), Qu (3)
-constexpr int GX_XK = 46;                         //   per state column i: Qux(:,i) (3), K(:,i) (3)
-static_assert(GX_XK + 7 * 6 <= PK_GXW && PK_GXW % 2 == 0 && GX_XK % 2 == 0, "exchange block layout");
-static_assert(PkRec<0>::RECS % RPU == 0 && PkRec<1>::RECS % RPU == 0 && PkRec<0>::RECS <= PK_RECS, "a record is a whole number of 16-byte units");
+constexpr int PK_GXW = 64;                        // per-trajectory block of the Riccati lanes: S~ = [S; s'] between two passes, doubles [r][8]
+static_assert(PkRec<0>::RECS % RPUJ == 0 && PkRec<1>::RECS % RPUJ == 0 && PkRec<0>::RECS <= PK_RECS, "a record is a whole number of 16-byte units");
 constexpr int L_GTR = L_UNION;
 constexpr int L_GX = L_GTR + PK_BG * PK_GTRW;
 constexpr int L_GREC = L_GX + PK_BG * PK_GXW;
-constexpr int PK_SLOT = PK_BG * PK_RECS;
-static_assert(L_GREC + PK_RING * PK_SLOT <= LDS_REALS, "joint backward sweep fits the wave's LDS block");
-constexpr int PK_JW_WAVE = PK_BG * PK_JCH * PK_RECS;    // workspace reals per wavefront (its passes of four trajectories share it)
+constexpr int PK_SLOT = PK_BG * PK_RECS;                // record values (jac_t) per ring slot
+static_assert(L_GREC * (int)sizeof(cfg_real) + PK_RING * PK_SLOT * (int)sizeof(jac_t) <= LDS_REALS * (int)sizeof(cfg_real), "joint backward sweep fits the wave's LDS block");
+constexpr int PK_JW_WAVE = PK_BG * PK_JCH * PK_RECS;    // workspace values (jac_t) per wavefront (its passes of four trajectories share it)
+// the record ring (values of type jac_t, from L_GREC on)
+TSAT_DEV jac_t* ring_base() { return reinterpret_cast<jac_t*>(lds_base<cfg_real>() + L_GREC); }
 static_assert(PK_JW_WAVE == TSAT_JW_REALS_PER_4, "host allocation of a.JW");
 // packed index of (i <= j) in an n x n upper triangle, row by row
 constexpr int sym_ut(int i, int j, int n) { return i * n - (i * (i - 1)) / 2 + (j - i); }
@@ -371,7 +368,7 @@ TSAT_PK_FWD FwdOut<real> forward_sweep_packed(const KArgs<real>& a, int traj0, i
 // ([4][16][PK_RECS]). Same per-knot arithmetic as jacobian_chunk (tsat_device.hpp).
 // --------------------------------------------------------------------------------------------------
 template <typename real, int INTEG, int DIAGJ, int ES>
-TSAT_PHASE void jacobian16(const KArgs<real>& a, int traj0, TSAT_GLOBAL real* jw, int kb0, bool need, int N, real mu, int cur) {
+TSAT_PHASE void jacobian16(const KArgs<real>& a, int traj0, TSAT_GLOBAL jac_t* jw, int kb0, bool need, int N, real mu, int cur) {
   real* lds = lds_base<real>();
   const int lane = TSAT_LANE(), g = lane / PK_BC, kk = lane % PK_BC;
   const int k = kb0 + kk;
@@ -392,59 +389,16 @@ TSAT_PHASE void jacobian16(const KArgs<real>& a, int traj0, TSAT_GLOBAL real* jw
   // the last PK_RING knots of the chunk are the first the recursion consumes: their lanes put the record straight into its
   // ring slot in LDS; the others go through the workspace (one code path for both: a generic pointer, flat stores)
   using R = PkRec<ES>;
-  real* rc = (kk >= PK_JCH - PK_RING) ? lds + L_GREC + (kk & (PK_RING - 1)) * R::SLOT + g * R::RECS
-                                      : (real*)(jw + (size_t)(g * PK_JCH + kk) * R::RECS);
-  real lx[7];
-  for (int i = 0; i < 7; ++i) lx[i] = tr.Qd[i] * (x[i] - tr.xf[i]);
-  if (!ES) {
-    rk_jacobian_cols<real, INTEG, DIAGJ, ES, real*, R::FSR>(tr, x, u, b0, b1, b2, rc, 0, 10);
-  } else {
-    // error coordinates: A^ = E(q_{k+1})' A E(q_k), B^ = E(q_{k+1})' B column by column (rk_jacobian_es_cols),
-    // lx^ = E(q_k)' lx, Qxx^ = E(q_k)' Q E(q_k) (src/quaternion_toolbox.jl:15-36)
-    real qk[4], qn[4];
-    for (int i = 0; i < 4; ++i) { qk[i] = x[3 + i]; qn[i] = xu[XUW + 3 + i]; }
-    rk_jacobian_es_cols<real, INTEG, DIAGJ, real*, R::FSR>(tr, x, u, b0, b1, b2, qn, rc, 0, 9);
-    {
-      real o[3];
-      gt_apply(qk, lx[3], lx[4], lx[5], lx[6], o);
-      lx[3] = o[0]; lx[4] = o[1]; lx[5] = o[2];
-    }
-    {  // G' diag(Qd[3:7]) G, upper triangle (0,0)(0,1)(0,2)(1,1)(1,2)(2,2); G rows: [-v'; s I + hat(v)]
-      const real sq = qk[0], v0 = qk[1], v1 = qk[2], v2 = qk[3];
-      const real G[4][3] = {{-v0, -v1, -v2}, {sq, -v2, v1}, {v2, sq, -v0}, {-v1, v0, sq}};
-      int idx = 0;
-      for (int j = 0; j < 3; ++j)
-        for (int l = j; l < 3; ++l) {
-          real acc = 0;
-          for (int r = 0; r < 4; ++r) acc += G[r][j] * tr.Qd[3 + r] * G[r][l];
-          rc[R::QQ + idx++] = acc;
-        }
-    }
-  }
-  for (int i = 0; i < BwdCfg<ES>::NH; ++i) rc[R::LX + i] = lx[i];
-  real lu[3], luu[3];
-  al_control_terms(tr, u, lam, mu, lu, luu);
-  for (int c = 0; c < 3; ++c) { rc[R::LU + c] = lu[c]; rc[R::LUU + c] = luu[c]; }
+  jac_t* rc = (kk >= PK_JCH - PK_RING) ? ring_base() + (kk & (PK_RING - 1)) * R::SLOT + g * R::RECS
+                                       : (jac_t*)(jw + (size_t)(g * PK_JCH + kk) * R::RECS);
+  real qn[4];
+  for (int i = 0; i < 4; ++i) qn[i] = xu[XUW + 3 + i];
+  knot_record<real, INTEG, DIAGJ, ES, jac_t*>(tr, x, u, lam, b0, b1, b2, qn, mu, rc);
 }
 
 // --------------------------------------------------------------------------------------------------
-// joint backward sweep, Riccati lanes: the recursion over one chunk (last knot first) for the PK_G trajectories at once.
-// Lane j (of the trajectory's 16) owns column j of F = [A|B]; S~ = [S; s'] is replicated in the registers of the trajectory's
-// lanes and re-read from its exchange block after every knot. Per output element the operations are those of riccati_chunk.
-// `ok`: no Quu_reg of this trajectory has failed the PD test so far (group-uniform); returned updated.
+// joint backward sweep, Riccati lanes: the recursion over one chunk (last knot first) for the four trajectories of a pass at once
 // --------------------------------------------------------------------------------------------------
-// n consecutive reals of LDS into registers. In double with `aligned` set (six-real rows that start on 16-byte boundaries: the
-// columns of an error-state record, the gain exchange rows) as 16-byte reads, two reals each.
-template <typename real, int n, int aligned>
-TSAT_DEV void lds_row(const real* p, real out[n]) {
-  if constexpr (aligned && sizeof(real) == 8 && n % 2 == 0) {
-    typedef real v2 __attribute__((vector_size(16)));
-    const v2* q = reinterpret_cast<const v2*>(p);
-    for (int t = 0; t < n / 2; ++t) { const v2 v = q[t]; out[2 * t] = v[0]; out[2 * t + 1] = v[1]; }
-  } else {
-    for (int m = 0; m < n; ++m) out[m] = p[m];
-  }
-}
 // wait until at most min(l, PK_RING - 1) copy sets of NCI instructions are outstanding (the immediate of s_waitcnt is a
 // compile-time constant: one case per possible count)
 template <int NCI, int M = PK_RING - 1>
@@ -454,215 +408,17 @@ TSAT_DEV void ring_wait(int l) {
 }
 template <typename real> struct GBwd { acc_t dV1, dV2; int ok; };
 
+// ROW-oriented (riccati_row_step, tsat_device.hpp): the trajectory's 16 lanes are a DPP row, lane j owns column j of F and of S~,
+// and every value another lane holds is read as the `row_newbcast` operand of the FMA that consumes it — no exchange block, no
+// barrier and no re-read of S~ between the steps of a knot; the four trajectories of the pass run the same instructions side by
+// side (a row whose trajectory does not take part in a knot is switched off as a whole). The one-trajectory builds run the very
+// same step function: bit-identical results. S~ lives in the registers of the row across the 16 knots of a pass and in the
+// trajectory's exchange block (as doubles, [r][8]) between passes.
+// Record ring: the records of 12 (8 with float records) of a pass's 16 knots come back from the wavefront's workspace: a slot (one
+// knot of the four trajectories, contiguous) is copied by global_load_lds PK_RING - 1 knots ahead of its use, every copy lane
+// with a fixed role; the wait counts the copy sets issued SINCE — younger loads only, safe whatever the gain stores do.
 template <typename real, int NH>
-TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_GLOBAL real* jw, int kb0, bool need, int N, real rho,
-                                    acc_t dV1, acc_t dV2, int ok_in) {
-  constexpr int ES = (NH == 6) ? 1 : 0;
-  constexpr int NC = NH + 3;
-  constexpr int NP = NH * (NH + 1) / 2;
-  constexpr int RMAX = (NH + 1) / 2;             // rows of the symmetric blocks a lane computes (the column's rows are split in two)
-  constexpr int GX_SINK = GX_S + NP + NH;        // a word of the exchange block nobody reads: target of the lanes without a role
-  static_assert(GX_SINK < GX_QU, "sink word inside the exchange block");
-  real* lds = lds_base<real>();
-  const int lane = TSAT_LANE(), g = lane / PK_BC, j = lane % PK_BC;
-  // Lane roles. Lanes 0 .. NC-1 own the columns of F = [A|B] ("main" lanes: state columns j < NH, control columns after them).
-  // The symmetric blocks need rows i <= c of a state column c: the main lane takes the first (c + 2) / 2 of them and a HELPER
-  // lane (lanes NC .. : columns 1 .. NH-1) the rest — the helper repeats the main lane's W~ column and gain column (same
-  // operations on the same operands, for free: the lanes would idle otherwise) and contributes its rows of Qxx and of S.
-  const bool helper = j >= NC && (j - NC + 1) < NH;
-  const int col = (j < NC) ? j : (helper ? j - NC + 1 : NH - 1);     // column of F this lane works on
-  const bool xmain = j < NH, umain = j >= NH && j < NC;
-  const int cx = (col < NH) ? col : NH - 1;                          // state column (clamped on the control lanes)
-  const int jb = umain ? j - NH : 0;                                 // control column (clamped)
-  const int rmain = (cx + 2) / 2;
-  const int rlo = helper ? rmain : 0, rhi = helper ? cx + 1 : (xmain ? rmain : 0);
-  real* gx = lds + L_GX + g * PK_GXW;
-  const real* Qd = lds + L_GTR + g * PK_GTRW + P_QD;
-  using R = PkRec<ES>;
-  const real* recs = lds + L_GREC + g * R::RECS;                   // this trajectory's record inside a ring slot
-  // copy lanes of the record ring: a slot (the records of one knot of the four trajectories, contiguous) is SLOT / RPU
-  // 16-byte units; unit v belongs to trajectory v / (RECS / RPU). Source of knot q: jw + (trajectory * 16 + q) * RECS.
-  constexpr int UPR = R::RECS / RPU, UPS = R::SLOT / RPU, NCI = (UPS + WAVE - 1) / WAVE;
-  const TSAT_GLOBAL real* cp_src[NCI];
-  bool cp_on[NCI];
-  for (int i = 0; i < NCI; ++i) {
-    const int v = lane + WAVE * i;
-    cp_on[i] = v < UPS;
-    const int vg = cp_on[i] ? v / UPR : 0, ve = cp_on[i] ? v - vg * UPR : 0;
-    cp_src[i] = jw + (size_t)vg * PK_JCH * R::RECS + (size_t)ve * RPU;
-  }
-  auto ring_copy = [&](int q) {          // knot q of the chunk into slot q % PK_RING; every lane with a unit copies, whatever its
-    real* slot = lds + L_GREC + (q & (PK_RING - 1)) * R::SLOT;      // trajectory's state: the count of copies in flight is fixed
-    for (int i = 0; i < NCI; ++i)
-      if (cp_on[i]) glds_put_at<real>(slot + GLDS * i, cp_src[i] + (size_t)q * R::RECS);
-  };
-  // (knots 15 .. 12 of the chunk are in their slots already: their Jacobian lanes wrote them there)
-  const int tmax = a.T - 1;
-  const int traj = (traj0 + g <= tmax) ? traj0 + g : tmax;
-  TSAT_GLOBAL real* KDg = (TSAT_GLOBAL real*)(a.KD + (size_t)traj * kd_stride<real>(a.N));
-  bool ok = ok_in != 0;
-  // per row slot r of this lane: the row i = rlo + r, whether it is one of the lane's rows, where Qxx(i, col) starts from (the
-  // stage Hessian: diag(Qd); error-state mode: diag(Qd[0:3]) on the rates, G'QG of the knot record on the attitude block),
-  // and where S(i, col) goes
-  int ri[RMAX], qq_off[RMAX], s_off[RMAX];
-  bool rv[RMAX];
-  real qdiag[RMAX];
-  for (int r = 0; r < RMAX; ++r) {
-    const int i = (rlo + r < NH) ? rlo + r : NH - 1;
-    ri[r] = i;
-    rv[r] = rlo + r < rhi;
-    qdiag[r] = (i == cx && (!ES || i < 3)) ? Qd[i] : (real)0;
-    const int aa = i - 3, bb = cx - 3;
-    qq_off[r] = (ES && i >= 3 && cx >= i) ? R::QQ + (aa == 0 ? bb : (aa == 1 ? 2 + bb : 5)) : -1;
-    s_off[r] = rv[r] ? GX_S + (i * NH - (i * (i - 1)) / 2 + (cx - i)) : GX_SINK;
-  }
-  // where the control lanes put Quu(a, jb), a <= jb, and Qu(jb)
-  int qu_off[3];
-  for (int aa = 0; aa < 3; ++aa) qu_off[aa] = (umain && aa <= jb) ? GX_QU + ((aa == 0) ? jb : (aa == 1 ? 2 + jb : 5)) : GX_SINK;
-  const int quu_off = umain ? GX_QU + 6 + jb : GX_SINK;
-  const int xk_off = xmain ? GX_XK + j * 6 : GX_SINK;
-  const int ss_off = xmain ? GX_S + NP + j : GX_SINK;
-  real Ss[NP], sv[NH];
-  for (int e = 0; e < NP; ++e) Ss[e] = gx[GX_S + e];
-  for (int m = 0; m < NH; ++m) sv[m] = gx[GX_S + NP + m];
-  for (int l = PK_JCH - 1; l >= 0; --l) {
-    const int k = kb0 + l;
-    bool act = need && ok && k < N - 1;
-    // the record PK_RING - 1 knots ahead starts its way into the slot knot l + 1 has just left
-    if (l >= PK_RING - 1 && l < PK_JCH - 1) ring_copy(l - (PK_RING - 1));
-    // knot l's record was copied PK_RING - 1 steps ago (or written straight into its slot); the copy sets issued since — one
-    // per step, NCI instructions each, none any more once l < PK_RING - 1 — may stay in flight, together with whatever gain
-    // stores were issued behind them: vector-memory operations retire in issue order
-    ring_wait<NCI>(l);
-    const real* rc = recs + (l & (PK_RING - 1)) * R::SLOT;
-    // step 1: column `col` of W~ = [S; s'] F
-    real f[NH], W[NH + 1];
-    lds_row<real, NH, ES>(rc + col * R::FSR, f);
-    for (int r = 0; r < NH; ++r) {
-      real acc = 0;
-      for (int m = 0; m < NH; ++m) acc = fma_(Ss[(r <= m) ? sym_ut(r, m, NH) : sym_ut(m, r, NH)], f[m], acc);
-      W[r] = acc;
-    }
-    {
-      real acc = 0;
-      for (int m = 0; m < NH; ++m) acc = fma_(sv[m], f[m], acc);
-      W[NH] = acc;
-    }
-    // step 2: this lane's rows of column `col` of F'W~ — Qxx(i, col) for its row slots; rows NH + a: Qux(a, col) on a state
-    // column, Quu(a, b) (used for a <= b) on the control lane b; Qu(b) = lu + B(:, b)' s on the control lanes
-    real Qx[RMAX], Qh[3];
-    for (int r = 0; r < RMAX; ++r) {
-      const real ini = rc[(qq_off[r] >= 0) ? qq_off[r] : R::LUU];       // (a finite word of the record when there is no G'QG term)
-      real acc = qdiag[r] + ((qq_off[r] >= 0) ? ini : (real)0);
-      real fi[NH];
-      lds_row<real, NH, ES>(rc + ri[r] * R::FSR, fi);
-      for (int m = 0; m < NH; ++m) acc = fma_(fi[m], W[m], acc);
-      Qx[r] = acc;
-    }
-    for (int aa = 0; aa < 3; ++aa) {
-      const real luu = rc[R::LUU + aa];
-      real acc = (real)0 + ((umain && jb == aa) ? luu : (real)0);
-      real fb[NH];
-      lds_row<real, NH, ES>(rc + (NH + aa) * R::FSR, fb);
-      for (int m = 0; m < NH; ++m) acc = fma_(fb[m], W[m], acc);
-      Qh[aa] = acc;
-    }
-    real Qu;
-    {
-      real acc = (real)0 + rc[R::LU + jb];
-      for (int m = 0; m < NH; ++m) acc = fma_(f[m], sv[m], acc);
-      Qu = acc;
-    }
-    for (int aa = 0; aa < 3; ++aa) role_store(gx, act ? qu_off[aa] : GX_SINK, GX_SINK, Qh[aa]);
-    role_store(gx, act ? quu_off : GX_SINK, GX_SINK, Qu);
-    TSAT_SYNC_LDS();
-    // step 3: regularise, PD test (Sylvester), adjugate inverse, K(:, col) = -Quu_reg^-1 Qux(:, col), d = -Quu_reg^-1 Qu
-    real Kc[3], d[3], qu[3];
-    {
-      const real h00 = gx[GX_QU + 0], h01 = gx[GX_QU + 1], h02 = gx[GX_QU + 2], h11 = gx[GX_QU + 3], h12 = gx[GX_QU + 4],
-                 h22 = gx[GX_QU + 5];
-      for (int c = 0; c < 3; ++c) qu[c] = gx[GX_QU + 6 + c];
-      const real q00 = h00 + rho, q11 = h11 + rho, q22 = h22 + rho;
-      const real q10 = h01, q20 = h02, q21 = h12;
-      const real c00 = dmm_(q11, q22, q21, q21);
-      const real c01 = dmm_(q20, q21, q10, q22);
-      const real c02 = dmm_(q10, q21, q20, q11);
-      const real c11 = dmm_(q00, q22, q20, q20);
-      const real c12 = dmm_(q10, q20, q00, q21);
-      const real c22 = dmm_(q00, q11, q10, q10);
-      const real det = dot3_(q00, c00, q10, c01, q20, c02);
-      const bool pd = (q00 > 0 && c22 > 0 && det > 0);
-      const real nid = -rcp_(det);
-      for (int aa = 0; aa < 3; ++aa) {
-        const real Qi0 = ((aa == 0) ? c00 : (aa == 1 ? c01 : c02)) * nid;
-        const real Qi1 = ((aa == 0) ? c01 : (aa == 1 ? c11 : c12)) * nid;
-        const real Qi2 = ((aa == 0) ? c02 : (aa == 1 ? c12 : c22)) * nid;
-        Kc[aa] = dot3_(Qi0, Qh[0], Qi1, Qh[1], Qi2, Qh[2]);
-        d[aa] = dot3_(Qi0, qu[0], Qi1, qu[1], Qi2, qu[2]);
-      }
-      const int xo = act ? xk_off : GX_SINK;
-      for (int c = 0; c < 3; ++c) { role_store(gx, (xo == GX_SINK) ? GX_SINK : xo + c, GX_SINK, Qh[c]); role_store(gx, (xo == GX_SINK) ? GX_SINK : xo + 3 + c, GX_SINK, Kc[c]); }
-      // K,d record of the knot: lanes 0..6 their gain column (zero beyond NH), lane 7 the feed-forward; stays in flight
-      if (act && j < 8)
-        for (int c = 0; c < 3; ++c) {
-          const real v = (j < NH) ? Kc[c] : ((j == 7) ? d[c] : (real)0);
-          KDg[(size_t)k * KDW + ((j < 7) ? (c * 7 + j) : (21 + c))] = v;
-        }
-      ok = ok && (!act || pd);
-      act = act && ok;
-    }
-    TSAT_SYNC_LDS();
-    // step 4: cost-to-go. With K = -Quu_reg^-1 Qux: Sxx = Qxx + sym(Qux'K) - rho K'K ; Sx = Qx + sym(Qux'd, Qu'K) - rho K'd
-    {
-      const real dqu = dot3_(d[0], qu[0], d[1], qu[1], d[2], qu[2]);
-      dV1 += act ? (acc_t)dqu : (acc_t)0;
-      dV2 -= act ? (acc_t)((real)0.5 * fma_(rho, dot3_(d[0], d[0], d[1], d[1], d[2], d[2]), dqu)) : (acc_t)0;
-      const real* xk = gx + GX_XK;
-      real Sn[RMAX];
-      for (int r = 0; r < RMAX; ++r) {
-        real hk[6];
-        lds_row<real, 6, 1>(xk + ri[r] * 6, hk);
-        const real hi[3] = {hk[0], hk[1], hk[2]}, ki[3] = {hk[3], hk[4], hk[5]};
-        real acc = Qx[r] + (real)0;
-        real sy = 0, kk = 0;
-        for (int c = 0; c < 3; ++c) {
-          sy += fma_(hi[c], Kc[c], Qh[c] * ki[c]);
-          kk = fma_(ki[c], Kc[c], kk);
-        }
-        acc += dmm_((real)0.5, sy, rho, kk);
-        Sn[r] = acc;
-      }
-      real sn;
-      {   // s(col): the same formula with "column 7": hi = Qux(:, col), hj = Qu, ki = K(:, col), kj = d
-        real acc = rc[R::LX + cx] + W[NH];
-        real sy = 0, kk = 0;
-        for (int c = 0; c < 3; ++c) {
-          sy += fma_(Qh[c], d[c], qu[c] * Kc[c]);
-          kk = fma_(Kc[c], d[c], kk);
-        }
-        acc += dmm_((real)0.5, sy, rho, kk);
-        sn = acc;
-      }
-      for (int r = 0; r < RMAX; ++r) role_store(gx, act ? s_off[r] : GX_SINK, GX_SINK, Sn[r]);
-      role_store(gx, act ? ss_off : GX_SINK, GX_SINK, sn);
-    }
-    TSAT_SYNC_LDS();
-    for (int e = 0; e < NP; ++e) Ss[e] = gx[GX_S + e];
-    for (int m = 0; m < NH; ++m) sv[m] = gx[GX_S + NP + m];
-  }
-  GBwd<real> out;
-  out.dV1 = dV1; out.dV2 = dV2; out.ok = ok ? 1 : 0;
-  return out;
-}
-
-// The same recursion ROW-oriented (riccati_row_step, tsat_device.hpp): the trajectory's 16 lanes are a DPP row, lane j owns column j
-// of F and of S~, and every value another lane holds is read as the `row_newbcast` operand of the FMA that consumes it — no exchange
-// block, no barrier and no re-read of S~ between the steps of a knot; the four trajectories of the pass run the same instructions
-// side by side (a row whose trajectory does not take part in a knot is switched off as a whole). The one-trajectory builds run
-// the very same step function: bit-identical results. S~ lives in the registers of the row across the 16 knots of a pass and in
-// the trajectory's exchange block (as doubles, [r][8]) between passes. The record ring is that of riccati_group.
-template <typename real, int NH>
-TSAT_PHASE GBwd<real> riccati_group_rows(const KArgs<real>& a, int traj0, const TSAT_GLOBAL real* jw, int kb0, bool need, int N, real rho_,
+TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_GLOBAL jac_t* jw, int kb0, bool need, int N, real rho_,
                                          acc_t dV1, acc_t dV2, int ok_in) {
   constexpr int ES = (NH == 6) ? 1 : 0;
   real* lds = lds_base<real>();
@@ -673,20 +429,20 @@ TSAT_PHASE GBwd<real> riccati_group_rows(const KArgs<real>& a, int traj0, const 
   static_assert((NH + 1) * 8 <= PK_GXW, "S~ fits the exchange block");
   RowRoles<NH, R> ro;
   ro.template set<real>(j, lds + L_GTR + g * PK_GTRW + P_QD);
-  const real* recs = lds + L_GREC + g * R::RECS;                   // this trajectory's record inside a ring slot
-  constexpr int UPR = R::RECS / RPU, UPS = R::SLOT / RPU, NCI = (UPS + WAVE - 1) / WAVE;
-  const TSAT_GLOBAL real* cp_src[NCI];
+  const jac_t* recs = ring_base() + g * R::RECS;                   // this trajectory's record inside a ring slot
+  constexpr int UPR = R::RECS / RPUJ, UPS = R::SLOT / RPUJ, NCI = (UPS + WAVE - 1) / WAVE;
+  const TSAT_GLOBAL jac_t* cp_src[NCI];
   bool cp_on[NCI];
   for (int i = 0; i < NCI; ++i) {
     const int v = lane + WAVE * i;
     cp_on[i] = v < UPS;
     const int vg = cp_on[i] ? v / UPR : 0, ve = cp_on[i] ? v - vg * UPR : 0;
-    cp_src[i] = jw + (size_t)vg * PK_JCH * R::RECS + (size_t)ve * RPU;
+    cp_src[i] = jw + (size_t)vg * PK_JCH * R::RECS + (size_t)ve * RPUJ;
   }
   auto ring_copy = [&](int q) {
-    real* slot = lds + L_GREC + (q & (PK_RING - 1)) * R::SLOT;
+    jac_t* slot = ring_base() + (q & (PK_RING - 1)) * R::SLOT;
     for (int i = 0; i < NCI; ++i)
-      if (cp_on[i]) glds_put_at<real>(slot + GLDS * i, cp_src[i] + (size_t)q * R::RECS);
+      if (cp_on[i]) glds_put_at<jac_t>(slot + RPUJ * WAVE * i, cp_src[i] + (size_t)q * R::RECS);
   };
   const int tmax = a.T - 1;
   const int traj = (traj0 + g <= tmax) ? traj0 + g : tmax;
@@ -704,17 +460,17 @@ TSAT_PHASE GBwd<real> riccati_group_rows(const KArgs<real>& a, int traj0, const 
     const bool act = need && ok && k < N - 1;
     if (l >= PK_RING - 1 && l < PK_JCH - 1) ring_copy(l - (PK_RING - 1));
     ring_wait<NCI>(l);
-    const real* rc = recs + (l & (PK_RING - 1)) * R::SLOT;
+    const jac_t* rc = recs + (l & (PK_RING - 1)) * R::SLOT;
     double Kc[3], d[3];
 #ifdef TSAT_EMU
     // every emulated lane takes part in the exchanges of the step; a row that does not take part keeps its state
     RowState<NH> st2 = st;
     acc_t v1 = dV1, v2 = dV2;
-    const bool pd = riccati_row_step<NH, R>(st2, row_load<real, NH, R>(rc, ro), ro, rho, Kc, d, v1, v2);
+    const bool pd = riccati_row_step<NH, R>(st2, row_load<jac_t, NH, R>(rc, ro), ro, rho, Kc, d, v1, v2);
     if (act) { st = st2; dV1 = v1; dV2 = v2; }
 #else
     bool pd = true;
-    if (act) pd = riccati_row_step<NH, R>(st, row_load<real, NH, R>(rc, ro), ro, rho, Kc, d, dV1, dV2);
+    if (act) pd = riccati_row_step<NH, R>(st, row_load<jac_t, NH, R>(rc, ro), ro, rho, Kc, d, dV1, dV2);
 #endif
     if (act && j < 8) {      // K,d record of the knot: lanes 0..6 their gain column (zero beyond NH), lane 7 the feed-forward; stays in flight
       TSAT_GLOBAL real* kd = KDg + (size_t)k * KDW;
@@ -933,21 +689,15 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
             terminal_cost_to_go<real, ES>(XUg, u.N, u.mu, tmask);
             TSAT_SYNC_LDS();
             real* gx = lds + L_GX + g * PK_GXW;
-            if constexpr (sizeof(real) == 8) {          // row-oriented recursion: S~ as doubles, [r][8]
+            {          // row-oriented recursion: S~ as doubles, [r][8]
               double* gs = reinterpret_cast<double*>(gx);
               for (int e = lane; e < (NH + 1) * 8; e += WAVE)
                 if ((e & 7) < NH) gs[e] = (double)lds[L_ST + (e >> 3) * 9 + (e & 7)];
-            } else {
-              for (int e = lane; e < NP + NH; e += WAVE) {
-                int i = NH, j = e - NP;
-                if (e < NP) pair_ut(e, NH, i, j);
-                gx[GX_S + e] = lds[L_ST + i * 9 + j];
-              }
             }
             TSAT_SYNC_LDS();
           }
           const bool bneed = in.need != 0;
-          TSAT_GLOBAL real* jw = (TSAT_GLOBAL real*)(a.JW + (size_t)wave * PK_JW_WAVE);
+          TSAT_GLOBAL jac_t* jw = (TSAT_GLOBAL jac_t*)a.JW + (size_t)wave * PK_JW_WAVE;
           const int nch = (nmax - 1 + PK_JCH - 1) / PK_JCH;
           for (int ch = nch - 1; ch >= 0; --ch) {
             const int kb0 = ch * PK_JCH;
@@ -955,8 +705,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
             jacobian16<real, INTEG, DIAGJ, ES>(a, traj0 + t0, jw, kb0, bneed && bw.ok, in.N, in.mu, in.cur);
             TSAT_SYNC();         // the records are in the workspace (vmcnt(0)) before the ring copies read them
             const unsigned long long c1 = tick_();
-            if constexpr (sizeof(real) == 8) bw = riccati_group_rows<real, NH>(a, traj0 + t0, jw, kb0, bneed, in.N, in.rho, bw.dV1, bw.dV2, bw.ok);
-            else bw = riccati_group<real, NH>(a, traj0 + t0, jw, kb0, bneed, in.N, in.rho, bw.dV1, bw.dV2, bw.ok);
+            bw = riccati_group<real, NH>(a, traj0 + t0, jw, kb0, bneed, in.N, in.rho, bw.dV1, bw.dV2, bw.ok);
             TSAT_SYNC();         // every copy has landed and every record has been consumed before the next pass overwrites them
             pc_jac += c1 - c0; pc_ric += tick_() - c1;
           }

@@ -261,6 +261,14 @@ def random_unit_quats(rng, T):
     return q / np.linalg.norm(q, axis=1, keepdims=True)
 
 
+def trajectory_stream(seed, j):
+    """The random stream of GLOBAL trajectory ``j`` of a sweep: a counter-based generator (Philox4x64) keyed by (seed, j), so that
+    what is drawn for a trajectory depends on its index alone — not on the shard it falls into, nor on how many ranks share the
+    sweep (a sharded sweep is the concatenation of the single-GPU results; src/paper_images/heatmap.jl:114-127 draws
+    once per run index i)."""
+    return np.random.Generator(np.random.Philox(key=np.array([int(seed) & 0xFFFFFFFFFFFFFFFF, int(j)], dtype=np.uint64)))
+
+
 # --------------------------------------------------------------------------------------------------
 # BASELINE.json workloads (SURVEY.md §8d table)
 # --------------------------------------------------------------------------------------------------
@@ -278,20 +286,32 @@ def workload_single_slew(N=500):
     return b
 
 
-def workload_monte_carlo(T=1024, N=1000, seed=20190530, random_orbit=False, degenerate_rd=None, tables=True):
+def workload_monte_carlo(T=1024, N=1000, seed=20190530, random_orbit=False, degenerate_rd=None, tables=True, j0=None):
     """configs[1] (and [2] with random_orbit=True): Monte-Carlo of src/monte_carlo.jl:107-198 with the initial
     attitude randomised — q0 uniform on S^3, qf = [sqrt2/2, sqrt2/2, 0, 0] (:114), 1U inertia (:31-33),
     dt 0.2, U0 ~ U(0,1e-3) (:193), Bryson weights alpha = 0.1, beta = 1e3 (:170-176), |u| <= 19 (:179),
-    budget 5 x 10 with dJ_counter_limit 1 (:189-191), SSO i = 96.6 deg (:124)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
+    budget 5 x 10 with dJ_counter_limit 1 (:189-191), SSO i = 96.6 deg (:124).
+    ``j0`` = None: one stream for the batch (the instance depends on ``seed`` and ``T``). ``j0`` = the global index of the batch's
+    first trajectory: every trajectory draws from its own stream keyed by (seed, j0 + i) (``trajectory_stream``) — shards of a
+    sweep built with different ``j0`` / ``T`` concatenate to the same arrays, bit for bit, whatever the number of ranks."""
     dt = 0.2
     a_km = R_EARTH_KM + 400.0
-    q0 = random_unit_quats(rng, T)
     qf = np.array([np.sqrt(2.0) / 2.0, np.sqrt(2.0) / 2.0, 0.0, 0.0])
-    U0 = rng.random((T, N - 1, 3)) / 1000.0
+    if j0 is None:
+        rng = np.random.Generator(np.random.PCG64(seed))
+        q0 = random_unit_quats(rng, T)
+        U0 = rng.random((T, N - 1, 3)) / 1000.0
+        if random_orbit:
+            raan = rng.random(T) * 360.0
+            nu = rng.random(T) * 360.0
+    else:
+        q0 = np.empty((T, 4)); U0 = np.empty((T, N - 1, 3)); raan = np.empty(T); nu = np.empty(T)
+        for i in range(T):
+            g = trajectory_stream(seed, j0 + i)
+            q0[i] = random_unit_quats(g, 1)[0]
+            raan[i], nu[i] = g.random(2) * 360.0
+            U0[i] = g.random((N - 1, 3)) / 1000.0
     if random_orbit:
-        raan = rng.random(T) * 360.0
-        nu = rng.random(T) * 360.0
         # tables = False: placeholders, for callers that attach IGRF tables afterwards (magnetic.attach_igrf_tables)
         B = np.stack([dipole_btable(N, dt, a_km, 96.6, raan[i], nu[i]) for i in range(T)]) if tables else np.zeros((T, 1, 3))
         idx = np.arange(T, dtype=np.int32)
@@ -319,17 +339,21 @@ def workload_inclination_sweep(T=8192, N=1000, seed=20190601, j0=0, T_total=6553
     quaternion_expansion)`` (:154; ``meta["error_state"] = 1``). ``j0`` is the first global index of this shard, ``stride``
     the step between its indices: 1 for a contiguous block of the sweep; ``world`` (with ``j0 = rank``) deals the sweep out
     to the ranks like cards, so that every rank sees every inclination band — the iteration count of a slew depends on the
-    inclination, and contiguous blocks give the ranks unequal work (tools/shard_balance.py)."""
+    inclination, and contiguous blocks give the ranks unequal work (tools/shard_balance.py).
+    RAAN, true anomaly and U0 of global trajectory j come from its own stream keyed by (seed, j) (``trajectory_stream``): the
+    sweep is ONE set of 65536 slews however it is sharded — shards concatenate to the whole, bit for bit."""
     dt = 0.2
     a_km = R_EARTH_KM + 400.0
-    rng = np.random.Generator(np.random.PCG64([seed, j0]))
-    inc = 90.0 * (j0 + stride * np.arange(T) + 0.5) / float(T_total)
-    raan = rng.random(T) * 360.0
-    nu = rng.random(T) * 360.0
+    jg = j0 + stride * np.arange(T)
+    inc = 90.0 * (jg + 0.5) / float(T_total)
+    raan = np.empty(T); nu = np.empty(T); U0 = np.empty((T, N - 1, 3))
+    for i in range(T):
+        g = trajectory_stream(seed, jg[i])
+        raan[i], nu[i] = g.random(2) * 360.0
+        U0[i] = g.random((N - 1, 3)) / 1000.0
     B = np.stack([dipole_btable(N, dt, a_km, inc[i], raan[i], nu[i]) for i in range(T)]) if tables else np.zeros((T, 1, 3))
     q0 = np.repeat(np.array([[0.0, 0.0, 1.0, 0.0]]), T, axis=0)
     qf = np.array([np.sqrt(2.0) / 2.0, np.sqrt(2.0) / 2.0, 0.0, 0.0])
-    U0 = rng.random((T, N - 1, 3)) / 1000.0
     b = make_batch(N, dt, q0, qf[None], INERTIA["1U"], B, np.arange(T, dtype=np.int32), 0.1, 1.0e3, 19.0, U0, r_scale=0.1)
     kep = np.zeros((T, 6))
     kep[:, 1], kep[:, 2], kep[:, 3], kep[:, 5] = a_km, inc, raan, nu
