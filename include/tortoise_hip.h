@@ -271,6 +271,11 @@ int  tsat_set_kernel_variant(tsat_handle* h, int32_t variant);
  * does. For tuning and for the tests. */
 int  tsat_set_endgame(tsat_handle* h, int32_t suspend_at);
 
+/* What the next tsat_batch_run / tsat_mpc_run with options `o` will launch on the reserved batch: *build = 1 wide, 2 dense,
+ * 3 packed, 4 packed8 (of the precision `o` names), *endgame_at = the live count at which a packed launch parks its trajectories
+ * (0: no endgame). For reports (bench.py labels its lines with it); either pointer may be NULL. */
+int  tsat_selected_build(tsat_handle* h, const tsat_options* o, int32_t* build, int32_t* endgame_at);
+
 /* The same tracking for the RESIDENT batch right after tsat_batch_run: reference trajectories, field tables, table
  * clocks, inertias, goal states and per-trajectory horizons are the ones already on the device — nothing of the solve
  * travels back and forth between the two calls (src/monte_carlo.jl:196 -> :230). n_knots / n_tab of `o` are ignored. */

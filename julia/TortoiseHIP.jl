@@ -84,6 +84,13 @@ set_kernel_variant!(s::HIPSolver, v::Integer) =
 set_endgame!(s::HIPSolver, n::Integer) =
     check(s, ccall((:tsat_set_endgame, LIB), Cint, (Ptr{Cvoid}, Int32), s.handle, n), "tsat_set_endgame")
 
+"selected_build(s, o) — (build, endgame_at) the next run launches on the reserved batch: 1 wide, 2 dense, 3 packed, 4 packed8"
+function selected_build(s::HIPSolver, o::Options)
+    b = Ref{Int32}(0); e = Ref{Int32}(0)
+    check(s, ccall((:tsat_selected_build, LIB), Cint, (Ptr{Cvoid}, Ref{Options}, Ref{Int32}, Ref{Int32}), s.handle, o, b, e), "tsat_selected_build")
+    return Int(b[]), Int(e[])
+end
+
 """
 BatchProblem: T independent slews, arrays in the reference's own shapes.
   x0, xf :: 7×T   (ω; q scalar-first — the 8th time state of src/TortoiseSat.jl:124 is dropped)

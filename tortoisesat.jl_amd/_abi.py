@@ -102,6 +102,7 @@ PROTOTYPES = {
     "tsat_batch_trace_download": (C.c_int, [C.c_void_p, _dp]),
     "tsat_set_kernel_variant": (C.c_int, [C.c_void_p, C.c_int32]),
     "tsat_set_endgame": (C.c_int, [C.c_void_p, C.c_int32]),
+    "tsat_selected_build": (C.c_int, [C.c_void_p, C.POINTER(Options), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tsat_tvlqr_resident": (C.c_int, [C.c_void_p, C.POINTER(TvlqrOptions), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p,
                                       C.POINTER(C.c_int64)]),
     "tsat_mpc_run": (C.c_int, [C.c_void_p, C.POINTER(Options), C.c_int32, C.c_int32, _dp, _dp, C.c_void_p, C.POINTER(C.c_float)]),

@@ -414,10 +414,14 @@ bool uses_packed_build(const tsat_handle* h, int precision) { return selected_bu
 // enough to spread the trajectories (the 1 x 3 budget of the receding-horizon loop ends all of them together).
 // One block for both precisions: two counters, then T ids, then T Resume records (sized for doubles).
 struct EndgameArgs { int suspend_at = 0; int *live = nullptr, *susp_n = nullptr, *susp_ids = nullptr; void* susp_state = nullptr; };
-EndgameArgs endgame_args(tsat_handle* h, const tsat_options* o) {
-  EndgameArgs a;
+int endgame_threshold(const tsat_handle* h, const tsat_options* o) {
   int at = h->endgame;
   if (at < 0) at = ((int64_t)o->max_outer * o->max_inner >= 20) ? (int)std::min<int64_t>(2048, h->T / 4) : 0;
+  return at <= 0 ? 0 : (int)std::min<int64_t>(at, h->T);
+}
+EndgameArgs endgame_args(tsat_handle* h, const tsat_options* o) {
+  EndgameArgs a;
+  const int at = endgame_threshold(h, o);
   if (at <= 0) return a;
   const size_t T = (size_t)h->T, ids_at = 16, st_at = (ids_at + T * sizeof(int) + 15) / 16 * 16;
   char* w = (char*)ws_get(h, tsat_handle::WS_ENDGAME, st_at + T * sizeof(Resume<double>));
@@ -467,6 +471,15 @@ int tsat_set_kernel_variant(tsat_handle* h, int32_t variant) {
   if (!(variant >= 0 && variant <= 4))
     return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), 3 (packed, 4 trajectories per wavefront) or 4 (packed, 8)");
   h->variant = variant;
+  return 0;
+}
+
+int tsat_selected_build(tsat_handle* h, const tsat_options* o, int32_t* build, int32_t* endgame_at) {
+  if (!h || !o) return -1;
+  if (h->T <= 0) return fail(h, -1, "tsat_batch_reserve has not been called");
+  const int b = selected_build(h, o->precision);
+  if (build) *build = b;
+  if (endgame_at) *endgame_at = b >= 3 ? endgame_threshold(h, o) : 0;
   return 0;
 }
 

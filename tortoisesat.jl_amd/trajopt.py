@@ -272,6 +272,13 @@ class AugmentedLagrangianSolver:
         (-1 automatic, 0 never): see tsat_set_endgame. Results do not depend on it."""
         self._check(self._lib.tsat_set_endgame(self._h, int(suspend_at)), "tsat_set_endgame")
 
+    def selected_build(self, abi_opts):
+        """(build, endgame_at) the next run with these options launches on the reserved batch: build 1 wide, 2 dense, 3 packed,
+        4 packed8; endgame_at = live count at which a packed launch parks its trajectories (0: none). tsat_selected_build."""
+        b, e = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.tsat_selected_build(self._h, C.byref(abi_opts), C.byref(b), C.byref(e)), "tsat_selected_build")
+        return int(b.value), int(e.value)
+
     # ---- resident-batch API -------------------------------------------------------------------
     def upload(self, batch: SlewBatch, max_linesearch):
         # batch.Btab is None: one table per trajectory, left on the device by the last tsat_btable_batch (magnetic.py, host=False)
