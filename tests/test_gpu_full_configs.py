@@ -143,6 +143,17 @@ def test_gpu_configs3_shard_8192(pkg, ol, solver):
     assert np.array_equal(gs["X"], X[lo:hi]) and np.array_equal(gs["U"], U[lo:hi])
     for f_ in st.dtype.names:            # n_forward counts the sweeps a build executed (64 candidates per sweep there, 16 here)
         assert f_ == "n_forward" or np.array_equal(gs["stats"][f_], st[lo:hi][f_]), f_
+    # The sweep is ONE set of slews however it is sharded (per-trajectory streams keyed by the global index): the two halves of
+    # this shard, built as shards of their own (what each of 16 GPUs would get) and solved separately, are its rows, bit for bit
+    for half in (0, 1):
+        rows = slice(4096 * half, 4096 * (half + 1))
+        hb = _sweep_batch(pkg, solver, 4096, 3 * 8192 + 4096 * half)
+        for f_ in ("x0", "xf", "U0", "Qd", "Qfd", "Rd", "Btab"):
+            assert np.array_equal(getattr(hb, f_), getattr(b, f_)[rows]), f_
+        gh = _gpu(pkg, solver, hb, o)
+        assert np.array_equal(gh["X"], X[rows]) and np.array_equal(gh["U"], U[rows]), half
+        for f_ in st.dtype.names:
+            assert f_ == "n_forward" or np.array_equal(gh["stats"][f_], st[rows][f_]), f_
     # oracle sub-sample
     idx = np.arange(40, T, T // 96)[:96]
     sb = b.slice(0, 1)

@@ -183,3 +183,39 @@ def test_batched_bryson_weights_equal_the_per_trial_functions(pkg):
         ss.bryson_weights_ragged(x0, xf, [2, 40], 0.0, 0.2, ss.INERTIA["1U"], 0.1, 1e3)
     with pytest.raises(ValueError):
         ss.bryson_weights_ragged(x0, x0, [40], 0.0, 0.2, ss.INERTIA["1U"], 0.1, 1e3)
+
+
+def test_sharded_workloads_concatenate_to_the_whole(pkg):
+    """configs[3] / configs[4] instances do not depend on the world size: RAAN, anomaly, q0 and U0 of GLOBAL trajectory j come from
+    a counter-based stream keyed by (seed, j) (slew_setup.trajectory_stream), so shards built with j0 = r T / W for W in {1, 2, 8}
+    concatenate to the same arrays, bit for bit (SURVEY.md §4: sharded sweep = concatenation of the single-GPU results;
+    src/paper_images/heatmap.jl:114-127 draws once per run index)."""
+    import os, sys
+    ss = pkg.slew_setup
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    T, N = 64, 40
+    whole = ss.workload_inclination_sweep(T=T, N=N, j0=0, T_total=T)
+    fields = ("x0", "xf", "U0", "Qd", "Qfd", "Rd", "ulo", "uhi", "dt", "tau0", "dtau", "Jmat")
+    for W in (2, 8):
+        parts = [ss.workload_inclination_sweep(T=T // W, N=N, j0=r * T // W, T_total=T) for r in range(W)]
+        for f in fields:
+            assert np.array_equal(np.concatenate([getattr(q, f) for q in parts]), getattr(whole, f)), (W, f)
+        assert np.array_equal(np.concatenate([q.Btab[q.btab_idx] for q in parts]), whole.Btab[whole.btab_idx]), W
+        assert np.array_equal(np.concatenate([q.meta["kep"] for q in parts]), whole.meta["kep"]), W
+    # a shard does not depend on its neighbours either: another shard size starting at the same global index gives the same head
+    a, b = ss.workload_inclination_sweep(T=8, N=N, j0=24, T_total=T), ss.workload_inclination_sweep(T=16, N=N, j0=24, T_total=T)
+    assert np.array_equal(a.U0, b.U0[:8]) and np.array_equal(a.meta["kep"], b.meta["kep"][:8])
+    # the receding-horizon workload of bench.py --config 4 (4096 trajectories sharded): the same property through its own builder
+    class _S:      # the two attributes mpc_workload touches on a solver
+        class opts:
+            class opts_uncon:
+                dJ_counter_limit = 1
+            @staticmethod
+            def to_abi(N, n_tab, m, error_state=0):
+                return pkg.trajopt.AugmentedLagrangianSolverOptions().to_abi(N, n_tab, m, error_state=error_state)
+    w, _ = bench.mpc_workload(ss, _S, 32, 20, 8, 0, 1)
+    for W in (2, 8):
+        parts = [bench.mpc_workload(ss, _S, 32 // W, 20, 8, r * 32 // W, 1)[0] for r in range(W)]
+        for f in ("x0", "U0", "Qd", "Rd"):
+            assert np.array_equal(np.concatenate([getattr(q, f) for q in parts]), getattr(w, f)), (W, f)
