@@ -30,7 +30,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.path.join(_HERE, "liboracle.so")
+    path = os.environ.get("TSAT_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")      # (another build of the oracle: tools/oracle_self_perturbation.py)
     if not os.path.exists(path):
         build()
     lib = C.CDLL(path)
