@@ -192,7 +192,8 @@ typedef struct tsat_tvlqr_options {
   double  w_tol;            /* 0.05 rad/s   (src/monte_carlo.jl:70)                                           */
   double  angle_tol;        /* 0.08727 rad  (src/monte_carlo.jl:71)                                           */
   int32_t noise_mode;       /* 0: the `noise` array (NULL = noise-free plant); 1: drawn inside the kernel, below */
-  int32_t rate_as_written;  /* statistic: 0 (default) |w| of sample j; 1 the line as the reference has it,
+  int32_t rate_as_written;  /* (a reserved word before version 300: values other than 0 / 1 are rejected — fill the struct with
+                               tsat_tvlqr_default_options first.) statistic: 0 (default) |w| of sample j; 1 the line as the reference has it,
                                `omega_norm_vec[j] = norm(sim_states[i][1:3,i])` (src/monte_carlo.jl:247): for every j the
                                rate of sample i, the 1-based number of the trial (`noise_id` + 1, or the position in the
                                batch + 1) — past the end of a shorter trajectory Julia raises a BoundsError, here the

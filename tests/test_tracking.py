@@ -254,6 +254,24 @@ def test_gpu_tracking_matches_oracle(pkg, ol):
     for tid in (None, np.array([250, 1, 2, 9000, 0], dtype=np.int64)):
         got = tr.attitude_simulation(s, b, r["X"], r["U"], x0s, Qd, Qfd, Rd, noise=nz, rate_as_written=True, trial_ids=tid)
         _same_tracking(ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz, opts=o, noise_ids=tid, nthreads=5), got)
+    # ... with the trial numbers given as noise_ids next to a noise ARRAY (a sharded Monte-Carlo that brings its own noise): they are
+    # the trial numbers all the same — not silently dropped for the position in the batch
+    tid = np.array([250, 1, 2, 9000, 0], dtype=np.int64)
+    got = tr.attitude_simulation(s, b, r["X"], r["U"], x0s, Qd, Qfd, Rd, noise=nz, rate_as_written=True, noise_ids=tid)
+    _same_tracking(ol.tvlqr_batch(b, r["X"], r["U"], Qd, Qfd, Rd, x0s, noise=nz, opts=o, noise_ids=tid, nthreads=5), got)
+    with pytest.raises(ValueError):      # ids that nothing would use
+        tr.attitude_simulation(s, b, r["X"], r["U"], x0s, Qd, Qfd, Rd, noise=nz, noise_ids=tid)
     with pytest.raises(RuntimeError):
         tr.attitude_simulation(s, b, r["X"], r["U"], x0s, Qd, Qfd, Rd, noise=nz, noise_seed=None if False else None, min_steps=-1)
+    # the switch was a reserved word of the options struct before version 300: garbage in it is rejected, not read as "on"
+    import ctypes as C
+    ob = pkg._abi.TvlqrOptions()
+    pkg._abi.load().tsat_tvlqr_default_options(C.byref(ob))
+    ob.n_knots, ob.n_tab, ob.rate_as_written = b.N, b.n_tab, 7
+    st = np.zeros(b.T, dtype=pkg._abi.TVLQR_STATS_DTYPE)
+    d = pkg._abi.as_dp
+    rc = pkg._abi.load().tsat_tvlqr_batch(s._h, C.byref(ob), b.T, b.Btab.shape[0], d(r["X"]), d(r["U"]), d(b.xf), d(b.Btab), pkg._abi.as_ip(b.btab_idx),
+                                         d(b.tau0), d(b.dtau), d(b.dt), d(b.Jmat), d(Qd), d(Qfd), d(Rd), d(x0s), None, None, None, None,
+                                         st.ctypes.data_as(C.c_void_p), pkg._abi.as_ip(np.ascontiguousarray(b.n_knots, dtype=np.int32)), None)
+    assert rc != 0 and b"rate_as_written" in pkg._abi.load().tsat_last_error(s._h)
     s.close()

@@ -219,6 +219,8 @@ inline std::string check_tv_options(const tsat_tvlqr_options& o) {
   if (o.n_tab < 1) return "n_tab must be >= 1";
   if (o.min_steps < 0) return "min_steps must be >= 0";
   if (o.noise_mode != 0 && o.noise_mode != 1) return "noise_mode must be 0 (array / none) or 1 (generated)";
+  if (o.rate_as_written != 0 && o.rate_as_written != 1)
+    return "rate_as_written must be 0 or 1 (the field was a reserved word before version 300: initialise the struct with tsat_tvlqr_default_options)";
   return "";
 }
 

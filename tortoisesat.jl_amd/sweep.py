@@ -136,12 +136,14 @@ class NativeGather:
     hand the 128-byte communicator id from rank 0 to the other ranks and to agree on the outcome of every step of the set-up;
     the gathered arrays land in torch device tensors.
 
-    The set-up is COLLECTIVE and so is its failure: every step that can fail on one rank alone (RCCL not loadable, the id
-    cannot be made, ``ncclCommInitRank`` reports an error, the shards have different shapes) is followed by an agreement
-    (all-reduce MIN of a success flag), and either every rank ends up with a working gatherer or every rank raises
-    ``NativeGatherUnavailable`` having left no collective half-entered — a caller's fallback (``make_gatherer``) then takes
-    the same branch everywhere. A rank deciding on its own would leave the others inside ``dist.broadcast`` or
-    ``ncclCommInitRank``."""
+    The set-up is COLLECTIVE and so is its failure, as far as that can be had: every step that can fail on one rank alone BEFORE
+    the communicator is initialised (RCCL not loadable, the id cannot be made, the shards have different shapes) is followed by
+    an agreement (all-reduce MIN of a success flag), and either every rank goes on or every rank raises
+    ``NativeGatherUnavailable`` having left no collective half-entered — a caller's fallback (``make_gatherer``) then takes the
+    same branch everywhere; a rank deciding on its own would leave the others inside ``dist.broadcast``. Step 4,
+    ``ncclCommInitRank``, is itself the collective: when it RETURNS an error on some rank the same agreement follows, but a rank
+    that dies or raises before entering it leaves its peers blocked inside the call until the NCCL timeout — that failure is
+    not recoverable here (the process group ends with a non-zero exit), and nobody falls back to torch after a partial init."""
 
     def __init__(self, solver, T, N, world, rank, device, mode="full", group=None):
         import torch

@@ -103,8 +103,12 @@ def attitude_simulation(solver, batch: SlewBatch, X, U, x0_sim, Qd, Qfd, Rd, noi
             raise ValueError("give either a noise array or a noise seed")
         o.noise_mode, o.noise_seed = 1, int(noise_seed)
         ids = None if noise_ids is None else np.ascontiguousarray(noise_ids, dtype=np.int64)
+    elif noise_ids is not None and not rate_as_written:
+        raise ValueError("noise_ids key the noise the kernel draws: they need noise_seed (or rate_as_written, whose trial numbers they are)")
     if rate_as_written:
         o.rate_as_written = 1
+        if ids is None and noise_ids is not None:      # the trial numbers, whatever the noise comes from (an array, or none)
+            ids = np.ascontiguousarray(noise_ids, dtype=np.int64)
         if trial_ids is not None:
             if ids is not None and not np.array_equal(ids, np.asarray(trial_ids, dtype=np.int64)):
                 raise ValueError("trial_ids and noise_ids are the same index of the reference's loop: give one, or equal arrays")
