@@ -25,7 +25,7 @@ namespace tsat_emu {
 thread_local int g_lane = 0;
 std::barrier<>* g_bar = nullptr;
 void* g_lds = nullptr;     // one emulated wavefront at a time
-double g_xch[64 * 16];     // scratch of the emulated cross-lane (DPP) reads: 16 doubles per lane
+double g_xch[3 * 64 * 16]; // scratch of the emulated cross-lane (DPP) reads: three blocks of 16 doubles per lane
 int lane() { return g_lane; }
 void sync() { g_bar->arrive_and_wait(); }
 void* lds() { return g_lds; }
@@ -76,7 +76,7 @@ struct Wave {
   int cur = 0, arrived = 0, n_done = 0;
   unsigned gen = 0;
   void* lds = nullptr;
-  double xch[64 * 16] = {};             // scratch of the emulated cross-lane (DPP) reads: 16 doubles per lane
+  double xch[3 * 64 * 16] = {};         // scratch of the emulated cross-lane (DPP) reads: three blocks of 16 doubles per lane
   std::function<void()> body;
   std::unique_ptr<char[]> stacks;
 };

@@ -1525,11 +1525,13 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
 #endif
 template <int NH> struct RowState { double Sc[NH + 1]; };
 #ifdef TSAT_EMU
-// emulator: the DPP reads of a block become one exchange through a scratch block — every lane publishes the registers the block
-// reads across lanes, one barrier, the block's arithmetic in the GPU's operation order, one barrier
-constexpr int XCH_W = 16;
-TSAT_DEV double* xch_mine() { return tsat_emu::xch() + TSAT_LANE() * XCH_W; }
-TSAT_DEV const double* xch_of(int row_lane) { return tsat_emu::xch() + ((TSAT_LANE() & ~15) + row_lane) * XCH_W; }
+// emulator: the DPP reads of a knot become three exchanges through scratch blocks — every lane publishes the registers the
+// following blocks read across lanes, ONE barrier, then the blocks' arithmetic in the GPU's operation order. Three blocks take
+// turns (b = 0, 1, 2): a lane can publish into block b again only after the barriers of the two other exchanges, which every
+// lane reaches only when it has finished reading block b — no second barrier per exchange.
+constexpr int XCH_W = 16, XCH_BLOCK = 64 * XCH_W;
+TSAT_DEV double* xch_mine(int b) { return tsat_emu::xch() + b * XCH_BLOCK + TSAT_LANE() * XCH_W; }
+TSAT_DEV const double* xch_of(int b, int row_lane) { return tsat_emu::xch() + b * XCH_BLOCK + ((TSAT_LANE() & ~15) + row_lane) * XCH_W; }
 #endif
 
 // per-lane constants of riccati_row_step for lane j of a row; Qd: the trajectory's stage weights.
@@ -1594,25 +1596,22 @@ TSAT_DEV bool riccati_row_step(RowState<NH>& st, const RowIn<NH>& in, const RowR
   for (int a = 0; a < 3; ++a) Q[NH + a] = in.luu[a] * ro.mu_[a];
 #ifdef TSAT_EMU
   {
-    double* x = xch_mine();
+    double* x = xch_mine(0);
     for (int r = 0; r <= NH; ++r) x[r] = st.Sc[r];
+    for (int m = 0; m < NH; ++m) x[NH + 1 + m] = f[m];
     tsat_emu::sync();
     for (int r = 0; r < NH; ++r) W[r] = 0;
     for (int m = 0; m < NH; ++m)
-      for (int r = 0; r <= NH; ++r) W[r] = fma_(xch_of(m)[r], f[m], W[r]);
-    tsat_emu::sync();
-    for (int m = 0; m < NH; ++m) x[m] = f[m];
-    tsat_emu::sync();
+      for (int r = 0; r <= NH; ++r) W[r] = fma_(xch_of(0, m)[r], f[m], W[r]);
     for (int m = 0; m < NH; ++m)
-      for (int i = 0; i < NC; ++i) Q[i] = fma_(xch_of(i)[m], W[m], Q[i]);
+      for (int i = 0; i < NC; ++i) Q[i] = fma_(xch_of(0, i)[NH + 1 + m], W[m], Q[i]);
+    double* y = xch_mine(1);
+    for (int a = 0; a < 3; ++a) y[a] = Q[NH + a];
+    y[3] = W[NH];
     tsat_emu::sync();
-    for (int a = 0; a < 3; ++a) x[a] = Q[NH + a];
-    x[3] = W[NH];
-    tsat_emu::sync();
-    h00 = xch_of(NH)[0]; h01 = xch_of(NH + 1)[0]; h02 = xch_of(NH + 2)[0];
-    h11 = xch_of(NH + 1)[1]; h12 = xch_of(NH + 2)[1]; h22 = xch_of(NH + 2)[2];
-    for (int a = 0; a < 3; ++a) qu[a] = xch_of(NH + a)[3];
-    tsat_emu::sync();
+    h00 = xch_of(1, NH)[0]; h01 = xch_of(1, NH + 1)[0]; h02 = xch_of(1, NH + 2)[0];
+    h11 = xch_of(1, NH + 1)[1]; h12 = xch_of(1, NH + 2)[1]; h22 = xch_of(1, NH + 2)[2];
+    for (int a = 0; a < 3; ++a) qu[a] = xch_of(1, NH + a)[3];
   }
 #else
   if constexpr (NH == 6) { TSAT_RB1_6(); TSAT_RB2_6(); TSAT_RB3_6(); }
@@ -1643,12 +1642,11 @@ TSAT_DEV bool riccati_row_step(RowState<NH>& st, const RowIn<NH>& in, const RowR
   for (int c = 0; c < 3; ++c) Tc[c] = fma_(-rho, Kc[c], Q[NH + c]);
 #ifdef TSAT_EMU
   {
-    double* x = xch_mine();
+    double* x = xch_mine(2);
     for (int c = 0; c < 3; ++c) x[c] = Tc[c];
     tsat_emu::sync();
     for (int c = 0; c < 3; ++c)
-      for (int i = 0; i < NH; ++i) Q[i] = fma_(xch_of(i)[c], Kc[c], Q[i]);
-    tsat_emu::sync();
+      for (int i = 0; i < NH; ++i) Q[i] = fma_(xch_of(2, i)[c], Kc[c], Q[i]);
   }
 #else
   if constexpr (NH == 6) { TSAT_RB4_6(); } else { TSAT_RB4_7(); }
