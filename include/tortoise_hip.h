@@ -266,7 +266,7 @@ int  tsat_set_kernel_variant(tsat_handle* h, int32_t variant);
  * running while the rest of the machine is idle. Once at most `suspend_at` trajectories of the batch are still iterating, every
  * wavefront therefore parks its live ones (state in HBM) and ends, and a second kernel, queued behind the first on the same
  * stream, continues each of them on a wavefront of its own.
- *   -1  automatic (default): a quarter of the batch, at most 2048, when max_outer * max_inner >= 20; never otherwise;
+ *   -1  automatic (default): an eighth of the batch, at most 2048, when max_outer * max_inner >= 20; never otherwise;
  *    0  never;  n > 0: at n live trajectories.
  * Results do not depend on it (X, U, K, costs, iteration counts: bit-identical); `n_forward`, the sweeps that were executed,
  * does. For tuning and for the tests. */

@@ -7,7 +7,7 @@ set -e -o pipefail
 OUT=$(realpath -m "${1:-gpurun_out/final}")
 ROOT=$(pwd)
 mkdir -p "$OUT"
-PART="${PART:-AB}"     # A: configs[1], pipeline, experiment, batch sizes; B: configs[2] (fp64, fp32), [3], [4] — one gpurun call each fits 20 minutes
+PART="${PART:-AB}"     # A: configs[1], pipeline, experiment, batch sizes; B: configs[2] (fp64, mixed), [3], [4] — one gpurun call each fits 20 minutes
 if [[ "$PART" == *A* ]]; then
 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 cd /tmp && export TMPDIR=/tmp
@@ -30,8 +30,8 @@ fi
 if [[ "$PART" == *B* ]]; then
 # larger configurations on this one GPU: configs[2] shape in fp64 (packed build) and as quoted (fp32), a configs[3] shard of
 # 8192 trajectories per GPU (what each of 8 GPUs gets), configs[4]; kernel statistics and PMC passes of the fp64 16384 run
-python3 bench.py --config 2 --precision 64 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c2_fp64.json" 2> "$OUT/bench_c2_fp64.err"
-python3 bench.py --config 2 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c2_fp32.json" 2> "$OUT/bench_c2_fp32.err"
+python3 bench.py --config 2 --precision 64 --steps 3 --warmup 1 --cpu-seconds 8 > "$OUT/bench_c2_fp64.json" 2> "$OUT/bench_c2_fp64.err"
+python3 bench.py --config 2 --steps 3 --warmup 1 --cpu-seconds 8 > "$OUT/bench_c2_mixed.json" 2> "$OUT/bench_c2_mixed.err"
 python3 bench.py --config 4 --steps 2 --warmup 1 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
 cd /tmp
 C2="python3 $ROOT/bench.py --config 2 --precision 64 --steps 2 --warmup 1 --no-cpu-baseline --gather none"
@@ -40,16 +40,16 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c2" -o run -- $C2 > /dev/null 2> "$OUT/pmc_write_c2.err"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
   --output-format csv -d "$OUT/pmc_sq_c2" -o run -- $C2 > /dev/null 2> "$OUT/pmc_sq_c2.err"
-# the same four passes for configs[2] as BASELINE.json quotes it (fp32) and for configs[3] (the whole 65536-trajectory sweep on this one GPU)
+# the same four passes for configs[2] as BASELINE.json quotes it (precision = 32: the mixed build) and for configs[3] (the whole 65536-trajectory sweep on this one GPU)
 C2F="python3 $ROOT/bench.py --config 2 --steps 2 --warmup 1 --no-cpu-baseline --gather none"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2f32" -o run -- $C2F > /dev/null 2> "$OUT/stats_c2f32.err"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_c2f32" -o run -- $C2F > /dev/null 2> "$OUT/pmc_fetch_c2f32.err"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c2f32" -o run -- $C2F > /dev/null 2> "$OUT/pmc_write_c2f32.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2mixed" -o run -- $C2F > /dev/null 2> "$OUT/stats_c2mixed.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_c2mixed" -o run -- $C2F > /dev/null 2> "$OUT/pmc_fetch_c2mixed.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c2mixed" -o run -- $C2F > /dev/null 2> "$OUT/pmc_write_c2mixed.err"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
-  --output-format csv -d "$OUT/pmc_sq_c2f32" -o run -- $C2F > /dev/null 2> "$OUT/pmc_sq_c2f32.err"
-echo "configs[2] fp32 passes done" > "$OUT/progress.txt"
+  --output-format csv -d "$OUT/pmc_sq_c2mixed" -o run -- $C2F > /dev/null 2> "$OUT/pmc_sq_c2mixed.err"
+echo "configs[2] mixed passes done" > "$OUT/progress.txt"
 cd "$ROOT"
-python3 bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline --gather none > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"
+python3 bench.py --config 3 --steps 2 --warmup 1 --cpu-seconds 8 --gather none > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"
 cd /tmp
 C3="python3 $ROOT/bench.py --config 3 --steps 1 --warmup 1 --no-cpu-baseline --gather none"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c3" -o run -- $C3 > /dev/null 2> "$OUT/stats_c3.err"
@@ -62,14 +62,15 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY
 echo "configs[3] passes done" >> "$OUT/progress.txt"
 cd "$ROOT"
 python3 tools/straggler_stats.py 8192 > "$OUT/straggler_stats.txt" 2> "$OUT/straggler_stats.err"
-python3 tools/fp32_paths.py 512 > "$OUT/fp32_paths.txt" 2> "$OUT/fp32_paths.err"
-python3 tools/store_probe.py 8192 > "$OUT/store_probe.txt" 2> "$OUT/store_probe.err"
+python3 tools/endgame_sweep.py > "$OUT/endgame_sweep.txt" 2> "$OUT/endgame_sweep.err"
 python3 tools/straggler_timeline.py 8192 0 2048 > "$OUT/straggler_timeline.txt" 2> "$OUT/straggler_timeline.err"
 TSAT_PK_G=4 python3 tools/phase_profile.py 16384 1000 3 1 > "$OUT/phase_clocks_packed.txt" 2> "$OUT/phase_clocks_packed.err"
 TSAT_PK_G=8 python3 tools/phase_profile.py 16384 1000 4 1 > "$OUT/phase_clocks_packed8.txt" 2> "$OUT/phase_clocks_packed8.err"
+TSAT_PK_G=8 python3 tools/phase_profile.py 16384 1000 4 1 32 > "$OUT/phase_clocks_packed8_mixed.txt" 2> "$OUT/phase_clocks_packed8_mixed.err"
 python3 tools/phase_profile.py 16384 1000 2 1 > "$OUT/phase_clocks_dense.txt" 2> "$OUT/phase_clocks_dense.err"
 fi
+tools/ubench/valu_f64 > "$OUT/valu_f64_ubench.txt" 2>&1 || true
 # gpurun copies back at most 64 MiB: report and drop anything large (the summaries need the small CSVs and text files only)
-find "$OUT" -type f -size +2M -exec ls -la {} \; -delete
+find "$OUT" -type f -size +4M -exec ls -la {} \; -delete
 du -sh "$OUT"
 echo done

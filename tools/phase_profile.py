@@ -14,6 +14,7 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 variant = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 0 auto, 1 wide, 2 dense, 3 packed (PK_G trajectories per wave)
 es = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+prec = int(sys.argv[5]) if len(sys.argv) > 5 else 64      # 32: the mixed-precision builds
 base = ss.workload_monte_carlo(T=min(T, 1024), N=N)
 if T > 1024:       # larger batches re-use the 1024 draws (tiling) so that host-side setup stays cheap
     k = T // 1024
@@ -27,6 +28,7 @@ opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = 5
 opts.opts_uncon.iterations = 10; opts.opts_uncon.dJ_counter_limit = 1
 solver = to.AugmentedLagrangianSolver(None, opts)
 o = opts.to_abi(b.N, b.n_tab, 3, error_state=es)
+o.precision = prec
 solver.set_kernel_variant(variant)
 solver.set_endgame(0)     # one kernel: the stamps of a wavefront cover its trajectories from start to end
 solver.upload(b, o.max_linesearch); solver.trace(1)
@@ -35,7 +37,7 @@ tr = solver.trace_download()[:, 0, :]
 nfw = solver.download(want_K=False)["stats"]["n_forward"].astype(float)
 if variant in (3, 4) or (variant == 0 and T >= 3072):   # the packed builds stamp one row per wavefront (its first trajectory): sums over
     tr = tr[::int(os.environ.get("TSAT_PK_G", "4"))]   # its PK_G trajectories
-print(f"T = {T}, variant {variant}, error_state {es}: {len(tr)} stamped wavefronts")
+print(f"T = {T}, variant {variant}, error_state {es}, precision {prec}: {len(tr)} stamped wavefronts")
 it = tr[:, 4]; nb = tr[:, 5]
 tot = tr[:, :4].sum(1)
 print(f"kernel {ms:.2f} ms (stamped build); mean inner its {it.mean():.1f}")

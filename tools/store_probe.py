@@ -1,7 +1,7 @@
 """Developer tool (GPU): stored line-search candidates per sweep of the packed builds against launch time (every stored candidate
 is 80 B per knot and sweep of HBM writes; a winner that was not stored costs its trajectory one more sweep).
 
-    python tools/store_probe.py [T=8192]
+    python tools/store_probe.py [T=8192]        (runs the diagnostic build libtortoise_hip_prof.so: its launches read TSAT_PK_STORE / TSAT_PK_FEW)
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from tsat_loader import load_package
 pkg = load_package()
+pkg._abi.LIB_NAME = os.environ.get("TSAT_PROF_LIB", "libtortoise_hip_prof.so")     # the TSAT_PK_* knobs exist in the diagnostic build only
 from tortoisesat_jl_amd import magnetic as mg, slew_setup as ss, trajopt as to
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 8192

@@ -20,10 +20,22 @@ def one(pattern):
     return g[0]
 
 
+RAW = os.path.join(dst, "raw")
+os.makedirs(RAW, exist_ok=True)
+
+
+def keep_raw(d):
+    """the raw rocprofv3 counter file of a pass, next to its summary (small: one row per dispatch and counter)"""
+    for f in glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True):
+        if os.path.getsize(f) < 4 << 20:
+            shutil.copy(f, os.path.join(RAW, f"{d}_counter_collection.csv"))
+
+
 def counters(d):
     """mean per LAUNCH: a packed launch with an endgame is two kernels (solve + resume, tsat_set_endgame), dispatched equally often"""
     acc, n = {}, {}
     kern = None
+    keep_raw(d)
     with open(one(f"{d}/**/*counter_collection.csv")) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
@@ -50,7 +62,8 @@ for a, b in (("phase_clocks.txt", "phase_clocks_final.txt"), ("pipeline.log", "p
              ("monte_carlo.txt", "monte_carlo_wall.txt"), ("large_batch.txt", "large_batch.txt"), ("mpc_timing.txt", "mpc_timing.txt"), ("stats.json", "bench_under_rocprof.json"),
              ("build_by_batch_size.txt", "build_by_batch_size.txt"), ("fp32_eval.txt", "fp32_eval.txt"), ("phase_clocks_packed.txt", "phase_clocks_packed.txt"),
              ("phase_clocks_packed8.txt", "phase_clocks_packed8.txt"), ("phase_clocks_dense.txt", "phase_clocks_dense.txt"),
-             ("bench_c2_fp64.json", "bench_c2_fp64.json"), ("bench_c2_fp32.json", "bench_c2_fp32.json"), ("bench_c4.json", "bench_c4.json")):
+             ("bench_c2_fp64.json", "bench_c2_fp64.json"), ("bench_c2_mixed.json", "bench_c2_mixed.json"), ("bench_c4.json", "bench_c4.json"),
+             ("phase_clocks_packed8_mixed.txt", "phase_clocks_packed8_mixed.txt"), ("valu_f64_ubench.txt", "valu_f64_ubench.txt"), ("endgame_sweep.txt", "endgame_sweep.txt")):
     if not os.path.exists(os.path.join(src, a)):
         continue
     with open(os.path.join(src, a)) as f:
@@ -97,7 +110,7 @@ def other(tag, bench_file, cfg, stats_csv):
         "algorithmic_bytes_per_launch": b2["roofline"]["algorithmic_bytes_per_launch"],
         "traffic_over_algorithmic": (2 * rd_raw + wr_b) / b2["roofline"]["algorithmic_bytes_per_launch"],
         "hbm_GBs_upper": (2 * rd_raw + wr_b) / (ms * 1e-3) / 1e9,
-        "valu_issue_frac_of_4_cycle_peak": sq["SQ_INSTS_VALU"] / (1024 * 2.4e9 * ms * 1e-3 / 4.0),
+        "valu_issue_frac_of_4_cycle_peak": sq["SQ_INSTS_VALU"] / (1024 * 2.4e9 * ms * 1e-3 / 4.0),      # at the nominal 2.4 GHz; bench.py prices it at the clock the device reports
         "note": "as pmc_summary.json; valu_issue_frac: SQ_INSTS_VALU against one VALU instruction per 4 cycles on each of the 1024 SIMDs at 2.4 GHz",
         "sq": sq,
     }
@@ -107,10 +120,9 @@ def other(tag, bench_file, cfg, stats_csv):
 
 
 other("c2", "bench_c2_fp64.json", 2, "kernel_stats_c2_fp64.csv")
-other("c2f32", "bench_c2_fp32.json", 2, "kernel_stats_c2_fp32.csv")
+other("c2mixed", "bench_c2_mixed.json", 2, "kernel_stats_c2_mixed.csv")
 other("c3", "bench_c3.json", 3, "kernel_stats_c3.csv")
-for a, b in (("bench_c3.json", "bench_c3.json"), ("straggler_stats.txt", "straggler_stats.txt"), ("fp32_paths.txt", "fp32_paths.txt"),
-             ("store_probe.txt", "store_probe.txt"), ("straggler_timeline.txt", "straggler_timeline.txt")):
+for a, b in (("bench_c3.json", "bench_c3.json"), ("straggler_stats.txt", "straggler_stats.txt"), ("straggler_timeline.txt", "straggler_timeline.txt")):
     if os.path.exists(os.path.join(src, a)):
         with open(os.path.join(src, a)) as f:
             keep = [ln for ln in f if not ln.startswith(("W20", "E20", "I20")) and "amdgpu.ids" not in ln]

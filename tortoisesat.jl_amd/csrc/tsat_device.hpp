@@ -1517,8 +1517,9 @@ TSAT_PHASE BwdOut<real> riccati_chunk(TSAT_GLOBAL real* KDg, int k0, int nk, rea
 //   step 3  Quu, Qu to every lane (v_mov_b64_dpp); regularise, Sylvester test, adjugate inverse, K(:, j), d (every lane)
 //   step 4  S(i,j) = Qxx(i,j) + sum_c T[c][i] K[c][j],  s(j) = Qx_j + sum_c T[c][j] d[c],  T = Qux - rho K
 //           (= Qxx + Qux'K - rho K'K: Quu K = -Qux - rho K by the definition of K)
-// S is formed column by column and is symmetric up to rounding only (both triangles are carried); the arithmetic is double
-// whatever the storage type of the records.
+// S is formed column by column (both triangles) and READ through its upper triangle only — S~[r][m] with r > m is taken as row m
+// of lane r's column, the same DPP read with the roles of register and lane exchanged — so the cost-to-go the recursion works
+// with is symmetric to the last bit. The arithmetic is double whatever the storage type of the records.
 // --------------------------------------------------------------------------------------------------
 #ifndef TSAT_EMU
 #include "tsat_riccati_dpp.inc"
@@ -1602,7 +1603,7 @@ TSAT_DEV bool riccati_row_step(RowState<NH>& st, const RowIn<NH>& in, const RowR
     tsat_emu::sync();
     for (int r = 0; r < NH; ++r) W[r] = 0;
     for (int m = 0; m < NH; ++m)
-      for (int r = 0; r <= NH; ++r) W[r] = fma_(xch_of(0, m)[r], f[m], W[r]);
+      for (int r = 0; r <= NH; ++r) W[r] = fma_((r < NH && r > m) ? xch_of(0, r)[m] : xch_of(0, m)[r], f[m], W[r]);
     for (int m = 0; m < NH; ++m)
       for (int i = 0; i < NC; ++i) Q[i] = fma_(xch_of(0, i)[NH + 1 + m], W[m], Q[i]);
     double* y = xch_mine(1);

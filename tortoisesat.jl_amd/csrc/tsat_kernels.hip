@@ -409,14 +409,14 @@ void* packed_workspace(tsat_handle* h) {
 // does the build that (h->variant, batch size, precision) selects need the packed builds' Jacobian workspace a.JW?
 bool uses_packed_build(const tsat_handle* h, int precision) { return selected_build(h, precision) >= 3; }
 
-// Endgame of a packed launch (tsat_packed.hpp, suspend_if_endgame). Automatic: once a quarter of the batch, at most the 2048
+// Endgame of a packed launch (tsat_packed.hpp, suspend_if_endgame). Automatic: once an eighth of the batch (profiles/r04/endgame_sweep.txt), at most the 2048
 // wavefront slots of the machine (256 CUs x 4 SIMDs x 2), is all that still iterates — and only for iteration budgets long
 // enough to spread the trajectories (the 1 x 3 budget of the receding-horizon loop ends all of them together).
 // One block for both precisions: two counters, then T ids, then T Resume records (sized for doubles).
 struct EndgameArgs { int suspend_at = 0; int *live = nullptr, *susp_n = nullptr, *susp_ids = nullptr; void* susp_state = nullptr; };
 int endgame_threshold(const tsat_handle* h, const tsat_options* o) {
   int at = h->endgame;
-  if (at < 0) at = ((int64_t)o->max_outer * o->max_inner >= 20) ? (int)std::min<int64_t>(2048, h->T / 4) : 0;
+  if (at < 0) at = ((int64_t)o->max_outer * o->max_inner >= 20) ? (int)std::min<int64_t>(2048, h->T / 8) : 0;
   return at <= 0 ? 0 : (int)std::min<int64_t>(at, h->T);
 }
 EndgameArgs endgame_args(tsat_handle* h, const tsat_options* o) {
