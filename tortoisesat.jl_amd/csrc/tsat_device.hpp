@@ -223,6 +223,7 @@ struct KArgs {
   // iterating, every wavefront parks its live ones — id and Resume record appended to the lists below — and leaves; a second
   // launch gives each parked trajectory a wavefront of its own in the one-trajectory mapping (tsat_resume_kernel_*).
   int pk_few = 0;               // packed builds: roll-outs kept per sweep while line searches end early (0: PK_FEW; tuning)
+  int pk_probe = 0;             // diagnostic build: the Riccati lanes repeat their gain stores pk_probe times (what a store costs them)
   int suspend_at = 0;           // 0: never
   int* live = nullptr;          // [1] trajectories that have not finished (set to T before the launch)
   int* susp_n = nullptr;        // [1] parked so far
@@ -950,6 +951,22 @@ TSAT_DEV void glds_put_at(real* base, const TSAT_GLOBAL real* src) {
   typedef __attribute__((address_space(1))) const void* gp_t;
   typedef __attribute__((address_space(3))) void* lp_t;
   __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)base, 16, 0, 0);
+#endif
+}
+// BYTES (4 or 16) per lane, global -> LDS, lane-linear from the wave-uniform LDS address `base`: lane l's piece lands at
+// base + BYTES * l. Counted in vmcnt like any load; the emulator copies synchronously.
+template <int BYTES>
+TSAT_DEV void glds_copy(void* base, const TSAT_GLOBAL void* src) {
+  static_assert(BYTES == 4 || BYTES == 16, "LDS-DMA piece sizes used here");
+#ifdef TSAT_EMU
+  unsigned char* d = reinterpret_cast<unsigned char*>(base) + BYTES * TSAT_LANE();
+  const unsigned char* q = reinterpret_cast<const unsigned char*>(src);
+  for (int i = 0; i < BYTES; ++i) d[i] = q[i];
+#else
+  typedef __attribute__((address_space(1))) const void* gp_t;
+  typedef __attribute__((address_space(3))) void* lp_t;
+  if constexpr (BYTES == 4) __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)base, 4, 0, 0);      // (the size must be a literal)
+  else __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)base, 16, 0, 0);
 #endif
 }
 // the three field rows of step kk of a staged chunk (rows at tau, tau + dtau/2, tau + dtau)

@@ -75,6 +75,7 @@ static_assert(L_FWD + PK_NBUF * PK_FB <= LDS_REALS, "packed forward buffers fit 
 //                    trajectories side by side: the results are bit-identical to the one-trajectory builds.
 constexpr int PK_JCH = 16;                        // knots per trajectory and Jacobian pass (= lanes per trajectory)
 constexpr int PK_RING = (sizeof(jac_t) == 8) ? 4 : 8;      // knots of every trajectory resident in LDS during the recursion (20 KB: 4 double records, 8 float ones)
+constexpr int PK_CPB = 16;                        // bytes per lane of a ring copy instruction (riccati_group)
 constexpr int PK_BC = 16;                         // lanes per trajectory in a backward pass
 constexpr int PK_BG = WAVE / PK_BC;               // trajectories per backward pass (4); a wave of PK_G trajectories takes PK_G / PK_BG passes
 static_assert(PK_G % PK_BG == 0 && PK_JCH == PK_BC, "Jacobian lanes: the 16 lanes of a trajectory linearise 16 knots");
@@ -390,7 +391,7 @@ TSAT_PHASE void jacobian16(const KArgs<real>& a, int traj0, TSAT_GLOBAL jac_t* j
   // ring slot in LDS; the others go through the workspace (one code path for both: a generic pointer, flat stores)
   using R = PkRec<ES>;
   jac_t* rc = (kk >= PK_JCH - PK_RING) ? ring_base() + (kk & (PK_RING - 1)) * R::SLOT + g * R::RECS
-                                       : (jac_t*)(jw + (size_t)(g * PK_JCH + kk) * R::RECS);
+                                       : (jac_t*)(jw + (size_t)(kk * PK_BG + g) * R::RECS);      // workspace: [knot][trajectory][record], a ring slot contiguous
   real qn[4];
   for (int i = 0; i < 4; ++i) qn[i] = xu[XUW + 3 + i];
   knot_record<real, INTEG, DIAGJ, ES, jac_t*>(tr, x, u, lam, b0, b1, b2, qn, mu, rc);
@@ -430,19 +431,21 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
   RowRoles<NH, R> ro;
   ro.template set<real>(j, lds + L_GTR + g * PK_GTRW + P_QD);
   const jac_t* recs = ring_base() + g * R::RECS;                   // this trajectory's record inside a ring slot
-  constexpr int UPR = R::RECS / RPUJ, UPS = R::SLOT / RPUJ, NCI = (UPS + WAVE - 1) / WAVE;
-  const TSAT_GLOBAL jac_t* cp_src[NCI];
-  bool cp_on[NCI];
-  for (int i = 0; i < NCI; ++i) {
-    const int v = lane + WAVE * i;
-    cp_on[i] = v < UPS;
-    const int vg = cp_on[i] ? v / UPR : 0, ve = cp_on[i] ? v - vg * UPR : 0;
-    cp_src[i] = jw + (size_t)vg * PK_JCH * R::RECS + (size_t)ve * RPUJ;
-  }
+  // Copy lanes of the record ring. A slot (one knot of the pass's four trajectories) is contiguous in the workspace as it is in
+  // LDS ([knot][trajectory][record]): NCI copy instructions of PK_CPB bytes per lane, lane-linear. The wait below may only
+  // count younger LOADS (M x NCI of them) while vmcnt counts the gain stores of the knots in between as well: with three 16-byte
+  // copies per knot the window is 9 operations in the double builds (14 with float records). A perturbation experiment
+  // (profiles/r04/kstore_probe.txt: three MORE stores per knot add 1000 cycles per trajectory and knot) shows where that window
+  // saturates; as built it does not: widening it to 27 with nine 4-byte copies per knot (PK_CPB = 4) changed nothing in the packed
+  // build and cost the packed8 build 250 cycles per trajectory and knot in copy instructions.
+  constexpr int SLOT_BYTES = R::SLOT * (int)sizeof(jac_t), NCI = (SLOT_BYTES + WAVE * PK_CPB - 1) / (WAVE * PK_CPB);
+  static_assert((PK_RING - 1) * NCI <= 63, "the wait count fits vmcnt");
+  const TSAT_GLOBAL unsigned char* cp_src = reinterpret_cast<const TSAT_GLOBAL unsigned char*>(jw) + PK_CPB * lane;
   auto ring_copy = [&](int q) {
-    jac_t* slot = ring_base() + (q & (PK_RING - 1)) * R::SLOT;
+    unsigned char* slot = reinterpret_cast<unsigned char*>(ring_base() + (q & (PK_RING - 1)) * R::SLOT);
+    const TSAT_GLOBAL unsigned char* src = cp_src + (size_t)q * SLOT_BYTES;
     for (int i = 0; i < NCI; ++i)
-      if (cp_on[i]) glds_put_at<jac_t>(slot + RPUJ * WAVE * i, cp_src[i] + (size_t)q * R::RECS);
+      if (PK_CPB * (lane + WAVE * i) < SLOT_BYTES) glds_copy<PK_CPB>(slot + PK_CPB * WAVE * i, src + PK_CPB * WAVE * i);
   };
   const int tmax = a.T - 1;
   const int traj = (traj0 + g <= tmax) ? traj0 + g : tmax;
@@ -475,6 +478,10 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
     if (act && j < 8) {      // K,d record of the knot: lanes 0..6 their gain column (zero beyond NH), lane 7 the feed-forward; stays in flight
       TSAT_GLOBAL real* kd = KDg + (size_t)k * KDW;
       for (int c = 0; c < 3; ++c) kd[slot_[c]] = (real)fma_(Kc[c], km, d[c] * dm);
+#ifdef TSAT_PROFILE
+      for (int rep = 0; rep < a.pk_probe; ++rep)      // perturbation experiment: the same stores again (same values, same addresses)
+        for (int c = 0; c < 3; ++c) ((volatile TSAT_GLOBAL real*)kd)[slot_[c]] = (real)fma_(Kc[c], km, d[c] * dm);
+#endif
     }
     ok = ok && (!act || pd);
   }
