@@ -10,14 +10,21 @@ mkdir -p "$OUT"
 PART="${PART:-AB}"     # A: configs[1], pipeline, experiment, batch sizes; B: configs[2] (fp64, mixed), [3], [4] — one gpurun call each fits 20 minutes
 if [[ "$PART" == *A* ]]; then
 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+fi
+if [[ "$PART" == *A* || "$PART" == *P* ]]; then      # P: the rocprofv3 passes of configs[1] alone
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+# (the profiled runs are the headline alone: --no-other-configs keeps the packed / mixed / receding-horizon launches of the default line out of them)
+B="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $B > "$OUT/stats.json" 2> "$OUT/stats.err"
-B2="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --gather none"
+B2="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --gather none"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- $B2 > /dev/null 2> "$OUT/pmc_fetch.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o run -- $B2 > /dev/null 2> "$OUT/pmc_write.err"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
   --output-format csv -d "$OUT/pmc_sq" -o run -- $B2 > /dev/null 2> "$OUT/pmc_sq.err"
+cd "$ROOT"
+fi
+if [[ "$PART" == *A* ]]; then
+cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pipeline" -o run -- python3 $ROOT/tools/pipeline_timing.py > "$OUT/pipeline.log" 2> "$OUT/pipeline.err"
 cd "$ROOT"
 python3 tools/phase_profile.py 1024 1000 1 1 > "$OUT/phase_clocks.txt" 2> "$OUT/phase_clocks.err"

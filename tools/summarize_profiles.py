@@ -40,7 +40,8 @@ def counters(d):
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
             kind = "solve" if "tsat_solve_kernel" in name else ("resume" if "tsat_resume_kernel" in name else None)
-            if kind is None:
+            # the timed configuration only — rk3, isotropic inertia, quaternion hooks on — not the hooks-off launches of `other_mode`
+            if kind is None or "3, 2, 1>" not in name:
                 continue
             k = (kind, r["Counter_Name"])
             acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])

@@ -223,7 +223,6 @@ struct KArgs {
   // iterating, every wavefront parks its live ones — id and Resume record appended to the lists below — and leaves; a second
   // launch gives each parked trajectory a wavefront of its own in the one-trajectory mapping (tsat_resume_kernel_*).
   int pk_few = 0;               // packed builds: roll-outs kept per sweep while line searches end early (0: PK_FEW; tuning)
-  int pk_probe = 0;             // diagnostic build: the Riccati lanes repeat their gain stores pk_probe times (what a store costs them)
   int suspend_at = 0;           // 0: never
   int* live = nullptr;          // [1] trajectories that have not finished (set to T before the launch)
   int* susp_n = nullptr;        // [1] parked so far

@@ -53,7 +53,6 @@ hipError_t TSAT_PK_NAME(tsat_launch_solve_packed)(const KArgs<double>& a, int rk
 #ifdef TSAT_PROFILE   // tuning knobs of the diagnostic build only (tools/store_probe.py): the product's launches do not read the environment
   if (const char* e = getenv("TSAT_PK_STORE")) { const int v = atoi(e); if (v >= 1 && v < b.max_ls) b.max_ls = v; }
   if (const char* e = getenv("TSAT_PK_FEW")) { const int v = atoi(e); if (v >= 1) b.pk_few = v; }
-  if (const char* e = getenv("TSAT_PK_PROBE")) b.pk_probe = atoi(e);
 #endif
   static const kern_t resume[2][3][2] = {
       {{TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 3, 0, 0>, TSAT_PK_NAME(tsat_resume_kernel_packed)<double, 3, 0, 1>},

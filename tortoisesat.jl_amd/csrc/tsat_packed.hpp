@@ -435,7 +435,7 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
   // LDS ([knot][trajectory][record]): NCI copy instructions of PK_CPB bytes per lane, lane-linear. The wait below may only
   // count younger LOADS (M x NCI of them) while vmcnt counts the gain stores of the knots in between as well: with three 16-byte
   // copies per knot the window is 9 operations in the double builds (14 with float records). A perturbation experiment
-  // (profiles/r04/kstore_probe.txt: three MORE stores per knot add 1000 cycles per trajectory and knot) shows where that window
+  // (profiles/r04/kstore_probe.txt — a scratch diagnostic build that issued the gain stores of a knot n more times: three MORE stores per knot add 1000 cycles per trajectory and knot) shows where that window
   // saturates; as built it does not: widening it to 27 with nine 4-byte copies per knot (PK_CPB = 4) changed nothing in the packed
   // build and cost the packed8 build 250 cycles per trajectory and knot in copy instructions.
   constexpr int SLOT_BYTES = R::SLOT * (int)sizeof(jac_t), NCI = (SLOT_BYTES + WAVE * PK_CPB - 1) / (WAVE * PK_CPB);
@@ -478,10 +478,6 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
     if (act && j < 8) {      // K,d record of the knot: lanes 0..6 their gain column (zero beyond NH), lane 7 the feed-forward; stays in flight
       TSAT_GLOBAL real* kd = KDg + (size_t)k * KDW;
       for (int c = 0; c < 3; ++c) kd[slot_[c]] = (real)fma_(Kc[c], km, d[c] * dm);
-#ifdef TSAT_PROFILE
-      for (int rep = 0; rep < a.pk_probe; ++rep)      // perturbation experiment: the same stores again (same values, same addresses)
-        for (int c = 0; c < 3; ++c) ((volatile TSAT_GLOBAL real*)kd)[slot_[c]] = (real)fma_(Kc[c], km, d[c] * dm);
-#endif
     }
     ok = ok && (!act || pd);
   }
