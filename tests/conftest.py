@@ -153,6 +153,24 @@ def emu_packed8(pkg):
 
 
 @pytest.fixture(scope="session")
+def emu_packed8w(pkg):
+    """eight trajectories per wavefront at one wavefront per SIMD: twelve-knot record ring, double-buffered forward chunks (tsat_kernels_packed8w.hip)"""
+    return Emu(pkg._abi, "libtsat_emu_packed8w.so")
+
+
+@pytest.fixture(scope="session")
+def emu_packed16w(pkg):
+    """sixteen trajectories per wavefront, four line-search candidates each (tsat_kernels_packed16w.hip)"""
+    return Emu(pkg._abi, "libtsat_emu_packed16w.so")
+
+
+@pytest.fixture(scope="session")
+def emu_packed16w_mixed(pkg):
+    """the mixed-precision sixteen-per-wavefront build: all sixteen knots of a pass in the record ring (tsat_kernels_packed16w_mixed.hip)"""
+    return Emu(pkg._abi, "libtsat_emu_packed16w_mixed.so")
+
+
+@pytest.fixture(scope="session")
 def emu_packed_mixed(pkg):
     """the mixed-precision packed build (tsat_kernels_packed_mixed.hip)"""
     return Emu(pkg._abi, "libtsat_emu_packed_mixed.so")

@@ -41,6 +41,36 @@ def test_packed8_build_is_the_same_solve(pkg, ol, emu, emu_packed8, T, N, es, in
     _same_bits(wide, packed)
 
 
+@pytest.mark.parametrize("which,T,N,es,integ", [("emu_packed8w", 11, 34, 1, 3), ("emu_packed8w", 19, 40, 0, 4), ("emu_packed16w", 19, 40, 1, 3),
+                                                ("emu_packed16w", 35, 21, 0, 3)])
+def test_one_wavefront_per_simd_builds_are_the_same_solve(pkg, ol, request, emu, which, T, N, es, integ):
+    """eight and sixteen trajectories per wavefront at one wavefront per SIMD (40 KB of LDS: a twelve-knot record ring whose slots
+    are taken modulo twelve, double-buffered forward chunks; sixteen: four line-search candidates per trajectory and sweep, so
+    deeper searches go on in further sweeps): ragged horizons, partial last wavefronts, a diverging roll-out and an indefinite
+    Quu next to healthy trajectories — bit-identical to the wide build, equal to the oracle"""
+    e = request.getfixturevalue(which)
+    assert 20480 < e.lib.emu_lds_bytes() <= 40960            # one wavefront per SIMD
+    b = pkg.slew_setup.workload_monte_carlo(T=T, N=N, seed=500 + 7 * T + N, random_orbit=(T == 11))
+    nk = [N, 2, max(3, N // 2), N - 1, 3, N, N - 2, 7, N, N, 5, N, 4, N, N, 9, N, N, 6, N, N - 1, 3, N, N, N // 2, N, 8, N, N, 2, N, N, N, 5, N]
+    b.n_knots = np.array(nk[:T], dtype=np.int32)
+    kw = {}
+    if T == 19:
+        b.U0[1] = 1e12
+        b.Rd[3] = -1e-4
+        kw = dict(reg_max=1e-2)
+    o = oracle_options(ol, max_outer=2, max_inner=4, dj_counter_limit=1, error_state=es, integrator=integ, **kw)
+    wide, packed = emu.solve(b, o), e.solve(b, o)
+    _same_bits(wide, packed)
+    if T != 19:
+        assert_same_solution(ol.solve_batch(b, o), packed)
+    else:
+        assert np.array_equal(ol.solve_batch(b, o)["stats"]["status"], packed["stats"]["status"])
+    if which == "emu_packed16w":          # a search deeper than the four candidates of a sweep
+        b2 = pkg.slew_setup.workload_monte_carlo(T=5, N=36, seed=9)
+        o3 = oracle_options(ol, max_outer=2, max_inner=3, ls_lower=0.999999, ls_upper=1.000001, max_linesearch=20)
+        _same_bits(emu.solve(b2, o3), e.solve(b2, o3))
+
+
 @pytest.mark.parametrize("es", [0, 1])
 def test_packed_build_ragged_groups(pkg, ol, emu, emu_packed, es):
     """every trajectory of a group has its own horizon (t_total[i] = 0:0.2:t_final[i], src/monte_carlo.jl:140-145)"""
@@ -84,7 +114,8 @@ def test_packed_build_mixed_fates_in_one_group(pkg, ol, emu, emu_packed):
 
 
 @pytest.mark.parametrize("which,T,N,at", [("emu_packed", 11, 33, 6), ("emu_packed", 7, 20, 100), ("emu_packed8", 19, 21, 9),
-                                          ("emu_packed_mixed", 10, 30, 5)])
+                                          ("emu_packed_mixed", 10, 30, 5), ("emu_packed8w", 19, 21, 9), ("emu_packed16w", 37, 21, 12),
+                                          ("emu_packed16w_mixed", 21, 30, 6)])
 def test_packed_endgame_is_the_same_solve(pkg, ol, request, monkeypatch, which, T, N, at):
     """tsat_set_endgame: once `at` trajectories are left, the wavefronts park theirs and a second launch finishes each on a
     wavefront of its own (tsat_resume_kernel_packed). Which ones get parked depends on how the waves were scheduled — here: on
@@ -92,11 +123,11 @@ def test_packed_endgame_is_the_same_solve(pkg, ol, request, monkeypatch, which, 
     (ragged horizons, a diverging rollout, a regularisation failure), also when everything is parked at once (at >= T)."""
     e = request.getfixturevalue(which)
     b = pkg.slew_setup.workload_monte_carlo(T=T, N=N, seed=900 + T, random_orbit=True)
-    b.n_knots = np.array([N, 4, N - 3, N, 9, N, N // 2, N, 2, N, N - 1, N, N, 6, N, N, 3, N, N][:T], dtype=np.int32)
+    b.n_knots = np.array(([N, 4, N - 3, N, 9, N, N // 2, N, 2, N, N - 1, N, N, 6, N, N, 3, N, N] * 2)[:T], dtype=np.int32)
     b.U0[1] = 1e12
     b.Rd[3] = -1e-4
     o = oracle_options(ol, max_outer=3, max_inner=5, dj_counter_limit=1, error_state=T % 2, reg_max=1e-2)
-    if which == "emu_packed_mixed":
+    if which.endswith("_mixed"):
         o.precision = 32
     monkeypatch.delenv("TSAT_EMU_SUSPEND_AT", raising=False)
     plain = e.solve(b, o)
@@ -127,12 +158,14 @@ def test_mixed_build_against_the_fp64_oracle(pkg, ol, emu_mixed):
         np.testing.assert_allclose(got["stats"]["cost"], ref["stats"]["cost"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("T,N,es", [(5, 37, 1), (4, 26, 0)])
-def test_mixed_packed_build_is_the_mixed_solve(pkg, ol, emu_mixed, emu_packed_mixed, T, N, es):
-    """precision = 32 on large batches takes the packed mixed build: bit-identical to the one-trajectory mixed build"""
-    assert emu_packed_mixed.lib.emu_lds_bytes() <= 20480            # two wavefronts per SIMD
+@pytest.mark.parametrize("which,T,N,es", [("emu_packed_mixed", 5, 37, 1), ("emu_packed_mixed", 4, 26, 0), ("emu_packed16w_mixed", 5, 37, 1), ("emu_packed16w_mixed", 18, 26, 0)])
+def test_mixed_packed_build_is_the_mixed_solve(pkg, ol, request, emu_mixed, which, T, N, es):
+    """precision = 32 on large batches takes the packed mixed builds: bit-identical to the one-trajectory mixed build (sixteen per
+    wavefront at one wavefront per SIMD: all sixteen knots of a pass in the record ring, nothing through the workspace)"""
+    emu_packed_mixed = request.getfixturevalue(which)
+    assert emu_packed_mixed.lib.emu_lds_bytes() <= (20480 if which == "emu_packed_mixed" else 40960)
     b = pkg.slew_setup.workload_monte_carlo(T=T, N=N, seed=900 + N)
-    b.n_knots = np.array([N, max(2, N // 3), N - 1, N, 5][:T], dtype=np.int32)
+    b.n_knots = np.array(([N, max(2, N // 3), N - 1, N, 5] * 4)[:T], dtype=np.int32)
     o = oracle_options(ol, max_outer=3, max_inner=4, dj_counter_limit=1, error_state=es)
     o.precision = 32
     _same_bits(emu_mixed.solve(b, o), emu_packed_mixed.solve(b, o))

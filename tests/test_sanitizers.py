@@ -51,7 +51,7 @@ def test_oracle_is_clean_under_asan_and_ubsan(oracle_run):
     assert "mpc X" in out
 
 
-@pytest.mark.parametrize("exe", ["emu_tsan", "emu_tsan_dense", "emu_tsan_packed", "emu_tsan_packed8", "emu_tsan_packed_mixed", "emu_tsan_mixed"])
+@pytest.mark.parametrize("exe", ["emu_tsan", "emu_tsan_dense", "emu_tsan_packed", "emu_tsan_packed8", "emu_tsan_packed8w", "emu_tsan_packed_mixed", "emu_tsan_mixed"])
 def test_emulated_kernels_are_race_free_under_tsan(exe, oracle_run):
     _build(exe)
     rc, out, err = _run(exe, {"TSAN_OPTIONS": "halt_on_error=0:report_signal_unsafe=0"})

@@ -35,7 +35,7 @@ solver.upload(b, o.max_linesearch); solver.trace(1)
 ms = solver.run(o); ms = solver.run(o)
 tr = solver.trace_download()[:, 0, :]
 nfw = solver.download(want_K=False)["stats"]["n_forward"].astype(float)
-if variant in (3, 4) or (variant == 0 and T >= 3072):   # the packed builds stamp one row per wavefront (its first trajectory): sums over
+if variant >= 3 or (variant == 0 and T >= 3072):   # the packed builds stamp one row per wavefront (its first trajectory): sums over
     tr = tr[::int(os.environ.get("TSAT_PK_G", "4"))]   # its PK_G trajectories
 print(f"T = {T}, variant {variant}, error_state {es}, precision {prec}: {len(tr)} stamped wavefronts")
 it = tr[:, 4]; nb = tr[:, 5]
@@ -44,10 +44,10 @@ print(f"kernel {ms:.2f} ms (stamped build); mean inner its {it.mean():.1f}")
 for i, name in enumerate(("forward sweep", "jacobian lanes", "riccati", "parallel passes")):
     print(f"  {name:16s}: {tr[:, i].mean()/1e6:8.2f} Mcycles/wave  ({100*tr[:, i].sum()/tot.sum():5.1f} %)  "
           f"per iteration {np.mean(tr[:, i]/np.maximum(it,1))/1e3:8.1f} kcycles; per knot-iteration {np.mean(tr[:, i]/np.maximum(it,1))/N:7.1f} cycles")
-if variant in (3, 4) or (variant == 0 and T >= 3072):
+if variant >= 3 or (variant == 0 and T >= 3072):
     for i, name in ((6, "of the passes: copy of the accepted roll-out + gradient"), (7, "of the passes: end of an inner loop (duals, penalty, next outer)")):
         print(f"  {name:66s}: per knot-iteration {np.mean(tr[:, i]/np.maximum(it,1))/N:7.1f} cycles")
-if variant in (3, 4) or (variant == 0 and T >= 3072):   # a sweep serves the whole wavefront: cycles per sweep and knot of the WAVE
+if variant >= 3 or (variant == 0 and T >= 3072):   # a sweep serves the whole wavefront: cycles per sweep and knot of the WAVE
     G = int(os.environ.get("TSAT_PK_G", "4"))
     sw = nfw.reshape(-1, G).max(1)
     print(f"  forward sweep, per executed sweep of a wavefront and knot: {np.mean(tr[:, 0] / np.maximum(sw, 1)) / N:7.1f} cycles ({sw.mean():.1f} sweeps per wavefront)")

@@ -113,6 +113,28 @@ TEST_END
 TEST_BEGIN(rsq_dep1)
 asm volatile(".rept " STR(REPT) "\n .rept 8\n v_rsq_f64 %0, %0\n .endr\n.endr" : "+v"(a0));
 TEST_END
+// dependency distance: N interleaved chains for N = 5, 6, 7 (where does the one-cycle penalty of a dependent FMA end?)
+TEST_BEGIN(fma_dep5)
+asm volatile(".rept " STR(REPT) "\n v_fma_f64 %0, %0, %5, %6\n v_fma_f64 %1, %1, %5, %6\n v_fma_f64 %2, %2, %5, %6\n v_fma_f64 %3, %3, %5, %6\n v_fma_f64 %4, %4, %5, %6\n.endr"
+             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : "v"(x), "v"(y));
+TEST_END
+TEST_BEGIN(fma_dep6)
+asm volatile(".rept " STR(REPT) "\n v_fma_f64 %0, %0, %6, %7\n v_fma_f64 %1, %1, %6, %7\n v_fma_f64 %2, %2, %6, %7\n v_fma_f64 %3, %3, %6, %7\n v_fma_f64 %4, %4, %6, %7\n v_fma_f64 %5, %5, %6, %7\n.endr"
+             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : "v"(x), "v"(y));
+TEST_END
+TEST_BEGIN(fma_dep8)
+asm volatile(".rept " STR(REPT) "\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"
+             " v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n.endr"
+             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y));
+TEST_END
+// the dependent operand as src2 (the accumulator of an fmac) instead of src0
+TEST_BEGIN(fmac_acc_dep1)
+asm volatile(".rept " STR(REPT) "\n .rept 8\n v_fmac_f64 %0, %1, %2\n .endr\n.endr" : "+v"(a0) : "v"(x), "v"(y));
+TEST_END
+// a dependent FMA followed by an independent one, alternating (half of the instructions pay the penalty?)
+TEST_BEGIN(fma_dep_alt)
+asm volatile(".rept " STR(REPT) "\n .rept 4\n v_fma_f64 %0, %0, %2, %3\n v_fma_f64 %1, %2, %3, %2\n .endr\n.endr" : "+v"(a0), "+v"(a1) : "v"(x), "v"(y));
+TEST_END
 // fp32 FMA for comparison
 __global__ __launch_bounds__(64) void fma32_indep8(double* out, unsigned long long* cyc, int iters) {
   const int l = threadIdx.x;
@@ -180,6 +202,8 @@ int main() {
   const T tests[] = {
     {"v_fma_f64, 8 independent accumulators", fma_indep8, 8}, {"v_fma_f64, one dependent chain", fma_dep1, 8},
     {"v_fma_f64, 2 interleaved chains", fma_dep2, 8}, {"v_fma_f64, 4 interleaved chains", fma_dep4, 8},
+    {"v_fma_f64, 5 interleaved chains", fma_dep5, 5}, {"v_fma_f64, 6 interleaved chains", fma_dep6, 6}, {"v_fma_f64, 8 interleaved chains (dependent through src0)", fma_dep8, 8},
+    {"v_fmac_f64, one chain through the accumulator (src2)", fmac_acc_dep1, 8}, {"v_fma_f64, dependent / independent alternating", fma_dep_alt, 8},
     {"v_mul_f64, one dependent chain", mul_dep1, 8}, {"v_add_f64, one dependent chain", add_dep1, 8},
     {"v_fmac_f64_dpp row_newbcast, 8 independent", fmac_dpp_indep8, 8}, {"v_fmac_f64_dpp row_newbcast, one accumulator chain", fmac_dpp_dep1, 8},
     {"v_mul_f64 -> s_nop 1 -> v_fmac_f64_dpp on the product (chain; per pair+nop)", fmac_dpp_src_chain, 4},

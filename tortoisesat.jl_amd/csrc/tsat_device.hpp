@@ -163,7 +163,10 @@ template <int ES> struct PkRec {
   static constexpr int QQ = 54;
   static constexpr int LX = ES ? 60 : 70, LU = ES ? 66 : 77, LUU = ES ? 69 : 80;
   static constexpr int RECS = ES ? 72 : 84;
-  static constexpr int SLOT = (64 / 16) * RECS;   // packed builds: one ring slot = the records of ONE knot of a pass's four trajectories
+  // packed builds: one ring slot = the records of ONE knot of a pass's four trajectories + one 16-byte pad unit: the Jacobian lanes
+  // (lane = trajectory, knot) write their records side by side, and four whole records are a multiple of 256 bytes — every knot's
+  // lane would hit the same LDS banks. With the pad the slots start 16 bytes (mod 256) apart.
+  static constexpr int SLOT = (64 / 16) * RECS + RPUJ;
 };
 // the tracking kernel (tvlqr_trajectory) reduces a full-state record in place: error-state blocks with the full-state strides
 struct TvRec {
@@ -231,7 +234,7 @@ struct KArgs {
 };
 
 // reals of a.JW per group of four trajectories (4 trajectories x 16 knots x 84-real records): host allocation and kernels agree on it
-constexpr int TSAT_JW_REALS_PER_4 = 4 * 16 * 84;
+constexpr int TSAT_JW_REALS_PER_4 = 16 * (4 * 84 + 4);      // (16 ring slots: four records + a pad unit each)
 
 // per-trajectory pointers handed (by value) to the phase functions
 template <typename real>

@@ -23,11 +23,15 @@ hipError_t tsat_launch_solve_dense(const KArgs<double>& a, int rk4, int inertia_
 // the packed build — 8 trajectories per wavefront share the forward sweeps (tsat_kernels_packed.hip, tsat_packed.hpp)
 hipError_t tsat_launch_solve_packed(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_packed8(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+hipError_t tsat_launch_solve_packed8w(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+hipError_t tsat_launch_solve_packed16w(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 // the mixed-precision builds (options.precision = 32: float linearisation, everything else double; -DTSAT_JAC32 in tsat_device.hpp)
 // of the dense, packed and packed8 layouts, on the very arrays of the fp64 builds (tsat_kernels_*_mixed.hip)
 hipError_t tsat_launch_solve_dense_mixed(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_packed_mixed(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_packed_mixed8(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+hipError_t tsat_launch_solve_packed_mixed8w(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+hipError_t tsat_launch_solve_packed_mixed16w(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -371,28 +375,38 @@ solve_kern_t solve_variant(const tsat_handle* h, const tsat_options* o) {
   return variants[o->integrator == 4 ? 1 : 0][h->inertia_class][o->error_state ? 1 : 0];
 }
 
-// Build by batch size (measured on one MI355X, profiles/r02/build_by_batch_size.txt): one wave per SIMD (wide build) while the
-// batch fits the GPU that way — 256 CUs x 4 SIMDs; two waves per SIMD (dense build) up to about three times that; from there
-// the packed build, four trajectories per wavefront, and eight once eight per wavefront still fill the machine's 2048 slots.
+// Build by batch size (measured on one MI355X, profiles/r04/build_by_batch_size.txt): one wavefront per SIMD and trajectory (wide
+// build) while the batch fits the GPU that way — 256 CUs x 4 SIMDs; two wavefronts per SIMD (dense build) up to about three times
+// that; from there the packed builds, whose wavefronts own several trajectories: four per wavefront at two wavefronts per SIMD
+// (packed), then — once that many wavefronts fill three quarters of the machine's 1024 SIMDs — eight and sixteen per wavefront at
+// ONE wavefront per SIMD (packed8w, packed16w: 40 KB of LDS keep twelve of a backward pass's sixteen knot records on the chip, all
+// sixteen float ones). packed8 (eight per wavefront at two per SIMD) is no longer chosen automatically.
 constexpr int64_t TSAT_WIDE_MAX_T = 1024;
 constexpr int64_t TSAT_PACKED_MIN_T = 3072;
-constexpr int64_t TSAT_PACKED8_MIN_T = 16384;
-// the build (1 wide, 2 dense, 3 packed, 4 packed8) that (h->variant, batch size, precision) selects. precision = 32 — the
-// mixed-precision builds — has no wide layout: below 3072 trajectories its dense build runs (59-knot Jacobian passes in the
-// 20 KB of two wavefronts per SIMD, which the double records do not allow)
+constexpr int64_t TSAT_PACKED8W_MIN_T = 6144;
+constexpr int64_t TSAT_PACKED16W_MIN_T = 12288;
+// the build (1 wide, 2 dense, 3 packed, 4 packed8, 5 packed8w, 6 packed16w) that (h->variant, batch size, precision) selects.
+// precision = 32 — the mixed-precision builds — has no wide layout: below 3072 trajectories its dense build runs (59-knot Jacobian
+// passes in the 20 KB of two wavefronts per SIMD, which the double records do not allow)
 int selected_build(const tsat_handle* h, int precision) {
-  if (h->variant == 4 || (h->variant == 0 && h->T >= TSAT_PACKED8_MIN_T)) return 4;
-  if (h->variant == 3 || (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T)) return 3;
+  if (h->variant >= 3) return h->variant;
+  if (h->variant == 0 && h->T >= TSAT_PACKED16W_MIN_T) return 6;
+  if (h->variant == 0 && h->T >= TSAT_PACKED8W_MIN_T) return 5;
+  if (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T) return 3;
   if (precision == 32) return 2;
   return (h->variant == 2 || (h->variant != 1 && h->T > TSAT_WIDE_MAX_T)) ? 2 : 1;
 }
 hipError_t launch_solve(const tsat_handle* h, const tsat_options* o, const KArgs<double>& a) {
   const int build = selected_build(h, o->precision), rk4 = o->integrator == 4;
   if (o->precision == 32) {
+    if (build == 6) return tsat_launch_solve_packed_mixed16w(a, rk4, h->inertia_class, o->error_state, h->stream);
+    if (build == 5) return tsat_launch_solve_packed_mixed8w(a, rk4, h->inertia_class, o->error_state, h->stream);
     if (build == 4) return tsat_launch_solve_packed_mixed8(a, rk4, h->inertia_class, o->error_state, h->stream);
     if (build == 3) return tsat_launch_solve_packed_mixed(a, rk4, h->inertia_class, o->error_state, h->stream);
     return tsat_launch_solve_dense_mixed(a, rk4, h->inertia_class, o->error_state, h->stream);
   }
+  if (build == 6) return tsat_launch_solve_packed16w(a, rk4, h->inertia_class, o->error_state, h->stream);
+  if (build == 5) return tsat_launch_solve_packed8w(a, rk4, h->inertia_class, o->error_state, h->stream);
   if (build == 4) return tsat_launch_solve_packed8(a, rk4, h->inertia_class, o->error_state, h->stream);
   if (build == 3) return tsat_launch_solve_packed(a, rk4, h->inertia_class, o->error_state, h->stream);
   if (build == 2) return tsat_launch_solve_dense(a, rk4, h->inertia_class, o->error_state, h->stream);
@@ -468,8 +482,8 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
 
 int tsat_set_kernel_variant(tsat_handle* h, int32_t variant) {
   if (!h) return -1;
-  if (!(variant >= 0 && variant <= 4))
-    return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), 3 (packed, 4 trajectories per wavefront) or 4 (packed, 8)");
+  if (!(variant >= 0 && variant <= 6))
+    return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), 3 (packed: 4 trajectories per wavefront), 4 (packed8), 5 (packed8w: 8, one wavefront per SIMD) or 6 (packed16w)");
   h->variant = variant;
   return 0;
 }

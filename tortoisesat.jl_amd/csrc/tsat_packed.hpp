@@ -32,6 +32,12 @@ namespace tsat {
 #ifndef TSAT_PK_STORE
 #define TSAT_PK_STORE 6
 #endif
+#ifndef TSAT_PK_WAVES
+#define TSAT_PK_WAVES 2
+#endif
+// One wavefront per SIMD (the `w` builds): nobody hides this wavefront's waits, so the Riccati lanes read the record of knot l - 1
+// from the ring while they work on knot l (riccati_rows does the same in the one-trajectory builds).
+constexpr bool PK_ALONE = (TSAT_PK_WAVES == 1);
 constexpr int PK_STORE = TSAT_PK_STORE;     // line-search candidates per trajectory whose rollouts a sweep keeps in HBM at most
 constexpr int PK_FEW = 3;                   // ... and while the trajectory's line searches end early (see solve_group)
 constexpr int PK_G = TSAT_PK_G;             // trajectories per wavefront
@@ -74,7 +80,10 @@ static_assert(L_FWD + PK_NBUF * PK_FB <= LDS_REALS, "packed forward buffers fit 
 //                    is the `row_newbcast` source of the FMA that consumes it — no exchange through LDS inside a knot), four
 //                    trajectories side by side: the results are bit-identical to the one-trajectory builds.
 constexpr int PK_JCH = 16;                        // knots per trajectory and Jacobian pass (= lanes per trajectory)
-constexpr int PK_RING = (sizeof(jac_t) == 8) ? 4 : 8;      // knots of every trajectory resident in LDS during the recursion (20 KB: 4 double records, 8 float ones)
+#ifndef TSAT_PK_RING
+#define TSAT_PK_RING ((sizeof(jac_t) == 8) ? 4 : 8)
+#endif
+constexpr int PK_RING = TSAT_PK_RING;      // knots of every trajectory resident in LDS during the recursion (20 KB: 4 double records, 8 float ones)
 constexpr int PK_CPB = 16;                        // bytes per lane of a ring copy instruction (riccati_group)
 constexpr int PK_BC = 16;                         // lanes per trajectory in a backward pass
 constexpr int PK_BG = WAVE / PK_BC;               // trajectories per backward pass (4); a wave of PK_G trajectories takes PK_G / PK_BG passes
@@ -88,19 +97,19 @@ static_assert(PkRec<0>::RECS % RPUJ == 0 && PkRec<1>::RECS % RPUJ == 0 && PkRec<
 constexpr int L_GTR = L_UNION;
 constexpr int L_GX = L_GTR + PK_BG * PK_GTRW;
 constexpr int L_GREC = L_GX + PK_BG * PK_GXW;
-constexpr int PK_SLOT = PK_BG * PK_RECS;                // record values (jac_t) per ring slot
+constexpr int PK_SLOT = PK_BG * PK_RECS + RPUJ;         // record values (jac_t) per ring slot (PkRec::SLOT of the larger record)
 static_assert(L_GREC * (int)sizeof(cfg_real) + PK_RING * PK_SLOT * (int)sizeof(jac_t) <= LDS_REALS * (int)sizeof(cfg_real), "joint backward sweep fits the wave's LDS block");
-constexpr int PK_JW_WAVE = PK_BG * PK_JCH * PK_RECS;    // workspace values (jac_t) per wavefront (its passes of four trajectories share it)
+constexpr int PK_JW_WAVE = PK_JCH * PK_SLOT;             // workspace values (jac_t) per wavefront (its passes of four trajectories share it)
 // the record ring (values of type jac_t, from L_GREC on)
 TSAT_DEV jac_t* ring_base() { return reinterpret_cast<jac_t*>(lds_base<cfg_real>() + L_GREC); }
-static_assert(PK_JW_WAVE == TSAT_JW_REALS_PER_4, "host allocation of a.JW");
+static_assert(PK_JW_WAVE <= TSAT_JW_REALS_PER_4, "host allocation of a.JW");
 // packed index of (i <= j) in an n x n upper triangle, row by row
 constexpr int sym_ut(int i, int j, int n) { return i * n - (i * (i - 1)) / 2 + (j - i); }
 // hand-over between the trajectories' state lanes (PK_C per trajectory) and the lanes of a backward pass (PK_BC per trajectory),
 // in the part of the one-trajectory Riccati scratch the packed build does not use
 template <typename real> struct BwdIn { int N, need; real mu, rho; int cur, pad; };
 template <typename real> struct BwdRes { acc_t dV1, dV2; int ok, pad; };
-constexpr int L_BWT = L_HXX;
+constexpr int L_BWT = L_WT;      // (the scratch of the element-oriented recursion: unused by the solve kernels)
 static_assert(L_BWT % 2 == 0, "hand-over tables are 8-byte aligned");
 
 // per-trajectory position in the AL-iLQR iteration; lives in the registers of the trajectory's PK_C lanes and is made
@@ -390,8 +399,8 @@ TSAT_PHASE void jacobian16(const KArgs<real>& a, int traj0, TSAT_GLOBAL jac_t* j
   // the last PK_RING knots of the chunk are the first the recursion consumes: their lanes put the record straight into its
   // ring slot in LDS; the others go through the workspace (one code path for both: a generic pointer, flat stores)
   using R = PkRec<ES>;
-  jac_t* rc = (kk >= PK_JCH - PK_RING) ? ring_base() + (kk & (PK_RING - 1)) * R::SLOT + g * R::RECS
-                                       : (jac_t*)(jw + (size_t)(kk * PK_BG + g) * R::RECS);      // workspace: [knot][trajectory][record], a ring slot contiguous
+  jac_t* rc = (kk >= PK_JCH - PK_RING) ? ring_base() + (kk % PK_RING) * R::SLOT + g * R::RECS
+                                       : (jac_t*)(jw + (size_t)kk * R::SLOT + g * R::RECS);      // workspace: [knot][trajectory][record], a ring slot contiguous
   real qn[4];
   for (int i = 0; i < 4; ++i) qn[i] = xu[XUW + 3 + i];
   knot_record<real, INTEG, DIAGJ, ES, jac_t*>(tr, x, u, lam, b0, b1, b2, qn, mu, rc);
@@ -406,6 +415,13 @@ template <int NCI, int M = PK_RING - 1>
 TSAT_DEV void ring_wait(int l) {
   if (l >= M) { TSAT_SYNC_OLDER_THAN(M * NCI); }
   else if constexpr (M > 0) ring_wait<NCI, M - 1>(l);
+}
+// one wavefront per SIMD (riccati_group): copy instructions issued at knots l + PK_RING - 3 ... l — NCI per knot that copies a record,
+// `dummy` per knot that does not
+constexpr int ring_younger(int nci, int dummy, int l) {
+  int c = 0;
+  for (int i = l; i <= l + PK_RING - 3; ++i) c += (i >= PK_RING - 1 && i < PK_JCH - 1) ? nci : dummy;
+  return c;
 }
 template <typename real> struct GBwd { acc_t dV1, dV2; int ok; };
 
@@ -442,7 +458,7 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
   static_assert((PK_RING - 1) * NCI <= 63, "the wait count fits vmcnt");
   const TSAT_GLOBAL unsigned char* cp_src = reinterpret_cast<const TSAT_GLOBAL unsigned char*>(jw) + PK_CPB * lane;
   auto ring_copy = [&](int q) {
-    unsigned char* slot = reinterpret_cast<unsigned char*>(ring_base() + (q & (PK_RING - 1)) * R::SLOT);
+    unsigned char* slot = reinterpret_cast<unsigned char*>(ring_base() + (q % PK_RING) * R::SLOT);
     const TSAT_GLOBAL unsigned char* src = cp_src + (size_t)q * SLOT_BYTES;
     for (int i = 0; i < NCI; ++i)
       if (PK_CPB * (lane + WAVE * i) < SLOT_BYTES) glds_copy<PK_CPB>(slot + PK_CPB * WAVE * i, src + PK_CPB * WAVE * i);
@@ -458,12 +474,68 @@ TSAT_PHASE GBwd<real> riccati_group(const KArgs<real>& a, int traj0, const TSAT_
   RowState<NH> st;
   const int js = (j < NH) ? j : 0;
   for (int r = 0; r <= NH; ++r) st.Sc[r] = gs[r * 8 + js];
+#ifndef TSAT_EMU
+  if constexpr (PK_ALONE) {
+    // One wavefront per SIMD. The record of knot l - 1 is read while knot l is worked on, two register sets taking turns. fetch(l),
+    // at the top of knot l: this knot's copy instructions, then — if it came through the workspace — the wait for the copy of
+    // record l - 1, then its read.
+    // The wait may only count YOUNGER LOADS (TSAT_SYNC_OLDER_THAN), and vmcnt counts the gain stores in between as well: with
+    // nothing else in flight the last copies of a pass would be waited for with vmcnt(0), i.e. together with every gain store
+    // of the pass — a store takes microseconds to retire under the launch's write load, and this wavefront has no neighbour on
+    // its SIMD to fill the time. So every knot that has no record to copy issues PK_DUMMY four-byte copies into a sink behind
+    // the ring: loads like the others, retiring in order behind the real copies. The copy of record q, issued at knot
+    // q + PK_RING - 1, is then always followed by the copy instructions of PK_RING - 2 more knots before it is waited for, and
+    // the wait lets that many operations — gain stores among them — stay in flight.
+    static_assert(PK_JCH % 2 == 0 && PK_RING >= 3, "two knots per turn");
+    constexpr int PK_DUMMY = 2, NVIA = PK_JCH - PK_RING;       // NVIA: records per trajectory and pass that go through the workspace
+    unsigned char* sink = reinterpret_cast<unsigned char*>(lds + LDS_REALS) - 4 * WAVE;      // (one sink for all of them)
+    static_assert(NVIA == 0 || (L_GREC * (int)sizeof(cfg_real) + PK_RING * PK_SLOT * (int)sizeof(jac_t) + 4 * WAVE <= LDS_REALS * (int)sizeof(cfg_real)),
+                  "the sink of the padding copies lies behind the ring");
+    const TSAT_GLOBAL unsigned char* dsrc = reinterpret_cast<const TSAT_GLOBAL unsigned char*>(jw) + 4 * lane;
+    auto recp = [&](int l) { return recs + (((l > 0) ? l : 0) % PK_RING) * R::SLOT; };
+    auto fetch = [&](int l) {
+      if constexpr (NVIA > 0) {
+        if (l >= PK_RING - 1 && l < PK_JCH - 1) ring_copy(l - (PK_RING - 1));
+        else if (l >= 1 && l < PK_RING - 1)
+          for (int i = 0; i < PK_DUMMY; ++i) glds_copy<4>(sink, dsrc + 4 * WAVE * i);
+        // record l - 1 (< NVIA) was copied at knot l + PK_RING - 2; younger copy instructions: those of knots l + PK_RING - 3 ... l
+        static_assert(NVIA <= 4, "one case per record that goes through the workspace");
+        if (l == 1) { constexpr int c = ring_younger(NCI, PK_DUMMY, 1); static_assert(c <= 63); TSAT_SYNC_OLDER_THAN(c); }
+        else if (l == 2 && NVIA >= 2) { constexpr int c = ring_younger(NCI, PK_DUMMY, 2); static_assert(c <= 63); TSAT_SYNC_OLDER_THAN(c); }
+        else if (l == 3 && NVIA >= 3) { constexpr int c = ring_younger(NCI, PK_DUMMY, 3); static_assert(c <= 63); TSAT_SYNC_OLDER_THAN(c); }
+        else if (l == 4 && NVIA >= 4) { constexpr int c = ring_younger(NCI, PK_DUMMY, 4); static_assert(c <= 63); TSAT_SYNC_OLDER_THAN(c); }
+      }
+      return row_load<jac_t, NH, R>(recp(l - 1), ro);
+    };
+    auto knot = [&](const RowIn<NH>& in, int l) {
+      const int k = kb0 + l;
+      const bool act = need && ok && k < N - 1;
+      double Kc[3], d[3];
+      bool pd = true;
+      if (act) pd = riccati_row_step<NH, R>(st, in, ro, rho, Kc, d, dV1, dV2);
+      if (act && j < 8) {
+        TSAT_GLOBAL real* kd = KDg + (size_t)k * KDW;
+        for (int c = 0; c < 3; ++c) kd[slot_[c]] = (real)fma_(Kc[c], km, d[c] * dm);
+      }
+      ok = ok && (!act || pd);
+    };
+    RowIn<NH> A = row_load<jac_t, NH, R>(recp(PK_JCH - 1), ro);
+    for (int l = PK_JCH - 1; l >= 0; l -= 2) {
+      const RowIn<NH> B = fetch(l);
+      TSAT_SCHED_FENCE();
+      knot(A, l);
+      A = fetch(l - 1);
+      TSAT_SCHED_FENCE();
+      knot(B, l - 1);
+    }
+  } else
+#endif
   for (int l = PK_JCH - 1; l >= 0; --l) {
     const int k = kb0 + l;
     const bool act = need && ok && k < N - 1;
     if (l >= PK_RING - 1 && l < PK_JCH - 1) ring_copy(l - (PK_RING - 1));
     ring_wait<NCI>(l);
-    const jac_t* rc = recs + (l & (PK_RING - 1)) * R::SLOT;
+    const jac_t* rc = recs + (l % PK_RING) * R::SLOT;
     double Kc[3], d[3];
 #ifdef TSAT_EMU
     // every emulated lane takes part in the exchanges of the step; a row that does not take part keeps its state
@@ -709,9 +781,13 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
             TSAT_SYNC();         // the records are in the workspace (vmcnt(0)) before the ring copies read them
             const unsigned long long c1 = tick_();
             bw = riccati_group<real, NH>(a, traj0 + t0, jw, kb0, bneed, in.N, in.rho, bw.dV1, bw.dV2, bw.ok);
-            TSAT_SYNC();         // every copy has landed and every record has been consumed before the next pass overwrites them
+            // every copy has landed and every record has been consumed before the next pass overwrites them. One wavefront per
+            // SIMD: every real copy has been waited for inside the pass and the padding copies write a sink, so the gain stores
+            // need not be drained here (the Jacobian lanes' own drain, a pass of arithmetic later, finds them retired)
+            if (PK_ALONE) { TSAT_SYNC_LDS(); } else { TSAT_SYNC(); }
             pc_jac += c1 - c0; pc_ric += tick_() - c1;
           }
+          if (PK_ALONE) TSAT_SYNC();     // the gains are in memory before anything reads them
         }
         if (lane % PK_BC == 0) { tres[t0 + bg].dV1 = bw.dV1; tres[t0 + bg].dV2 = bw.dV2; tres[t0 + bg].ok = bw.ok; }
         TSAT_SYNC_LDS();
@@ -923,6 +999,7 @@ TSAT_DEV void solve_group(const KArgs<real>& a, int wave) {
       const double jac = (double)pc_jac, ric = (double)pc_ric;
       trace[0] = (double)pc_fwd; trace[1] = jac; trace[2] = ric; trace[3] = (double)pc_adv - jac - ric;
       trace[4] = (double)its; trace[5] = (double)nb; trace[6] = (double)pc_adopt; trace[7] = (double)pc_end;
+
     }
   }
 #else
