@@ -29,8 +29,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pipeline" -o run -
 cd "$ROOT"
 python3 tools/phase_profile.py 1024 1000 1 1 > "$OUT/phase_clocks.txt" 2> "$OUT/phase_clocks.err"
 python3 tools/monte_carlo_timing.py 1024 1024 > "$OUT/monte_carlo.txt" 2> "$OUT/monte_carlo.err"
-TSAT_VARIANTS=2,3,4 python3 tools/large_batch.py > "$OUT/large_batch.txt" 2> "$OUT/large_batch.err"
-python3 tools/threshold_timing.py > "$OUT/build_by_batch_size.txt" 2> "$OUT/build_by_batch_size.err"
+TSAT_VARIANTS=2,3,4,5,6 python3 tools/large_batch.py > "$OUT/large_batch.txt" 2> "$OUT/large_batch.err"
+python3 tools/threshold_timing.py 1024 2048 3072 4096 6144 8192 12288 16384 > "$OUT/build_by_batch_size.txt" 2> "$OUT/build_by_batch_size.err"
 python3 tools/fp32_eval.py 16384 512 > "$OUT/fp32_eval.txt" 2> "$OUT/fp32_eval.err"
 { python3 tools/mpc_timing.py 512 500; python3 tools/mpc_timing.py 4096 200; } > "$OUT/mpc_timing.txt" 2> "$OUT/mpc_timing.err"
 fi
@@ -73,7 +73,9 @@ python3 tools/endgame_sweep.py > "$OUT/endgame_sweep.txt" 2> "$OUT/endgame_sweep
 python3 tools/straggler_timeline.py 8192 0 2048 > "$OUT/straggler_timeline.txt" 2> "$OUT/straggler_timeline.err"
 TSAT_PK_G=4 python3 tools/phase_profile.py 16384 1000 3 1 > "$OUT/phase_clocks_packed.txt" 2> "$OUT/phase_clocks_packed.err"
 TSAT_PK_G=8 python3 tools/phase_profile.py 16384 1000 4 1 > "$OUT/phase_clocks_packed8.txt" 2> "$OUT/phase_clocks_packed8.err"
-TSAT_PK_G=8 python3 tools/phase_profile.py 16384 1000 4 1 32 > "$OUT/phase_clocks_packed8_mixed.txt" 2> "$OUT/phase_clocks_packed8_mixed.err"
+TSAT_PK_G=8 python3 tools/phase_profile.py 8192 1000 5 1 > "$OUT/phase_clocks_packed8w.txt" 2> "$OUT/phase_clocks_packed8w.err"
+TSAT_PK_G=16 python3 tools/phase_profile.py 16384 1000 6 1 > "$OUT/phase_clocks_packed16w.txt" 2> "$OUT/phase_clocks_packed16w.err"
+TSAT_PK_G=16 python3 tools/phase_profile.py 16384 1000 6 1 32 > "$OUT/phase_clocks_packed16w_mixed.txt" 2> "$OUT/phase_clocks_packed16w_mixed.err"
 python3 tools/phase_profile.py 16384 1000 2 1 > "$OUT/phase_clocks_dense.txt" 2> "$OUT/phase_clocks_dense.err"
 fi
 tools/ubench/valu_f64 > "$OUT/valu_f64_ubench.txt" 2>&1 || true

@@ -23,7 +23,7 @@ o = opts.to_abi(b.N, b.n_tab, 3, error_state=1)
 s.upload(b, o.max_linesearch)
 res = {}
 s.trace(64)
-for name, prec, var in (("fp64 auto (packed8)", 64, 0), ("fp64 packed, 4 per wave", 64, 3), ("mixed auto (packed8)", 32, 0), ("mixed packed, 4 per wave", 32, 3),
+for name, prec, var in (("fp64 auto (packed16w)", 64, 0), ("fp64 packed, 4 per wave", 64, 3), ("mixed auto (packed16w)", 32, 0), ("mixed packed, 4 per wave", 32, 3),
                         ("mixed one trajectory per wave, 2 waves/SIMD", 32, 2)):
     o.precision = prec
     s.set_kernel_variant(var)

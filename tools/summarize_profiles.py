@@ -64,7 +64,8 @@ for a, b in (("phase_clocks.txt", "phase_clocks_final.txt"), ("pipeline.log", "p
              ("build_by_batch_size.txt", "build_by_batch_size.txt"), ("fp32_eval.txt", "fp32_eval.txt"), ("phase_clocks_packed.txt", "phase_clocks_packed.txt"),
              ("phase_clocks_packed8.txt", "phase_clocks_packed8.txt"), ("phase_clocks_dense.txt", "phase_clocks_dense.txt"),
              ("bench_c2_fp64.json", "bench_c2_fp64.json"), ("bench_c2_mixed.json", "bench_c2_mixed.json"), ("bench_c4.json", "bench_c4.json"),
-             ("phase_clocks_packed8_mixed.txt", "phase_clocks_packed8_mixed.txt"), ("valu_f64_ubench.txt", "valu_f64_ubench.txt"), ("endgame_sweep.txt", "endgame_sweep.txt")):
+             ("phase_clocks_packed8w.txt", "phase_clocks_packed8w.txt"), ("phase_clocks_packed16w.txt", "phase_clocks_packed16w.txt"),
+             ("phase_clocks_packed16w_mixed.txt", "phase_clocks_packed16w_mixed.txt"), ("valu_f64_ubench.txt", "valu_f64_ubench.txt"), ("endgame_sweep.txt", "endgame_sweep.txt")):
     if not os.path.exists(os.path.join(src, a)):
         continue
     with open(os.path.join(src, a)) as f:
