@@ -378,19 +378,20 @@ solve_kern_t solve_variant(const tsat_handle* h, const tsat_options* o) {
 // Build by batch size (measured on one MI355X, profiles/r04/build_by_batch_size.txt): one wavefront per SIMD and trajectory (wide
 // build) while the batch fits the GPU that way — 256 CUs x 4 SIMDs; two wavefronts per SIMD (dense build) up to about three times
 // that; from there the packed builds, whose wavefronts own several trajectories: four per wavefront at two wavefronts per SIMD
-// (packed), then — once that many wavefronts fill three quarters of the machine's 1024 SIMDs — eight and sixteen per wavefront at
-// ONE wavefront per SIMD (packed8w, packed16w: 40 KB of LDS keep twelve of a backward pass's sixteen knot records on the chip, all
-// sixteen float ones). packed8 (eight per wavefront at two per SIMD) is no longer chosen automatically.
+// (packed); eight per wavefront at ONE wavefront per SIMD once that fills three quarters of the 1024 SIMDs, up to one full round of
+// them (packed8w: 40 KB of LDS keep twelve of a backward pass's sixteen knot records on the chip, all sixteen float ones);
+// eight per wavefront at two per SIMD in between (packed8); sixteen per wavefront at one per SIMD from one full round on (packed16w).
 constexpr int64_t TSAT_WIDE_MAX_T = 1024;
 constexpr int64_t TSAT_PACKED_MIN_T = 3072;
-constexpr int64_t TSAT_PACKED8W_MIN_T = 6144;
-constexpr int64_t TSAT_PACKED16W_MIN_T = 12288;
+constexpr int64_t TSAT_PACKED8W_MIN_T = 6144, TSAT_PACKED8W_MAX_T = 8192;
+constexpr int64_t TSAT_PACKED16W_MIN_T = 16384;
 // the build (1 wide, 2 dense, 3 packed, 4 packed8, 5 packed8w, 6 packed16w) that (h->variant, batch size, precision) selects.
 // precision = 32 — the mixed-precision builds — has no wide layout: below 3072 trajectories its dense build runs (59-knot Jacobian
 // passes in the 20 KB of two wavefronts per SIMD, which the double records do not allow)
 int selected_build(const tsat_handle* h, int precision) {
   if (h->variant >= 3) return h->variant;
   if (h->variant == 0 && h->T >= TSAT_PACKED16W_MIN_T) return 6;
+  if (h->variant == 0 && h->T > TSAT_PACKED8W_MAX_T) return 4;
   if (h->variant == 0 && h->T >= TSAT_PACKED8W_MIN_T) return 5;
   if (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T) return 3;
   if (precision == 32) return 2;
