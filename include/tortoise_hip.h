@@ -257,7 +257,8 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
  *   4 packed8 the same with eight trajectories per wavefront (eight candidates each, two backward passes): 8193 .. 16383;
  *   5 packed8w  eight trajectories per wavefront at ONE wavefront per SIMD (40 KB of LDS: twelve of a backward pass's sixteen knot
  *             records stay on the chip instead of four, all sixteen float ones; the whole register file: no spills): 6144 .. 8192;
- *   6 packed16w sixteen trajectories per wavefront (four candidates each) at one wavefront per SIMD: from 16384.
+ *   6 packed16w sixteen trajectories per wavefront (four candidates each) at one wavefront per SIMD: from 16384, unless the
+ *             iteration budget max_outer * max_inner is 100 or more (then packed8: a wavefront lasts as long as its slowest trajectory).
  * precision = 32 has the dense layout and the packed ones (below 3072 trajectories the dense one; `variant` 1 means 2 there).
  * The builds of one precision give bit-identical results (X, U, K, iteration counts; `n_forward` counts the sweeps a build
  * executed and differs). The switch exists for tuning and for the tests. */

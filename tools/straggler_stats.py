@@ -9,16 +9,20 @@ pkg = load_package()
 from tortoisesat_jl_amd import magnetic as mg, slew_setup as ss, trajopt as to
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+J0 = int(sys.argv[2]) if len(sys.argv) > 2 else 3 * 8192      # first global index of the shard (0 with T = 65536: the whole sweep)
+ONLY_VARIANTS = len(sys.argv) > 3
 opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = 3
 opts.opts_uncon.iterations = 50; opts.opts_uncon.dJ_counter_limit = 1
 s = to.AugmentedLagrangianSolver(None, opts)
-b = mg.attach_igrf_tables(s, ss.workload_inclination_sweep(T=T, N=1000, j0=3 * 8192, tables=False))
+b = mg.attach_igrf_tables(s, ss.workload_inclination_sweep(T=T, N=1000, j0=J0, tables=False))
 o = opts.to_abi(b.N, b.n_tab, 3, error_state=1)
 s.upload(b, o.max_linesearch)
-for v in (0, 2, 3, 4):
+for v in ((0, 3, 4, 5, 6) if T > 8192 else (0, 2, 3, 4, 5, 6)):
     s.set_kernel_variant(v)
     ms = s.run(o); ms = s.run(o)
     print(f"variant {v}: {ms:.1f} ms -> {T / ms * 1e3:.0f} solves/s")
+if ONLY_VARIANTS:
+    s.close(); sys.exit(0)
 s.set_kernel_variant(3)
 for at in (0, 512, 1024, 1536, 2048, 3072, 4096):     # tsat_set_endgame: park the last `at` live trajectories for a one-per-wavefront launch
     s.set_endgame(at)

@@ -380,17 +380,21 @@ solve_kern_t solve_variant(const tsat_handle* h, const tsat_options* o) {
 // that; from there the packed builds, whose wavefronts own several trajectories: four per wavefront at two wavefronts per SIMD
 // (packed); eight per wavefront at ONE wavefront per SIMD once that fills three quarters of the 1024 SIMDs, up to one full round of
 // them (packed8w: 40 KB of LDS keep twelve of a backward pass's sixteen knot records on the chip, all sixteen float ones);
-// eight per wavefront at two per SIMD in between (packed8); sixteen per wavefront at one per SIMD from one full round on (packed16w).
+// eight per wavefront at two per SIMD in between (packed8); sixteen per wavefront at one per SIMD from one full round on (packed16w;
+// packed8 with a long iteration budget: selected_build).
 constexpr int64_t TSAT_WIDE_MAX_T = 1024;
 constexpr int64_t TSAT_PACKED_MIN_T = 3072;
 constexpr int64_t TSAT_PACKED8W_MIN_T = 6144, TSAT_PACKED8W_MAX_T = 8192;
-constexpr int64_t TSAT_PACKED16W_MIN_T = 16384;
+constexpr int64_t TSAT_PACKED16W_MIN_T = 16384, TSAT_LONG_BUDGET = 100;     // (budget = max_outer x max_inner)
 // the build (1 wide, 2 dense, 3 packed, 4 packed8, 5 packed8w, 6 packed16w) that (h->variant, batch size, precision) selects.
 // precision = 32 — the mixed-precision builds — has no wide layout: below 3072 trajectories its dense build runs (59-knot Jacobian
 // passes in the 20 KB of two wavefronts per SIMD, which the double records do not allow)
-int selected_build(const tsat_handle* h, int precision) {
+int selected_build(const tsat_handle* h, int precision, int64_t budget) {
   if (h->variant >= 3) return h->variant;
-  if (h->variant == 0 && h->T >= TSAT_PACKED16W_MIN_T) return 6;
+  // from one full round on: sixteen per wavefront — unless the iteration budget is long enough to spread the trajectories' iteration
+  // counts widely (3 x 50 on the inclination sweep: 30 ... 150), where a wavefront lasts as long as the slowest of its trajectories
+  // and eight per wavefront on 2048 wavefront slots lose less (65536 trajectories: 3.91 s against 4.27 s; 5 x 10: 0.47 against 0.43 s)
+  if (h->variant == 0 && h->T >= TSAT_PACKED16W_MIN_T) return budget >= TSAT_LONG_BUDGET ? 4 : 6;
   if (h->variant == 0 && h->T > TSAT_PACKED8W_MAX_T) return 4;
   if (h->variant == 0 && h->T >= TSAT_PACKED8W_MIN_T) return 5;
   if (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T) return 3;
@@ -398,7 +402,7 @@ int selected_build(const tsat_handle* h, int precision) {
   return (h->variant == 2 || (h->variant != 1 && h->T > TSAT_WIDE_MAX_T)) ? 2 : 1;
 }
 hipError_t launch_solve(const tsat_handle* h, const tsat_options* o, const KArgs<double>& a) {
-  const int build = selected_build(h, o->precision), rk4 = o->integrator == 4;
+  const int build = selected_build(h, o->precision, (int64_t)o->max_outer * o->max_inner), rk4 = o->integrator == 4;
   if (o->precision == 32) {
     if (build == 6) return tsat_launch_solve_packed_mixed16w(a, rk4, h->inertia_class, o->error_state, h->stream);
     if (build == 5) return tsat_launch_solve_packed_mixed8w(a, rk4, h->inertia_class, o->error_state, h->stream);
@@ -422,7 +426,7 @@ void* packed_workspace(tsat_handle* h) {
 }
 
 // does the build that (h->variant, batch size, precision) selects need the packed builds' Jacobian workspace a.JW?
-bool uses_packed_build(const tsat_handle* h, int precision) { return selected_build(h, precision) >= 3; }
+bool uses_packed_build(const tsat_handle* h, int precision) { return selected_build(h, precision, 0) >= 3; }     // (whatever the budget)
 
 // Endgame of a packed launch (tsat_packed.hpp, suspend_if_endgame). Automatic: once an eighth of the batch (profiles/r04/endgame_sweep.txt), at most the 2048
 // wavefront slots of the machine (256 CUs x 4 SIMDs x 2), is all that still iterates — and only for iteration budgets long
@@ -492,7 +496,7 @@ int tsat_set_kernel_variant(tsat_handle* h, int32_t variant) {
 int tsat_selected_build(tsat_handle* h, const tsat_options* o, int32_t* build, int32_t* endgame_at) {
   if (!h || !o) return -1;
   if (h->T <= 0) return fail(h, -1, "tsat_batch_reserve has not been called");
-  const int b = selected_build(h, o->precision);
+  const int b = selected_build(h, o->precision, (int64_t)o->max_outer * o->max_inner);
   if (build) *build = b;
   if (endgame_at) *endgame_at = b >= 3 ? endgame_threshold(h, o) : 0;
   return 0;
