@@ -8,8 +8,15 @@ OUT=$(realpath -m "${1:-gpurun_out/final}")
 ROOT=$(pwd)
 mkdir -p "$OUT"
 PART="${PART:-AB}"     # A: configs[1], pipeline, experiment, batch sizes; B: configs[2] (fp64, mixed), [3], [4] — one gpurun call each fits 20 minutes
-if [[ "$PART" == *A* ]]; then
+                       # L: the bench lines alone, once more (after the PMC summaries of A / P / B have been committed: the lines then carry `roofline.traffic`)
+if [[ "$PART" == *A* || "$PART" == *L* ]]; then
 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+fi
+if [[ "$PART" == *L* ]]; then
+python3 bench.py --config 2 --precision 64 --steps 3 --warmup 1 --cpu-seconds 8 > "$OUT/bench_c2_fp64.json" 2> "$OUT/bench_c2_fp64.err"
+python3 bench.py --config 2 --steps 3 --warmup 1 --cpu-seconds 8 > "$OUT/bench_c2_mixed.json" 2> "$OUT/bench_c2_mixed.err"
+python3 bench.py --config 4 --steps 2 --warmup 1 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 bench.py --config 3 --steps 2 --warmup 1 --cpu-seconds 8 --gather none > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"
 fi
 if [[ "$PART" == *A* || "$PART" == *P* ]]; then      # P: the rocprofv3 passes of configs[1] alone
 cd /tmp && export TMPDIR=/tmp

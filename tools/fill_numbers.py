@@ -47,9 +47,10 @@ c2, c2m, c3, c4 = line("bench_c2_fp64.json"), line("bench_c2_mixed.json"), line(
 p1, p2, p2m, p3 = pmc("pmc_summary.json"), pmc("pmc_summary_c2.json"), pmc("pmc_summary_c2mixed.json"), pmc("pmc_summary_c3.json")
 ur = line("bench_under_rocprof.json")
 ks, _ = stats_row("kernel_stats_bench_steps5_final.csv", "tsat_solve_kernel<double, 3, 2, 1>")
-ks2a, _ = stats_row("kernel_stats_c2_mixed.csv", "tsat_solve_kernel_packed_mixed8")
-ks2b, _ = stats_row("kernel_stats_c2_mixed.csv", "tsat_resume_kernel_packed_mixed8")
+ks2a, _ = stats_row("kernel_stats_c2_mixed.csv", "tsat_solve_kernel_packed_mixed16w")
+ks2b, _ = stats_row("kernel_stats_c2_mixed.csv", "tsat_resume_kernel_packed_mixed<")
 ph = phase("phase_clocks_final.txt")
+phw = phase("phase_clocks_packed8w.txt")
 lower = lambda p: p["hbm_bytes_per_launch_lower"] / p["algorithmic_bytes_per_launch"]
 shard_ms = None
 with open(os.path.join(rdir, "straggler_stats.txt")) as f:
@@ -75,6 +76,7 @@ V = {
     "C3S_MS": f"{shard_ms:.0f}", "C3S_SPS": f"{shard_sps / 1e3:.1f}",
     "C4_MS": f"{c4['ms_per_step'] / 100:.2f}", "C4_SPS": f"{c4['value'] / 1e6:.2f}", "C4_FRAC": f"{c4['roofline']['frac']:.3f}",
     "KS_MS": f"{ks:.2f}", "KS_HIP": f"{ur['roofline']['kernel_ms']:.2f}", "KS_C2M": f"{ks2a:.1f} + {ks2b:.1f}",
+    "W_FWD": f"{phw['forward sweep']:.0f}", "W_JAC": f"{phw['jacobian lanes']:.0f}", "W_RIC": f"{phw['riccati']:.0f}", "W_PAR": f"{phw['parallel passes']:.0f}",
     "P_FWD": f"{ph['forward sweep']:.0f}", "P_JAC": f"{ph['jacobian lanes']:.0f}", "P_RIC": f"{ph['riccati']:.0f}", "P_PAR": f"{ph['parallel passes']:.0f}",
 }
 text = sys.stdin.read()
