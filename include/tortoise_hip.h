@@ -253,18 +253,19 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
  *   2 dense   one trajectory per wavefront, two wavefronts per SIMD (20 KB, 256 registers): 1025 .. 3071;
  *   3 packed  four trajectories per wavefront share every forward sweep (16 line-search candidates each) and run their
  *             backward sweeps together (Jacobian lanes = trajectory x knot x column quarter, Riccati recursion on 16 lanes per
- *             trajectory), two wavefronts per SIMD: from 3072 trajectories;
+ *             trajectory), two wavefronts per SIMD: 4097 .. 6143 trajectories;
  *   4 packed8 the same with eight trajectories per wavefront (eight candidates each, two backward passes): 8193 .. 16383;
  *   5 packed8w  eight trajectories per wavefront at ONE wavefront per SIMD (40 KB of LDS: twelve of a backward pass's sixteen knot
  *             records stay on the chip instead of four, all sixteen float ones; the whole register file: no spills): 6144 .. 8192;
  *   6 packed16w sixteen trajectories per wavefront (four candidates each) at one wavefront per SIMD: from 16384, unless the
  *             iteration budget max_outer * max_inner is 100 or more (then packed8: a wavefront lasts as long as its slowest trajectory).
+ *   7 packed4w  four trajectories per wavefront at one wavefront per SIMD: 3072 .. 4096 (the receding-horizon loop of 4096).
  * precision = 32 has the dense layout and the packed ones (below 3072 trajectories the dense one; `variant` 1 means 2 there).
  * The builds of one precision give bit-identical results (X, U, K, iteration counts; `n_forward` counts the sweeps a build
  * executed and differs). The switch exists for tuning and for the tests. */
 int  tsat_set_kernel_variant(tsat_handle* h, int32_t variant);
 
-/* Endgame of the packed builds (variants 3 to 6). The trajectories of one launch need different numbers of iterations (21 .. 150
+/* Endgame of the packed builds (variants 3 to 7). The trajectories of one launch need different numbers of iterations (21 .. 150
  * on the inclination sweep of src/paper_images/heatmap.jl:139-185 with its 3 x 50 budget), and a wavefront that holds four or
  * eight of them lasts as long as its slowest: towards the end of a launch a few wavefronts with several long trajectories keep
  * running while the rest of the machine is idle. Once at most `suspend_at` trajectories of the batch are still iterating, every
@@ -277,7 +278,7 @@ int  tsat_set_kernel_variant(tsat_handle* h, int32_t variant);
 int  tsat_set_endgame(tsat_handle* h, int32_t suspend_at);
 
 /* What the next tsat_batch_run / tsat_mpc_run with options `o` will launch on the reserved batch: *build = 1 wide, 2 dense,
- * 3 packed, 4 packed8, 5 packed8w, 6 packed16w (of the precision `o` names), *endgame_at = the live count at which a packed launch parks its trajectories
+ * 3 packed, 4 packed8, 5 packed8w, 6 packed16w, 7 packed4w (of the precision `o` names), *endgame_at = the live count at which a packed launch parks its trajectories
  * (0: no endgame). For reports (bench.py labels its lines with it); either pointer may be NULL. */
 int  tsat_selected_build(tsat_handle* h, const tsat_options* o, int32_t* build, int32_t* endgame_at);
 

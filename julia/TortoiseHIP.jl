@@ -76,7 +76,7 @@ function default_options()
     return o
 end
 
-"set_kernel_variant!(s, v) — 0 automatic by batch size; 1 wide, 2 dense, 3 packed, 4 packed8, 5 packed8w, 6 packed16w (results do not depend on it)"
+"set_kernel_variant!(s, v) — 0 automatic by batch size; 1 wide, 2 dense, 3 packed, 4 packed8, 5 packed8w, 6 packed16w, 7 packed4w (results do not depend on it)"
 set_kernel_variant!(s::HIPSolver, v::Integer) =
     check(s, ccall((:tsat_set_kernel_variant, LIB), Cint, (Ptr{Cvoid}, Int32), s.handle, v), "tsat_set_kernel_variant")
 
@@ -84,7 +84,7 @@ set_kernel_variant!(s::HIPSolver, v::Integer) =
 set_endgame!(s::HIPSolver, n::Integer) =
     check(s, ccall((:tsat_set_endgame, LIB), Cint, (Ptr{Cvoid}, Int32), s.handle, n), "tsat_set_endgame")
 
-"selected_build(s, o) — (build, endgame_at) the next run launches on the reserved batch: 1 wide, 2 dense, 3 packed, 4 packed8, 5 packed8w, 6 packed16w"
+"selected_build(s, o) — (build, endgame_at) the next run launches on the reserved batch: 1 wide, 2 dense, 3 packed, 4 packed8, 5 packed8w, 6 packed16w, 7 packed4w"
 function selected_build(s::HIPSolver, o::Options)
     b = Ref{Int32}(0); e = Ref{Int32}(0)
     check(s, ccall((:tsat_selected_build, LIB), Cint, (Ptr{Cvoid}, Ref{Options}, Ref{Int32}, Ref{Int32}), s.handle, o, b, e), "tsat_selected_build")

@@ -153,6 +153,12 @@ def emu_packed8(pkg):
 
 
 @pytest.fixture(scope="session")
+def emu_packed4w(pkg):
+    """four trajectories per wavefront at one wavefront per SIMD (tsat_kernels_packed4w.hip)"""
+    return Emu(pkg._abi, "libtsat_emu_packed4w.so")
+
+
+@pytest.fixture(scope="session")
 def emu_packed8w(pkg):
     """eight trajectories per wavefront at one wavefront per SIMD: twelve-knot record ring, double-buffered forward chunks (tsat_kernels_packed8w.hip)"""
     return Emu(pkg._abi, "libtsat_emu_packed8w.so")

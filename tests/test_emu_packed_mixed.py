@@ -41,10 +41,10 @@ def test_packed8_build_is_the_same_solve(pkg, ol, emu, emu_packed8, T, N, es, in
     _same_bits(wide, packed)
 
 
-@pytest.mark.parametrize("which,T,N,es,integ", [("emu_packed8w", 11, 34, 1, 3), ("emu_packed8w", 19, 40, 0, 4), ("emu_packed16w", 19, 40, 1, 3),
+@pytest.mark.parametrize("which,T,N,es,integ", [("emu_packed4w", 11, 34, 1, 3), ("emu_packed8w", 11, 34, 1, 3), ("emu_packed8w", 19, 40, 0, 4), ("emu_packed16w", 19, 40, 1, 3),
                                                 ("emu_packed16w", 35, 21, 0, 3)])
 def test_one_wavefront_per_simd_builds_are_the_same_solve(pkg, ol, request, emu, which, T, N, es, integ):
-    """eight and sixteen trajectories per wavefront at one wavefront per SIMD (40 KB of LDS: a twelve-knot record ring whose slots
+    """four, eight and sixteen trajectories per wavefront at one wavefront per SIMD (40 KB of LDS: a twelve-knot record ring whose slots
     are taken modulo twelve, double-buffered forward chunks; sixteen: four line-search candidates per trajectory and sweep, so
     deeper searches go on in further sweeps): ragged horizons, partial last wavefronts, a diverging roll-out and an indefinite
     Quu next to healthy trajectories — bit-identical to the wide build, equal to the oracle"""
@@ -114,7 +114,7 @@ def test_packed_build_mixed_fates_in_one_group(pkg, ol, emu, emu_packed):
 
 
 @pytest.mark.parametrize("which,T,N,at", [("emu_packed", 11, 33, 6), ("emu_packed", 7, 20, 100), ("emu_packed8", 19, 21, 9),
-                                          ("emu_packed_mixed", 10, 30, 5), ("emu_packed8w", 19, 21, 9), ("emu_packed16w", 37, 21, 12),
+                                          ("emu_packed_mixed", 10, 30, 5), ("emu_packed4w", 9, 21, 4), ("emu_packed8w", 19, 21, 9), ("emu_packed16w", 37, 21, 12),
                                           ("emu_packed16w_mixed", 21, 30, 6)])
 def test_packed_endgame_is_the_same_solve(pkg, ol, request, monkeypatch, which, T, N, at):
     """tsat_set_endgame: once `at` trajectories are left, the wavefronts park theirs and a second launch finishes each on a

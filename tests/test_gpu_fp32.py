@@ -70,7 +70,7 @@ def _same_bits(a, b, what):
         assert np.array_equal(a["stats"][f], b["stats"][f]), (what, f)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("es", [0, 1])
 def test_gpu_mixed_short_solves_agree_outright(pkg, ol, solver, variant, es):
     """the dense, packed, packed8, packed8w and packed16w mixed builds (taken automatically below 3072 / from 3072 / from 8193 / from 6144 / from 16384 trajectories) on short

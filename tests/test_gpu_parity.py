@@ -262,17 +262,17 @@ def test_gpu_igrf_tables_attached_to_a_workload(pkg, ol, solver):
 
 
 def test_gpu_dense_and_wide_builds_agree(pkg, ol, solver):
-    """tsat_set_kernel_variant: the six fp64 builds of the solve kernel (wide, dense, packed with 4 and with 8 trajectories per
-    wavefront at two wavefronts per SIMD, with 8 and with 16 at one) give bit-identical results; batches above 1024 trajectories
+    """tsat_set_kernel_variant: the seven fp64 builds of the solve kernel (wide, dense, packed with 4 and with 8 trajectories per
+    wavefront at two wavefronts per SIMD, with 4, 8 and 16 at one) give bit-identical results; batches above 1024 trajectories
     take the dense one automatically, from 3072 / 6144 / 8193 / 16384 the packed, packed8w, packed8 and packed16w ones"""
     b = pkg.slew_setup.workload_monte_carlo(T=37, N=300, seed=12, random_orbit=True)      # (partial last wavefronts of 4, 8 and 16)
     o = oracle_options(ol, max_outer=3, max_inner=6, dj_counter_limit=1)
     out = {}
-    for name, v in (("wide", 1), ("dense", 2), ("packed", 3), ("packed8", 4), ("packed8w", 5), ("packed16w", 6)):
+    for name, v in (("wide", 1), ("dense", 2), ("packed", 3), ("packed8", 4), ("packed8w", 5), ("packed16w", 6), ("packed4w", 7)):
         solver.set_kernel_variant(v)
         out[name] = gpu_solve(pkg, solver, b, o)
     solver.set_kernel_variant(0)
-    for other in ("dense", "packed", "packed8", "packed8w", "packed16w"):
+    for other in ("dense", "packed", "packed8", "packed8w", "packed16w", "packed4w"):
         for k in ("X", "U", "K"):
             assert np.array_equal(out["wide"][k], out[other][k]), (other, k)
         for f in out["wide"]["stats"].dtype.names:      # n_forward counts executed sweeps (a packed sweep carries fewer candidates)
@@ -282,10 +282,10 @@ def test_gpu_dense_and_wide_builds_agree(pkg, ol, solver):
     o2 = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1)
     assert_same_solution(ol.solve_batch(big, o2, nthreads=8), gpu_solve(pkg, solver, big, o2))
     with pytest.raises(RuntimeError):
-        solver.set_kernel_variant(7)
+        solver.set_kernel_variant(8)
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [3, 4, 5, 6, 7])
 @pytest.mark.parametrize("es", [0, 1])
 def test_gpu_packed_builds_ragged_and_tiny_horizons(pkg, ol, solver, variant, es):
     """the packed builds forced onto small odd batches: horizons of 2 ... 97 knots inside one batch (partial 16-knot passes,

@@ -9,7 +9,7 @@ if os.environ.get("TSAT_LIB"):            # developer switch: another build of t
     pkg._abi.LIB_NAME = os.environ["TSAT_LIB"]
 from tortoisesat_jl_amd import trajopt as to, slew_setup as ss
 
-VARIANTS = {0: "auto", 1: "wide", 2: "dense", 3: "packed", 4: "packed8", 5: "packed8w", 6: "packed16w"}
+VARIANTS = {0: "auto", 1: "wide", 2: "dense", 3: "packed", 4: "packed8", 5: "packed8w", 6: "packed16w", 7: "packed4w"}
 
 
 def run(name, b, outer, inner, es=0, variants=(0,)):

@@ -5,7 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from tsat_loader import load_package
-load_package()
+pkg = load_package()
+if os.environ.get("TSAT_LIB"):            # developer switch: another build of the same library (experiments)
+    pkg._abi.LIB_NAME = os.environ["TSAT_LIB"]
 from tortoisesat_jl_amd import trajopt as to, slew_setup as ss, mpc
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 512        # 4096 over 8 GPUs
@@ -17,8 +19,11 @@ b.Btab, b.n_tab = np.ascontiguousarray(B[None]), B.shape[0]
 b.dtau[:] = 1.0
 s = to.AugmentedLagrangianSolver(None, to.AugmentedLagrangianSolverOptions())
 s.opts.opts_uncon.dJ_counter_limit = 1
+VARIANT = int(os.environ.get("TSAT_VARIANT", "0"))
 prob = to.BatchProblem.from_arrays(b)
 mpc.receding_horizon(prob, s, 5)
+if VARIANT:
+    s.set_kernel_variant(VARIANT)
 t0 = time.time()
 r = mpc.receding_horizon(prob, s, steps, plant_integrator=4)
 wall = time.time() - t0

@@ -17,7 +17,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "tortoisesat.jl_amd", "csrc")
-UNITS = ["tsat_kernels.hip", "tsat_kernels_dense.hip", "tsat_kernels_packed.hip", "tsat_kernels_packed8.hip", "tsat_kernels_packed8w.hip", "tsat_kernels_packed16w.hip", "tsat_kernels_dense_mixed.hip",
+UNITS = ["tsat_kernels.hip", "tsat_kernels_dense.hip", "tsat_kernels_packed.hip", "tsat_kernels_packed8.hip", "tsat_kernels_packed4w.hip", "tsat_kernels_packed8w.hip", "tsat_kernels_packed16w.hip", "tsat_kernels_dense_mixed.hip",
          "tsat_kernels_packed_mixed.hip", "tsat_kernels_packed8_mixed.hip", "tsat_kernels_packed8w_mixed.hip", "tsat_kernels_packed16w_mixed.hip"]
 # the variants the BASELINE configs run (rk3, isotropic inertia) first, then the worst of the others
 BENCH = ("3, 2, 1>", "3, 2, 0>")

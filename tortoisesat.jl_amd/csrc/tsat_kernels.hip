@@ -25,6 +25,7 @@ hipError_t tsat_launch_solve_packed(const KArgs<double>& a, int rk4, int inertia
 hipError_t tsat_launch_solve_packed8(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_packed8w(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_packed16w(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+hipError_t tsat_launch_solve_packed4w(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 // the mixed-precision builds (options.precision = 32: float linearisation, everything else double; -DTSAT_JAC32 in tsat_device.hpp)
 // of the dense, packed and packed8 layouts, on the very arrays of the fp64 builds (tsat_kernels_*_mixed.hip)
 hipError_t tsat_launch_solve_dense_mixed(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
@@ -32,6 +33,7 @@ hipError_t tsat_launch_solve_packed_mixed(const KArgs<double>& a, int rk4, int i
 hipError_t tsat_launch_solve_packed_mixed8(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_packed_mixed8w(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 hipError_t tsat_launch_solve_packed_mixed16w(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
+hipError_t tsat_launch_solve_packed_mixed4w(const KArgs<double>& a, int rk4, int inertia_class, int error_state, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -377,16 +379,16 @@ solve_kern_t solve_variant(const tsat_handle* h, const tsat_options* o) {
 
 // Build by batch size (measured on one MI355X, profiles/r04/build_by_batch_size.txt): one wavefront per SIMD and trajectory (wide
 // build) while the batch fits the GPU that way — 256 CUs x 4 SIMDs; two wavefronts per SIMD (dense build) up to about three times
-// that; from there the packed builds, whose wavefronts own several trajectories: four per wavefront at two wavefronts per SIMD
-// (packed); eight per wavefront at ONE wavefront per SIMD once that fills three quarters of the 1024 SIMDs, up to one full round of
+// that; from there the packed builds, whose wavefronts own several trajectories: four per wavefront, at ONE wavefront per SIMD
+// while that is one round of the 1024 SIMDs (packed4w, up to 4096), at two per SIMD beyond (packed); eight per wavefront at ONE wavefront per SIMD once that fills three quarters of the 1024 SIMDs, up to one full round of
 // them (packed8w: 40 KB of LDS keep twelve of a backward pass's sixteen knot records on the chip, all sixteen float ones);
 // eight per wavefront at two per SIMD in between (packed8); sixteen per wavefront at one per SIMD from one full round on (packed16w;
 // packed8 with a long iteration budget: selected_build).
 constexpr int64_t TSAT_WIDE_MAX_T = 1024;
-constexpr int64_t TSAT_PACKED_MIN_T = 3072;
+constexpr int64_t TSAT_PACKED_MIN_T = 3072, TSAT_PACKED4W_MAX_T = 4096;
 constexpr int64_t TSAT_PACKED8W_MIN_T = 6144, TSAT_PACKED8W_MAX_T = 8192;
 constexpr int64_t TSAT_PACKED16W_MIN_T = 16384, TSAT_LONG_BUDGET = 100;     // (budget = max_outer x max_inner)
-// the build (1 wide, 2 dense, 3 packed, 4 packed8, 5 packed8w, 6 packed16w) that (h->variant, batch size, precision) selects.
+// the build (1 wide, 2 dense, 3 packed, 4 packed8, 5 packed8w, 6 packed16w, 7 packed4w) that (h->variant, batch size, precision) selects.
 // precision = 32 — the mixed-precision builds — has no wide layout: below 3072 trajectories its dense build runs (59-knot Jacobian
 // passes in the 20 KB of two wavefronts per SIMD, which the double records do not allow)
 int selected_build(const tsat_handle* h, int precision, int64_t budget) {
@@ -397,19 +399,21 @@ int selected_build(const tsat_handle* h, int precision, int64_t budget) {
   if (h->variant == 0 && h->T >= TSAT_PACKED16W_MIN_T) return budget >= TSAT_LONG_BUDGET ? 4 : 6;
   if (h->variant == 0 && h->T > TSAT_PACKED8W_MAX_T) return 4;
   if (h->variant == 0 && h->T >= TSAT_PACKED8W_MIN_T) return 5;
-  if (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T) return 3;
+  if (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T) return h->T <= TSAT_PACKED4W_MAX_T ? 7 : 3;
   if (precision == 32) return 2;
   return (h->variant == 2 || (h->variant != 1 && h->T > TSAT_WIDE_MAX_T)) ? 2 : 1;
 }
 hipError_t launch_solve(const tsat_handle* h, const tsat_options* o, const KArgs<double>& a) {
   const int build = selected_build(h, o->precision, (int64_t)o->max_outer * o->max_inner), rk4 = o->integrator == 4;
   if (o->precision == 32) {
+    if (build == 7) return tsat_launch_solve_packed_mixed4w(a, rk4, h->inertia_class, o->error_state, h->stream);
     if (build == 6) return tsat_launch_solve_packed_mixed16w(a, rk4, h->inertia_class, o->error_state, h->stream);
     if (build == 5) return tsat_launch_solve_packed_mixed8w(a, rk4, h->inertia_class, o->error_state, h->stream);
     if (build == 4) return tsat_launch_solve_packed_mixed8(a, rk4, h->inertia_class, o->error_state, h->stream);
     if (build == 3) return tsat_launch_solve_packed_mixed(a, rk4, h->inertia_class, o->error_state, h->stream);
     return tsat_launch_solve_dense_mixed(a, rk4, h->inertia_class, o->error_state, h->stream);
   }
+  if (build == 7) return tsat_launch_solve_packed4w(a, rk4, h->inertia_class, o->error_state, h->stream);
   if (build == 6) return tsat_launch_solve_packed16w(a, rk4, h->inertia_class, o->error_state, h->stream);
   if (build == 5) return tsat_launch_solve_packed8w(a, rk4, h->inertia_class, o->error_state, h->stream);
   if (build == 4) return tsat_launch_solve_packed8(a, rk4, h->inertia_class, o->error_state, h->stream);
@@ -487,8 +491,8 @@ int tsat_batch_run(tsat_handle* h, const tsat_options* o, float* kernel_ms) {
 
 int tsat_set_kernel_variant(tsat_handle* h, int32_t variant) {
   if (!h) return -1;
-  if (!(variant >= 0 && variant <= 6))
-    return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), 3 (packed: 4 trajectories per wavefront), 4 (packed8), 5 (packed8w: 8, one wavefront per SIMD) or 6 (packed16w)");
+  if (!(variant >= 0 && variant <= 7))
+    return fail(h, -1, "variant must be 0 (automatic), 1 (wide), 2 (dense), 3 (packed: 4 trajectories per wavefront), 4 (packed8), 5 (packed8w: 8, one wavefront per SIMD) or 6 (packed16w) or 7 (packed4w: 4, one wavefront per SIMD)");
   h->variant = variant;
   return 0;
 }

@@ -274,7 +274,7 @@ class AugmentedLagrangianSolver:
 
     def selected_build(self, abi_opts):
         """(build, endgame_at) the next run with these options launches on the reserved batch: build 1 wide, 2 dense, 3 packed,
-        4 packed8, 5 packed8w, 6 packed16w; endgame_at = live count at which a packed launch parks its trajectories (0: none). tsat_selected_build."""
+        4 packed8, 5 packed8w, 6 packed16w, 7 packed4w; endgame_at = live count at which a packed launch parks its trajectories (0: none). tsat_selected_build."""
         b, e = C.c_int32(0), C.c_int32(0)
         self._check(self._lib.tsat_selected_build(self._h, C.byref(abi_opts), C.byref(b), C.byref(e)), "tsat_selected_build")
         return int(b.value), int(e.value)
