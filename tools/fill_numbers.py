@@ -51,6 +51,7 @@ ks2a, _ = stats_row("kernel_stats_c2_mixed.csv", "tsat_solve_kernel_packed_mixed
 ks2b, _ = stats_row("kernel_stats_c2_mixed.csv", "tsat_resume_kernel_packed_mixed<")
 ph = phase("phase_clocks_final.txt")
 phw = phase("phase_clocks_packed8w.txt")
+ph8 = phase("phase_clocks_packed8.txt")
 lower = lambda p: p["hbm_bytes_per_launch_lower"] / p["algorithmic_bytes_per_launch"]
 shard_ms = None
 with open(os.path.join(rdir, "straggler_stats.txt")) as f:
@@ -77,6 +78,7 @@ V = {
     "C4_MS": f"{c4['ms_per_step'] / 100:.2f}", "C4_SPS": f"{c4['value'] / 1e6:.2f}", "C4_FRAC": f"{c4['roofline']['frac']:.3f}",
     "KS_MS": f"{ks:.2f}", "KS_HIP": f"{ur['roofline']['kernel_ms']:.2f}", "KS_C2M": f"{ks2a:.1f} + {ks2b:.1f}",
     "W_FWD": f"{phw['forward sweep']:.0f}", "W_JAC": f"{phw['jacobian lanes']:.0f}", "W_RIC": f"{phw['riccati']:.0f}", "W_PAR": f"{phw['parallel passes']:.0f}",
+    "P8H_FWD": f"{ph8['forward sweep'] / 2:.0f}", "P8H_JAC": f"{ph8['jacobian lanes'] / 2:.0f}", "P8H_RIC": f"{ph8['riccati'] / 2:.0f}", "P8H_PAR": f"{ph8['parallel passes'] / 2:.0f}",
     "P_FWD": f"{ph['forward sweep']:.0f}", "P_JAC": f"{ph['jacobian lanes']:.0f}", "P_RIC": f"{ph['riccati']:.0f}", "P_PAR": f"{ph['parallel passes']:.0f}",
 }
 text = sys.stdin.read()
