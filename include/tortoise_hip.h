@@ -250,17 +250,17 @@ int  tsat_tvlqr_batch(tsat_handle* h, const tsat_tvlqr_options* o, int64_t T, in
 
 /* Build of the solve kernel used by tsat_batch_run / tsat_solve_batch / tsat_mpc_run. 0 = automatic (default), by batch size:
  *   1 wide    one trajectory per wavefront, one wavefront per SIMD (40 KB of LDS, full register file): up to 1024 trajectories;
- *   2 dense   one trajectory per wavefront, two wavefronts per SIMD (20 KB, 256 registers): 1025 .. 3071;
+ *   2 dense   one trajectory per wavefront, two wavefronts per SIMD (20 KB, 256 registers): 1025 .. 2047;
  *   3 packed  four trajectories per wavefront share every forward sweep (16 line-search candidates each) and run their
  *             backward sweeps together (Jacobian lanes = trajectory x knot x column quarter, Riccati recursion on 16 lanes per
- *             trajectory), two wavefronts per SIMD: 4097 .. 6143 trajectories;
+ *             trajectory), two wavefronts per SIMD: never automatically;
  *   4 packed8 the same with eight trajectories per wavefront (eight candidates each, two backward passes): 8193 .. 16383;
  *   5 packed8w  eight trajectories per wavefront at ONE wavefront per SIMD (40 KB of LDS: twelve of a backward pass's sixteen knot
- *             records stay on the chip instead of four, all sixteen float ones; the whole register file: no spills): 6144 .. 8192;
+ *             records stay on the chip instead of four, all sixteen float ones; the whole register file: no spills): 4097 .. 8192;
  *   6 packed16w sixteen trajectories per wavefront (four candidates each) at one wavefront per SIMD: from 16384, unless the
  *             iteration budget max_outer * max_inner is 100 or more (then packed8: a wavefront lasts as long as its slowest trajectory).
- *   7 packed4w  four trajectories per wavefront at one wavefront per SIMD: 3072 .. 4096 (the receding-horizon loop of 4096).
- * precision = 32 has the dense layout and the packed ones (below 3072 trajectories the dense one; `variant` 1 means 2 there).
+ *   7 packed4w  four trajectories per wavefront at one wavefront per SIMD: 2048 .. 4096 (the receding-horizon loop of 4096).
+ * precision = 32 has the dense layout and the packed ones (below 2048 trajectories the dense one; `variant` 1 means 2 there).
  * The builds of one precision give bit-identical results (X, U, K, iteration counts; `n_forward` counts the sweeps a build
  * executed and differs). The switch exists for tuning and for the tests. */
 int  tsat_set_kernel_variant(tsat_handle* h, int32_t variant);

@@ -73,7 +73,7 @@ def _same_bits(a, b, what):
 @pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("es", [0, 1])
 def test_gpu_mixed_short_solves_agree_outright(pkg, ol, solver, variant, es):
-    """the dense, packed, packed8, packed8w and packed16w mixed builds (taken automatically below 3072 / from 3072 / from 8193 / from 6144 / from 16384 trajectories) on short
+    """the dense, packed, packed8, packed8w and packed16w mixed builds (dense: taken automatically below 2048 trajectories; packed8w from 4097, packed8 from 8193, packed16w from 16384, packed4w 2048 .. 4096) on short
     solves: the oracle's statuses and counts, |dX| < 1e-5, |dU| < 1e-3 of the control scale"""
     b = pkg.slew_setup.workload_monte_carlo(T=16, N=120, seed=31)
     o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1, error_state=es)

@@ -58,7 +58,7 @@ def test_gpu_configs2_inputs_fp64(pkg, ol, solver):
     b = pkg.magnetic.attach_igrf_tables(solver, pkg.slew_setup.workload_monte_carlo(T=512, N=1000, seed=20190531, random_orbit=True, tables=False))
     o = oracle_options(ol, max_outer=5, max_inner=10, dj_counter_limit=1, error_state=1)
     ref = ol.solve_batch(b, o, nthreads=ol.num_procs(), want_K=False)
-    for variant in (1, 2, 3, 4, 5, 6, 7):    # wide, dense, packed (the automatic choice from 3072 trajectories on), packed8 (8193 .. 16383), packed8w (6144 .. 8192), packed16w (from 16384), packed4w (3072 .. 4096)
+    for variant in (1, 2, 3, 4, 5, 6, 7):    # wide, dense, packed, packed8 (8193 .. 16383), packed8w (4097 .. 8192), packed16w (from 16384), packed4w (2048 .. 4096)
         got = _gpu(pkg, solver, b, o, variant)
         _report(f"configs[2] inputs fp64, build {variant}", ref, got)
         assert_same_solution(ref, got)

@@ -264,7 +264,7 @@ def test_gpu_igrf_tables_attached_to_a_workload(pkg, ol, solver):
 def test_gpu_dense_and_wide_builds_agree(pkg, ol, solver):
     """tsat_set_kernel_variant: the seven fp64 builds of the solve kernel (wide, dense, packed with 4 and with 8 trajectories per
     wavefront at two wavefronts per SIMD, with 4, 8 and 16 at one) give bit-identical results; batches above 1024 trajectories
-    take the dense one automatically, from 3072 / 6144 / 8193 / 16384 the packed, packed8w, packed8 and packed16w ones"""
+    take the dense one automatically, from 2048 / 4097 / 8193 / 16384 the packed4w, packed8w, packed8 and packed16w ones"""
     b = pkg.slew_setup.workload_monte_carlo(T=37, N=300, seed=12, random_orbit=True)      # (partial last wavefronts of 4, 8 and 16)
     o = oracle_options(ol, max_outer=3, max_inner=6, dj_counter_limit=1)
     out = {}

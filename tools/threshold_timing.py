@@ -12,8 +12,8 @@ from tortoisesat_jl_amd import trajopt as to, slew_setup as ss
 base = ss.workload_monte_carlo(T=1024, N=1000, seed=20190531, random_orbit=True)
 SIZES = tuple(int(a) for a in sys.argv[1:]) or (1024, 2048, 3072, 4096, 6144, 8192)
 for T in SIZES:
-    k = T // 1024
-    rep = lambda a: np.ascontiguousarray(np.concatenate([a] * k))
+    k = (T + 1023) // 1024
+    rep = lambda a: np.ascontiguousarray(np.concatenate([a] * k)[:T])      # (tiling the 1024 draws; a ragged last tile is cut)
     b = ss.SlewBatch(base.N, base.n_tab, rep(base.x0), rep(base.xf), base.Btab, rep(base.btab_idx), rep(base.tau0), rep(base.dtau),
                      rep(base.dt), rep(base.Jmat), rep(base.Qd), rep(base.Qfd), rep(base.Rd), rep(base.ulo), rep(base.uhi), rep(base.U0))
     opts = to.AugmentedLagrangianSolverOptions(); opts.iterations = 5

@@ -378,18 +378,18 @@ solve_kern_t solve_variant(const tsat_handle* h, const tsat_options* o) {
 }
 
 // Build by batch size (measured on one MI355X, profiles/r04/build_by_batch_size.txt): one wavefront per SIMD and trajectory (wide
-// build) while the batch fits the GPU that way — 256 CUs x 4 SIMDs; two wavefronts per SIMD (dense build) up to about three times
-// that; from there the packed builds, whose wavefronts own several trajectories: four per wavefront, at ONE wavefront per SIMD
-// while that is one round of the 1024 SIMDs (packed4w, up to 4096), at two per SIMD beyond (packed); eight per wavefront at ONE wavefront per SIMD once that fills three quarters of the 1024 SIMDs, up to one full round of
-// them (packed8w: 40 KB of LDS keep twelve of a backward pass's sixteen knot records on the chip, all sixteen float ones);
-// eight per wavefront at two per SIMD in between (packed8); sixteen per wavefront at one per SIMD from one full round on (packed16w;
-// packed8 with a long iteration budget: selected_build).
+// build) while the batch fits the GPU that way — 256 CUs x 4 SIMDs; two wavefronts per SIMD (dense build) up to twice that; from
+// there the packed builds at ONE wavefront per SIMD, whose wavefronts own several trajectories (40 KB of LDS keep twelve of a
+// backward pass's sixteen knot records on the chip, all sixteen float ones): four per wavefront up to one round of the 1024 SIMDs
+// (packed4w, 2048 .. 4096), eight per wavefront up to one round (packed8w, .. 8192), sixteen from one full round on (packed16w);
+// between 8192 and 16384, and from there on with a long iteration budget, eight per wavefront at two wavefronts per SIMD
+// (packed8: selected_build). packed (four per wavefront at two per SIMD) is no longer chosen automatically.
 constexpr int64_t TSAT_WIDE_MAX_T = 1024;
-constexpr int64_t TSAT_PACKED_MIN_T = 3072, TSAT_PACKED4W_MAX_T = 4096;
-constexpr int64_t TSAT_PACKED8W_MIN_T = 6144, TSAT_PACKED8W_MAX_T = 8192;
+constexpr int64_t TSAT_PACKED_MIN_T = 2048, TSAT_PACKED4W_MAX_T = 4096;
+constexpr int64_t TSAT_PACKED8W_MAX_T = 8192;
 constexpr int64_t TSAT_PACKED16W_MIN_T = 16384, TSAT_LONG_BUDGET = 100;     // (budget = max_outer x max_inner)
 // the build (1 wide, 2 dense, 3 packed, 4 packed8, 5 packed8w, 6 packed16w, 7 packed4w) that (h->variant, batch size, precision) selects.
-// precision = 32 — the mixed-precision builds — has no wide layout: below 3072 trajectories its dense build runs (59-knot Jacobian
+// precision = 32 — the mixed-precision builds — has no wide layout: below 2048 trajectories its dense build runs (59-knot Jacobian
 // passes in the 20 KB of two wavefronts per SIMD, which the double records do not allow)
 int selected_build(const tsat_handle* h, int precision, int64_t budget) {
   if (h->variant >= 3) return h->variant;
@@ -398,8 +398,8 @@ int selected_build(const tsat_handle* h, int precision, int64_t budget) {
   // and eight per wavefront on 2048 wavefront slots lose less (65536 trajectories: 3.91 s against 4.27 s; 5 x 10: 0.47 against 0.43 s)
   if (h->variant == 0 && h->T >= TSAT_PACKED16W_MIN_T) return budget >= TSAT_LONG_BUDGET ? 4 : 6;
   if (h->variant == 0 && h->T > TSAT_PACKED8W_MAX_T) return 4;
-  if (h->variant == 0 && h->T >= TSAT_PACKED8W_MIN_T) return 5;
-  if (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T) return h->T <= TSAT_PACKED4W_MAX_T ? 7 : 3;
+  if (h->variant == 0 && h->T > TSAT_PACKED4W_MAX_T) return 5;
+  if (h->variant == 0 && h->T >= TSAT_PACKED_MIN_T) return 7;
   if (precision == 32) return 2;
   return (h->variant == 2 || (h->variant != 1 && h->T > TSAT_WIDE_MAX_T)) ? 2 : 1;
 }
