@@ -285,6 +285,45 @@ def test_gpu_dense_and_wide_builds_agree(pkg, ol, solver):
         solver.set_kernel_variant(8)
 
 
+def test_gpu_automatic_build_by_batch_size(pkg, ol, solver):
+    """tsat_selected_build: which build a batch takes by itself (include/tortoise_hip.h, tsat_set_kernel_variant) — by size, and from
+    16384 trajectories on by the iteration budget —, and that the launch it names is the one that runs: short solves of every size
+    class in the automatic build, bit for bit those of the dense build, the last wavefront of each partial"""
+    ss = pkg.slew_setup
+    base = ss.workload_monte_carlo(T=64, N=24, seed=77)
+
+    def batch(T):
+        rep = lambda a: np.ascontiguousarray(np.concatenate([a] * ((T + 63) // 64))[:T])
+        return ss.SlewBatch(base.N, base.n_tab, rep(base.x0), rep(base.xf), base.Btab, rep(base.btab_idx), rep(base.tau0), rep(base.dtau), rep(base.dt),
+                            rep(base.Jmat), rep(base.Qd), rep(base.Qfd), rep(base.Rd), rep(base.ulo), rep(base.uhi), rep(base.U0))
+
+    o = oracle_options(ol, max_outer=2, max_inner=3, dj_counter_limit=1, error_state=1)
+    long_budget = oracle_options(ol, max_outer=3, max_inner=50, dj_counter_limit=1, error_state=1)
+    solver.set_kernel_variant(0)
+    for T, want in ((1024, 1), (1025, 2), (2047, 2), (2048, 7), (4096, 7), (4097, 5), (8192, 5), (8193, 4), (16383, 4), (16387, 6)):
+        b = batch(T)
+        a = helpers.abi_options_like(o, pkg, b.N, b.n_tab)
+        solver.upload(b, a.max_linesearch)
+        assert solver.selected_build(a)[0] == want, (T, solver.selected_build(a))
+        a32 = helpers.abi_options_like(o, pkg, b.N, b.n_tab)
+        a32.precision = 32
+        assert solver.selected_build(a32)[0] == (2 if want == 1 else want), (T, "precision 32")
+        if T >= 16384:
+            al = helpers.abi_options_like(long_budget, pkg, b.N, b.n_tab)
+            assert solver.selected_build(al) == (4, 2048), solver.selected_build(al)       # long budget: eight per wavefront, endgame at an eighth
+        solver.run(a)
+        auto = solver.download()
+        if want != 2:
+            solver.set_kernel_variant(2)
+            solver.run(a)
+            dense = solver.download()
+            solver.set_kernel_variant(0)
+            for k in ("X", "U", "K"):
+                assert np.array_equal(auto[k], dense[k]), (T, k)
+        for k in ("X", "U"):                               # the batch is 64 solves repeated: so are the results, into the last partial wavefront
+            assert np.array_equal(auto[k][:64][: T % 64 or 64], auto[k][T - (T % 64 or 64):]), (T, k)
+
+
 @pytest.mark.parametrize("variant", [3, 4, 5, 6, 7])
 @pytest.mark.parametrize("es", [0, 1])
 def test_gpu_packed_builds_ragged_and_tiny_horizons(pkg, ol, solver, variant, es):
