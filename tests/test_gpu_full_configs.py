@@ -237,7 +237,8 @@ def test_gpu_large_batch_runs_are_repeatable(pkg, ol):
     """16384 DISTINCT trajectories x 1000 knots — BASELINE.json configs[2] as `bench.py --config 2` times it: random q0, random
     orbit and IGRF-12 table per trajectory — three times per build and precision: identical results run to run. The machine is
     under full memory load here, which is where an unsafe s_waitcnt count shows (the forward chunk wait of the packed builds once
-    did: loads and stores do not retire in order relative to each other) — small batches never saw it; and with 16384 different
+    did: loads and stores do not retire in order relative to each other; the record-ring waits of the one-wavefront-per-SIMD builds, which
+    count younger copies and padding copies, are of the same kind) — small batches never saw it; and with 16384 different
     slews the wavefronts diverge in their iteration counts as they do in the bench run. Both precisions are also held to the
     oracle at this size: fp64 on a sub-sample of 48 spread over the launch; precision = 32 (mixed) through the one-trajectory
     mixed build on a 1024-trajectory sub-range (same bits) and, on the sub-sample, SURVEY.md §8(d)'s bar against the oracle."""
@@ -249,7 +250,7 @@ def test_gpu_large_batch_runs_are_repeatable(pkg, ol):
     o = opts.to_abi(b.N, b.n_tab, 3, error_state=1)
     s.upload(b, o.max_linesearch)
     last = {}
-    for prec, variant in ((32, 4), (32, 3), (64, 4), (64, 3)):
+    for prec, variant in ((32, 6), (32, 5), (32, 4), (32, 3), (64, 6), (64, 5), (64, 4), (64, 3)):     # packed16w (the automatic choice), packed8w, packed8, packed
         o.precision = prec
         s.set_kernel_variant(variant)
         runs = []
@@ -263,7 +264,7 @@ def test_gpu_large_batch_runs_are_repeatable(pkg, ol):
             assert all(np.array_equal(st[f_], runs[0][0][f_]) for f_ in st.dtype.names if f_ != "n_forward"), (prec, variant)
             assert np.array_equal(X, runs[0][1]) and np.array_equal(U, runs[0][2]), (prec, variant)
         assert not np.any(runs[0][0]["status"] == pkg._abi.TSAT_DIVERGED)
-        if prec in last:      # packed and packed8 are the same solve
+        if prec in last:      # every packed build is the same solve
             assert np.array_equal(last[prec]["X"], r["X"]) and np.array_equal(last[prec]["stats"]["inner_iters"], r["stats"]["inner_iters"]), (prec, variant)
         last[prec] = r
     it = last[64]["stats"]["inner_iters"]

@@ -19,7 +19,7 @@ opts.opts_uncon.iterations = 10; opts.opts_uncon.dJ_counter_limit = 1
 s = to.AugmentedLagrangianSolver(None, opts)
 o = opts.to_abi(b.N, b.n_tab, 3, error_state=1)
 s.upload(b, o.max_linesearch)
-for prec, var in ((32, 4), (32, 3), (64, 4), (64, 3)):
+for prec, var in ((32, 6), (32, 5), (32, 7), (32, 4), (32, 3), (64, 6), (64, 5), (64, 7), (64, 4), (64, 3)):
     o.precision = prec; s.set_kernel_variant(var)
     out=[]
     for r in range(int(os.environ.get("REPS", "4"))):
