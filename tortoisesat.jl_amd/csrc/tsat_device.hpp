@@ -303,8 +303,8 @@ constexpr int L_BWD_END = L_REC + (L_BWD_SOLVE > TV_CHB * TvRec::RECS ? L_BWD_SO
 constexpr int L_BWD_END = L_REC + L_BWD_SOLVE;
 #endif
 #if defined(TSAT_PACKED)
-// packed build (tsat_packed.hpp): its own carve-up behind L_UNION, sized to the 20 480 B of two wavefronts per SIMD (fp64) or
-// to TSAT_PK_LDS_BYTES (the fp32 packed build: three wavefronts per SIMD, tsat_kernels_packed_f32.hip)
+// packed builds (tsat_packed.hpp): their own carve-up behind L_UNION, sized to the 20 480 B of two wavefronts per SIMD or to
+// TSAT_PK_LDS_BYTES (40 960 B: the one-wavefront-per-SIMD units, tsat_kernels_packed4w / 8w / 16w.hip)
 #ifndef TSAT_PK_LDS_BYTES
 #define TSAT_PK_LDS_BYTES 20480
 #endif

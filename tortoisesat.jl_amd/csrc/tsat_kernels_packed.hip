@@ -1,11 +1,12 @@
-// tsat_kernels_packed.hip — the "packed" build of the solve kernel for batches several times larger than the machine:
-// PK_G = 8 trajectories per wavefront share every forward sweep (tsat_packed.hpp), on the dense build's LDS / register budget
-// (two wavefronts per SIMD). Bit-identical results to the wide and dense builds. Separate translation unit because LDS size
-// and register budget are per-kernel compile-time facts.
-//
-// Compiled twice: itself (PK_G = 4 trajectories per wavefront, from TSAT_PACKED_MIN_T trajectories on) and through
-// tsat_kernels_packed8.hip (PK_G = 8, one single-buffered four-knot forward chunk: one forward sweep serves eight trajectories, eight line-search
-// candidates each; pays once eight trajectories per wavefront still fill the machine, from 16384 trajectories on).
+// tsat_kernels_packed.hip — the "packed" builds of the solve kernel for batches larger than the machine: PK_G trajectories per
+// wavefront share every forward sweep and run their backward sweeps together (tsat_packed.hpp). Bit-identical results to the wide
+// and dense builds. Separate translation units because LDS size, register budget and wavefronts per SIMD are per-kernel
+// compile-time facts; this file is the body of all of them:
+//   itself                      PK_G = 4, two wavefronts per SIMD (the dense build's budget: 20 KB of LDS, 256 registers)
+//   tsat_kernels_packed8.hip    PK_G = 8, two per SIMD, one single-buffered four-knot forward chunk
+//   tsat_kernels_packed4w.hip, ...8w.hip, ...16w.hip    PK_G = 4 / 8 / 16 at ONE wavefront per SIMD (40 KB, 512 registers): what
+//                               the automatic choice takes from 2048 / 4097 / 16384 trajectories on (tsat_kernels.hip)
+//   ..._mixed.hip               each of them with float linearisation (TSAT_JAC32, options.precision = 32)
 #define TSAT_DENSE 1
 #define TSAT_PACKED 1
 #ifndef TSAT_PK_WAVES

@@ -6,12 +6,15 @@
 // PK_G trajectories, lane = (trajectory g, candidate c) with PK_C = 64 / PK_G candidates alpha = 2^-(c + shift) per sweep
 // (a further sweep with shift += PK_C serves the trajectories whose search went deeper — rare), so ONE forward sweep advances
 // PK_G trajectories. The backward sweeps run jointly too, four trajectories at a time (below: 64-lane Jacobian passes into an
-// HBM workspace, a column-oriented Riccati recursion on 16 lanes per trajectory fed through an LDS ring); the lane-strided
+// LDS record ring and, for the knots it does not hold, an HBM workspace; the row-oriented Riccati recursion on 16 lanes per
+// trajectory); the lane-strided
 // passes (adopt, costs, duals) stay per trajectory and run one after the other through the very same phase functions as the
 // one-trajectory kernel. Each trajectory keeps its own position in the AL-iLQR iteration (outer / inner counters, penalty,
 // regularisation, multipliers): the driver below is the loop body of solve_trajectory (tsat_device.hpp) turned into a
 // per-trajectory state machine that is advanced between two forward sweeps. The arithmetic of a trajectory is, operation
 // for operation, that of solve_trajectory: results are bit-identical to the other builds (tests: emulator and GPU).
+// Compiled for two wavefronts per SIMD (20 KB of LDS, 256 registers: tsat_kernels_packed.hip, ...packed8.hip) and for ONE (40 KB,
+// 512 registers: ...packed4w / 8w / 16w.hip, TSAT_PK_WAVES = 1), which is what the automatic choice takes (tsat_kernels.hip).
 //
 // Replaces, like solve_trajectory, TrajectoryOptimization.solve!(prob, solver) (src/TortoiseSat.jl:199; loop body of
 // src/monte_carlo.jl:118-235) for a batch.
@@ -36,7 +39,8 @@ namespace tsat {
 #define TSAT_PK_WAVES 2
 #endif
 // One wavefront per SIMD (the `w` builds): nobody hides this wavefront's waits, so the Riccati lanes read the record of knot l - 1
-// from the ring while they work on knot l (riccati_rows does the same in the one-trajectory builds).
+// from the ring while they work on knot l (riccati_rows does the same in the one-trajectory builds) and pad their copy stream so
+// that a wait never has to drain the gain stores (riccati_group).
 constexpr bool PK_ALONE = (TSAT_PK_WAVES == 1);
 constexpr int PK_STORE = TSAT_PK_STORE;     // line-search candidates per trajectory whose rollouts a sweep keeps in HBM at most
 constexpr int PK_FEW = 3;                   // ... and while the trajectory's line searches end early (see solve_group)
@@ -67,14 +71,15 @@ static_assert(L_FWD + PK_NBUF * PK_FB <= LDS_REALS, "packed forward buffers fit 
 // ---- joint backward sweep: carve-up behind L_UNION (the forward chunk buffers overlay all of it between backward sweeps) -----
 // The PK_G trajectories of the wave run their backward sweeps TOGETHER, four at a time, 16 knots of each per chunk:
 //   Jacobian lanes   lane = (trajectory, knot): all 64 lanes linearise a knot each, all columns, and leave the finished record
-//                    (84 values of type jac_t) in the wavefront's HBM workspace a.JW — the LDS of two wavefronts per SIMD holds only
-//                    four knots per trajectory (eight with float records), and a narrower Jacobian pass repeats the primal stages on every lane of a knot
-//                    (measured 2.3x the instructions per knot); the workspace is written and read back by the same wavefront
-//                    within microseconds (42 KB per wavefront: it lives in L2 / MALL);
-//   record ring      the Riccati lanes stream the records back: PK_RING knots of the four trajectories are resident in LDS, the
-//                    record PK_RING - 1 knots ahead is copied by global_load_lds while the recursion works (the wait counts
-//                    younger LOADS only: safe whatever the stores do); the last PK_RING knots of a pass — the first the
-//                    recursion consumes — never leave the chip: their Jacobian lanes write them straight into the ring;
+//                    (84 values of type jac_t) in the LDS record ring — the last PK_RING knots of the pass, the first the recursion
+//                    consumes — or in the wavefront's HBM workspace a.JW: the LDS of two wavefronts per SIMD holds four knots per
+//                    trajectory (eight with float records), that of one wavefront per SIMD twelve (all sixteen float ones: no
+//                    workspace traffic); a narrower Jacobian pass would repeat the primal stages on every lane of a knot
+//                    (measured 2.3x the instructions per knot). The workspace is written and read back by the same wavefront
+//                    within microseconds (42 KB per wavefront);
+//   record ring      the Riccati lanes stream the workspace records back: the record PK_RING - 1 knots ahead is copied by
+//                    global_load_lds into the slot of the knot just consumed (slots modulo PK_RING) while the recursion works; the
+//                    wait counts younger LOADS only: safe whatever the stores do. A slot carries a 16-byte pad (PkRec::SLOT);
 //   Riccati lanes    PK_C = 16 lanes per trajectory = one DPP row: lane j < NH + 3 owns COLUMN j of [A|B] and of the cost-to-go; the
 //                    very step function of the one-trajectory builds (riccati_row_step, tsat_device.hpp: every cross-lane operand
 //                    is the `row_newbcast` source of the FMA that consumes it — no exchange through LDS inside a knot), four
@@ -83,7 +88,7 @@ constexpr int PK_JCH = 16;                        // knots per trajectory and Ja
 #ifndef TSAT_PK_RING
 #define TSAT_PK_RING ((sizeof(jac_t) == 8) ? 4 : 8)
 #endif
-constexpr int PK_RING = TSAT_PK_RING;      // knots of every trajectory resident in LDS during the recursion (20 KB: 4 double records, 8 float ones)
+constexpr int PK_RING = TSAT_PK_RING;      // knots of every trajectory resident in LDS during the recursion (20 KB: 4 double records, 8 float ones; 40 KB: 12 / 16)
 constexpr int PK_CPB = 16;                        // bytes per lane of a ring copy instruction (riccati_group)
 constexpr int PK_BC = 16;                         // lanes per trajectory in a backward pass
 constexpr int PK_BG = WAVE / PK_BC;               // trajectories per backward pass (4); a wave of PK_G trajectories takes PK_G / PK_BG passes
