@@ -2,7 +2,8 @@
 with it. DESIGN.md's results block is regenerated from tools/doc_templates/design_s5_results.md; every other quoted number is found
 by its context (the words around it) with the value the PREVIOUS measurement files gave — a git worktree of HEAD — and replaced.
 
-    python tools/refresh_doc_numbers.py profiles/r04        # run BEFORE committing the new measurement files
+    python tools/refresh_doc_numbers.py profiles/r04        # run BEFORE committing the new measurement files (the PMC summaries included:
+                                                            # a summary committed earlier leaves its figures to be patched by hand)
 """
 import json, os, subprocess, sys, tempfile
 
