@@ -8,6 +8,7 @@ OUT=$(realpath -m "${1:-gpurun_out/final}")
 ROOT=$(pwd)
 mkdir -p "$OUT"
 PART="${PART:-AB}"     # A: configs[1], pipeline, experiment, batch sizes; B: configs[2] (fp64, mixed), [3], [4] — one gpurun call each fits 20 minutes
+                       # S: the configs[3] shard entry of the default line on its own (bench entry, kernel statistics, PMC passes)
                        # L: the bench lines alone, once more (after the PMC summaries of A / P / B have been committed: the lines then carry `roofline.traffic`)
 if [[ "$PART" == *A* || "$PART" == *L* ]]; then
 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
@@ -84,6 +85,17 @@ TSAT_PK_G=8 python3 tools/phase_profile.py 8192 1000 5 1 > "$OUT/phase_clocks_pa
 TSAT_PK_G=16 python3 tools/phase_profile.py 16384 1000 6 1 > "$OUT/phase_clocks_packed16w.txt" 2> "$OUT/phase_clocks_packed16w.err"
 TSAT_PK_G=16 python3 tools/phase_profile.py 16384 1000 6 1 32 > "$OUT/phase_clocks_packed16w_mixed.txt" 2> "$OUT/phase_clocks_packed16w_mixed.err"
 python3 tools/phase_profile.py 16384 1000 2 1 > "$OUT/phase_clocks_dense.txt" 2> "$OUT/phase_clocks_dense.err"
+fi
+if [[ "$PART" == *S* ]]; then      # the configs[3] shard of the default line on its own: bench entry + kernel statistics + the three PMC passes
+python3 tools/shard_line.py > "$OUT/bench_c3shard.json" 2> "$OUT/bench_c3shard.err"
+cd /tmp && export TMPDIR=/tmp
+SH="python3 $ROOT/tools/shard_line.py"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c3shard" -o run -- $SH > /dev/null 2> "$OUT/stats_c3shard.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_c3shard" -o run -- $SH > /dev/null 2> "$OUT/pmc_fetch_c3shard.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c3shard" -o run -- $SH > /dev/null 2> "$OUT/pmc_write_c3shard.err"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
+  --output-format csv -d "$OUT/pmc_sq_c3shard" -o run -- $SH > /dev/null 2> "$OUT/pmc_sq_c3shard.err"
+cd "$ROOT"
 fi
 tools/ubench/valu_f64 > "$OUT/valu_f64_ubench.txt" 2>&1 || true
 # gpurun copies back at most 64 MiB: report and drop anything large (the summaries need the small CSVs and text files only)

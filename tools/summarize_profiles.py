@@ -99,6 +99,9 @@ def other(tag, bench_file, cfg, stats_csv):
         return
     shutil.copy(one(f"stats_{tag}/**/*kernel_stats.csv"), os.path.join(dst, stats_csv))
     b2 = json.loads(open(os.path.join(src, bench_file)).read().strip().splitlines()[-1])
+    if "config" not in b2:      # an `other_configs` entry of the default line on its own (tools/shard_line.py)
+        b2["config"] = {"workload": b2["workload"]}
+        b2["roofline"]["kernel_ms"] = b2["ms_per_step"]
     fe, kern = counters(f"pmc_fetch_{tag}")
     wr, _ = counters(f"pmc_write_{tag}")
     sq, _ = counters(f"pmc_sq_{tag}")
@@ -124,6 +127,9 @@ def other(tag, bench_file, cfg, stats_csv):
 other("c2", "bench_c2_fp64.json", 2, "kernel_stats_c2_fp64.csv")
 other("c2mixed", "bench_c2_mixed.json", 2, "kernel_stats_c2_mixed.csv")
 other("c3", "bench_c3.json", 3, "kernel_stats_c3.csv")
+other("c3shard", "bench_c3shard.json", 3, "kernel_stats_c3shard.csv")
+if os.path.exists(os.path.join(src, "bench_c3shard.json")):
+    shutil.copy(os.path.join(src, "bench_c3shard.json"), os.path.join(dst, "bench_c3shard.json"))
 for a, b in (("bench_c3.json", "bench_c3.json"), ("straggler_stats.txt", "straggler_stats.txt"), ("straggler_timeline.txt", "straggler_timeline.txt")):
     if os.path.exists(os.path.join(src, a)):
         with open(os.path.join(src, a)) as f:
