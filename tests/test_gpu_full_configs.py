@@ -293,6 +293,6 @@ def test_gpu_large_batch_runs_are_repeatable(pkg, ol):
     agree = np.mean(g32["stats"]["status"] == ref["stats"]["status"])
     dX = np.max(np.abs(g32["X"] - ref["X"]), axis=(1, 2))
     dU = np.max(np.abs(g32["U"] - ref["U"]), axis=(1, 2)) / np.maximum(1.0, np.max(np.abs(ref["U"]), axis=(1, 2)))
-    print(f"[configs[2] 16384 x 1000 precision = 32 (mixed packed8 = one-trajectory mixed build, bit for bit)] oracle sub-sample of 48: status "
+    print(f"[configs[2] 16384 x 1000 precision = 32 (every mixed packed build = one-trajectory mixed build, bit for bit)] oracle sub-sample of 48: status "
           f"agreement {agree:.3f}, |dX| < 1e-3 on {np.mean(dX < 1e-3):.3f} (max {dX.max():.2e}), |dU|/scale < 1e-3 on {np.mean(dU < 1e-3):.3f} (max {dU.max():.2e})")
     assert agree >= 0.97 and np.mean(dX < 1e-3) >= 0.97 and np.mean(dU < 1e-3) >= 0.97
